@@ -1,0 +1,450 @@
+"""CPU restatement (torch, fp32) of Sat-NeRF's volumetric-rendering hot path.
+
+TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  This file is the parity
+oracle for the HIP kernels in ``satnerf_amd/csrc`` and the ``cpu_baseline`` leg
+of ``bench.py``.  It is a from-spec restatement, written
+functionally over a flat ``{name: tensor}`` parameter dict instead of the
+reference's ``nn.Module`` classes.  Every function cites the reference lines
+(relative to ``/root/reference``) whose arithmetic it follows.
+
+Parity pinning: the reference ships NO tests or golden vectors for this path
+(SURVEY.md section 4), so the oracle is pinned against outputs of the reference
+itself, generated in the build container by ``tests/golden/make_golden.py`` and
+committed under ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks
+every one of them on CPU.
+
+The arithmetic is fp32 torch (ATen) because that IS the reference's arithmetic;
+a plain-C restatement would be a different floating-point program.
+"""
+from __future__ import annotations
+
+import math
+from collections import defaultdict
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------- RNG
+
+
+class TorchRng:
+    """Draws from torch's global generator in the reference's order.
+
+    Draw sites: ``rendering.py:77`` (rand_like), ``models/satnerf.py:58`` (randn),
+    ``rendering.py:33`` (rand).
+    """
+
+    def rand_like(self, ref):
+        return torch.rand_like(ref)
+
+    def randn(self, shape, device):
+        return torch.randn(shape, device=device)
+
+    def rand(self, n, m, device):
+        return torch.rand(n, m, device=device)
+
+
+class ReplayRng:
+    """Replays captured draws (a list of tensors) in order; used with the golden fixtures."""
+
+    def __init__(self, draws):
+        self.draws = [torch.as_tensor(d) for d in draws]
+        self.i = 0
+
+    def _next(self, shape):
+        d = self.draws[self.i]
+        self.i += 1
+        assert tuple(d.shape) == tuple(shape), (tuple(d.shape), tuple(shape))
+        return d
+
+    def rand_like(self, ref):
+        return self._next(ref.shape).to(ref.device)
+
+    def randn(self, shape, device):
+        return self._next(shape).to(device)
+
+    def rand(self, n, m, device):
+        return self._next((n, m)).to(device)
+
+
+# ----------------------------------------------------------------- parameters
+
+
+def params_of(model):
+    """Accepts an ``nn.Module`` (anything with ``named_parameters``) or a dict of tensors."""
+    if isinstance(model, dict):
+        return model
+    return dict(model.named_parameters())
+
+
+def satnerf_param_shapes(feat=256, tau=4, layers=8, skips=(4,)):
+    """``state_dict`` keys -> shapes of ``SatNeRF`` (``models/satnerf.py:104-153``), in module order."""
+    half = feat // 2
+    shapes = {}
+    for i in range(layers):
+        fan_in = 3 if i == 0 else (feat + 3 if i in skips else feat)
+        shapes[f"fc_net.{2 * i}.weight"] = (feat, fan_in)
+        shapes[f"fc_net.{2 * i}.bias"] = (feat,)
+    shapes["sigma_from_xyz.0.weight"] = (1, feat)
+    shapes["sigma_from_xyz.0.bias"] = (1,)
+    shapes["feats_from_xyz.weight"] = (feat, feat)
+    shapes["feats_from_xyz.bias"] = (feat,)
+    shapes["rgb_from_xyzdir.0.weight"] = (half, feat)
+    shapes["rgb_from_xyzdir.0.bias"] = (half,)
+    shapes["rgb_from_xyzdir.2.weight"] = (3, half)
+    shapes["rgb_from_xyzdir.2.bias"] = (3,)
+    shapes["sun_v_net.0.weight"] = (half, feat + 3)
+    shapes["sun_v_net.0.bias"] = (half,)
+    for j in (2, 4):
+        shapes[f"sun_v_net.{j}.weight"] = (half, half)
+        shapes[f"sun_v_net.{j}.bias"] = (half,)
+    shapes["sun_v_net.6.weight"] = (1, half)
+    shapes["sun_v_net.6.bias"] = (1,)
+    shapes["sky_color.0.weight"] = (half, 3)
+    shapes["sky_color.0.bias"] = (half,)
+    shapes["sky_color.2.weight"] = (3, half)
+    shapes["sky_color.2.bias"] = (3,)
+    shapes["beta_from_xyz.0.weight"] = (half, feat + tau)
+    shapes["beta_from_xyz.0.bias"] = (half,)
+    shapes["beta_from_xyz.2.weight"] = (1, half)
+    shapes["beta_from_xyz.2.bias"] = (1,)
+    return shapes
+
+
+def nerf_param_shapes(feat=256, layers=8, skips=(4,), map_xyz=10, map_dir=4):
+    """``state_dict`` keys -> shapes of classic ``NeRF`` (``models/nerf.py:156-177``)."""
+    in_xyz, in_dir = 2 * map_xyz * 3, 2 * map_dir * 3
+    shapes = {}
+    for i in range(layers):
+        fan_in = in_xyz if i == 0 else (feat + in_xyz if i in skips else feat)
+        shapes[f"fc_net.{2 * i}.weight"] = (feat, fan_in)
+        shapes[f"fc_net.{2 * i}.bias"] = (feat,)
+    shapes["sigma_from_xyz.0.weight"] = (1, feat)
+    shapes["sigma_from_xyz.0.bias"] = (1,)
+    shapes["feats_from_xyz.weight"] = (feat, feat)
+    shapes["feats_from_xyz.bias"] = (feat,)
+    shapes["rgb_from_xyzdir.0.weight"] = (feat // 2, feat + in_dir)
+    shapes["rgb_from_xyzdir.0.bias"] = (feat // 2,)
+    shapes["rgb_from_xyzdir.2.weight"] = (3, feat // 2)
+    shapes["rgb_from_xyzdir.2.bias"] = (3,)
+    return shapes
+
+
+def _splitmix64(x):
+    """Counter-based integer hash (numpy uint64, wraps mod 2^64) -- identical on every box."""
+    import numpy as np
+
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def procedural_uniform(shape, bound, seed):
+    """U(-bound, bound) fp32 tensor from an integer hash of (seed, index): no stored blobs needed."""
+    import numpy as np
+
+    n = int(np.prod(shape)) if len(shape) else 1
+    idx = np.arange(n, dtype=np.uint64) + (np.uint64(seed) << np.uint64(32))
+    bits = (_splitmix64(idx) >> np.uint64(40)).astype(np.float64)  # 24 random bits
+    u = (bits + 0.5) / float(1 << 24)  # (0,1)
+    vals = ((2.0 * u - 1.0) * float(bound)).astype(np.float32)
+    return torch.from_numpy(vals.reshape(shape))
+
+
+def procedural_satnerf_params(feat=256, tau=4, seed=1, layers=8, skips=(4,), scale=1.0):
+    """Deterministic SIREN-init-range weights for ``SatNeRF``.
+
+    Ranges follow ``models/nerf.py:9-21`` + ``models/satnerf.py:145-149`` (sine_init on fc_net and
+    sun_v_net weights, first_layer_sine_init on their first layers) and torch's default
+    ``nn.Linear`` init U(+-1/sqrt(fan_in)) for every bias and for the other heads.
+    """
+    shapes = satnerf_param_shapes(feat, tau, layers, skips)
+    out = {}
+    for k, (name, shp) in enumerate(shapes.items()):
+        is_w = name.endswith("weight")
+        fan_in = shp[-1] if is_w else shapes[name.replace("bias", "weight")][-1]
+        bound = 1.0 / math.sqrt(fan_in)
+        if is_w and (name.startswith("fc_net") or name.startswith("sun_v_net")):
+            first = name in ("fc_net.0.weight", "sun_v_net.0.weight")
+            bound = (1.0 / fan_in) if first else math.sqrt(6.0 / fan_in)
+        out[name] = procedural_uniform(shp, bound * scale, seed * 1000 + k)
+    return out
+
+
+def procedural_nerf_params(feat=256, seed=1):
+    shapes = nerf_param_shapes(feat)
+    out = {}
+    for k, (name, shp) in enumerate(shapes.items()):
+        is_w = name.endswith("weight")
+        fan_in = shp[-1] if is_w else shapes[name.replace("bias", "weight")][-1]
+        out[name] = procedural_uniform(shp, 1.0 / math.sqrt(fan_in), seed * 1000 + k)
+    return out
+
+
+def synthetic_rays(n_rays, seed=20240628, n_images=19, near=0.0, far_lo=0.5, far_hi=1.0, classic=False):
+    """Synthetic ray batch of SURVEY.md section 8(d).
+
+    (N,11) = o(3) d(3) near far sun_d(3), layout of ``datasets/satellite.py:60-65,239-241``; the
+    classic variant is (N,8) with near=2, far=6 (``datasets/blender.py:115-116``).
+    Returns (rays fp32, ts int64).
+    """
+    g = torch.Generator().manual_seed(seed)
+    o = torch.rand(n_rays, 3, generator=g) * 2 - 1
+    d = torch.randn(n_rays, 3, generator=g)
+    d = d / d.norm(dim=1, keepdim=True)
+    if classic:
+        rays = torch.cat([o, d, torch.full((n_rays, 1), 2.0), torch.full((n_rays, 1), 6.0)], 1)
+        return rays.float(), None
+    nr = torch.full((n_rays, 1), float(near))
+    fr = far_lo + (far_hi - far_lo) * torch.rand(n_rays, 1, generator=g)
+    az = torch.rand(n_images, generator=g) * 2 * math.pi
+    el = math.radians(30) + torch.rand(n_images, generator=g) * math.radians(50)
+    sun_tab = torch.stack([torch.sin(az) * torch.cos(el), torch.cos(az) * torch.cos(el), torch.sin(el)], 1)
+    ts = torch.randint(0, n_images, (n_rays,), generator=g)
+    rays = torch.cat([o, d, nr, fr, sun_tab[ts]], 1).float()
+    return rays, ts
+
+
+# ------------------------------------------------------------------- sampling
+
+
+def stratified_depths(rays, n_samples, u):
+    """Jittered depths along each ray: ``rendering.py:62-78`` (perturb hard-wired to 1, use_disp False)."""
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    steps = torch.linspace(0, 1, n_samples, device=rays.device)
+    z = near * (1 - steps) + far * steps  # rendering.py:67 -- this exact form
+    mid = 0.5 * (z[:, :-1] + z[:, 1:])  # :72
+    upper = torch.cat([mid, z[:, -1:]], -1)  # :74
+    lower = torch.cat([z[:, :1], mid], -1)  # :75
+    return lower + (upper - lower) * (1.0 * u)  # :77-78
+
+
+def points_along(origin, direction, z):
+    """``rendering.py:81`` -- xyz = o + d * z, (N,S,3)."""
+    return origin.unsqueeze(1) + direction.unsqueeze(1) * z.unsqueeze(2)
+
+
+def importance_depths(bins, weights, u, eps=1e-5):
+    """Inverse-CDF resampling: ``rendering.py:22-49`` with the random draw ``u`` (N,I) passed in."""
+    n_rays, n_w = weights.shape
+    w = weights + eps
+    pdf = w / torch.sum(w, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = torch.clamp_min(inds - 1, 0)
+    above = torch.clamp_max(inds, n_w)
+    cdf_b, cdf_a = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)
+    bin_b, bin_a = torch.gather(bins, 1, below), torch.gather(bins, 1, above)
+    denom = cdf_a - cdf_b
+    denom = torch.where(denom < eps, torch.ones_like(denom), denom)
+    return bin_b + (u - cdf_b) / denom * (bin_a - bin_b)
+
+
+# ------------------------------------------------------------------------ MLPs
+
+
+def satnerf_mlp(p, xyz, sun_d, t_emb, layers=8, skips=(4,), rgb_padding=0.001):
+    """``SatNeRF.forward`` (``models/satnerf.py:156-208``) on (B,3)/(B,3)/(B,tau) -> (B,9).
+
+    Columns: [0:3] albedo, [3] sigma, [4] sun visibility, [5:8] sky colour, [8] beta.
+    """
+    h = xyz
+    for i in range(layers):
+        if i in skips:
+            h = torch.cat([xyz, h], -1)  # :177, xyz first
+        h = F.linear(h, p[f"fc_net.{2 * i}.weight"], p[f"fc_net.{2 * i}.bias"])
+        h = torch.sin((30.0 if i == 0 else 1.0) * h)  # Siren, models/nerf.py:32-33; w0=30 only after fc_net.0
+    sigma = F.softplus(F.linear(h, p["sigma_from_xyz.0.weight"], p["sigma_from_xyz.0.bias"]))  # :183
+    feats = F.linear(h, p["feats_from_xyz.weight"], p["feats_from_xyz.bias"])  # :188
+    r = torch.sin(1.0 * F.linear(feats, p["rgb_from_xyzdir.0.weight"], p["rgb_from_xyzdir.0.bias"]))
+    rgb = torch.sigmoid(F.linear(r, p["rgb_from_xyzdir.2.weight"], p["rgb_from_xyzdir.2.bias"]))
+    rgb = rgb * (1 + 2 * rgb_padding) - rgb_padding  # :195
+    s = torch.cat([feats, sun_d], -1)  # :199, sun last
+    for j in (0, 2, 4):
+        s = torch.sin(1.0 * F.linear(s, p[f"sun_v_net.{j}.weight"], p[f"sun_v_net.{j}.bias"]))
+    sun_v = torch.sigmoid(F.linear(s, p["sun_v_net.6.weight"], p["sun_v_net.6.bias"]))
+    k = torch.relu(F.linear(sun_d, p["sky_color.0.weight"], p["sky_color.0.bias"]))
+    sky = torch.sigmoid(F.linear(k, p["sky_color.2.weight"], p["sky_color.2.bias"]))  # :201
+    b = torch.cat([feats, t_emb], -1)  # :204, t last
+    b = torch.sin(1.0 * F.linear(b, p["beta_from_xyz.0.weight"], p["beta_from_xyz.0.bias"]))
+    beta = F.softplus(F.linear(b, p["beta_from_xyz.2.weight"], p["beta_from_xyz.2.bias"]))
+    return torch.cat([rgb, sigma, sun_v, sky, beta], 1)
+
+
+def positional_map(x, n_freqs):
+    """``Mapping.forward`` (``models/nerf.py:53-69``): [sin(2^k x), cos(2^k x)] for k<n_freqs, NO identity term."""
+    bands = 2 ** torch.linspace(0, n_freqs - 1, n_freqs)
+    out = []
+    for f in bands:
+        out += [torch.sin(f * x), torch.cos(f * x)]
+    return torch.cat(out, -1)
+
+
+def nerf_mlp(p, xyz, dirs, layers=8, skips=(4,), rgb_padding=0.001, map_xyz=10, map_dir=4):
+    """Classic ``NeRF.forward`` (``models/nerf.py:184-227``): ReLU trunk on the encoded xyz -> (B,4)."""
+    e = positional_map(xyz, map_xyz)
+    h = e
+    for i in range(layers):
+        if i in skips:
+            h = torch.cat([e, h], -1)
+        h = torch.relu(F.linear(h, p[f"fc_net.{2 * i}.weight"], p[f"fc_net.{2 * i}.bias"]))
+    sigma = F.softplus(F.linear(h, p["sigma_from_xyz.0.weight"], p["sigma_from_xyz.0.bias"]))
+    feats = F.linear(h, p["feats_from_xyz.weight"], p["feats_from_xyz.bias"])
+    r = torch.cat([feats, positional_map(dirs, map_dir)], -1)
+    r = torch.relu(F.linear(r, p["rgb_from_xyzdir.0.weight"], p["rgb_from_xyzdir.0.bias"]))
+    rgb = torch.sigmoid(F.linear(r, p["rgb_from_xyzdir.2.weight"], p["rgb_from_xyzdir.2.bias"]))
+    rgb = rgb * (1 + 2 * rgb_padding) - rgb_padding
+    return torch.cat([rgb, sigma], 1)
+
+
+def _chunked(fn, chunk, *cols):
+    """Point-chunk loop of ``models/satnerf.py:35-40`` (kept so CPU GEMM blocking matches the reference)."""
+    n = cols[0].shape[0]
+    return torch.cat([fn(*[c[i : i + chunk] for c in cols]) for i in range(0, n, chunk)], 0)
+
+
+# ----------------------------------------------------------------- compositing
+
+
+def alpha_composite(z, sigma, noise):
+    """sigma -> alpha -> transmittance -> weights: ``models/satnerf.py:52-63``."""
+    deltas = z[:, 1:] - z[:, :-1]
+    deltas = torch.cat([deltas, 1e10 * torch.ones_like(deltas[:, :1])], -1)
+    alphas = 1 - torch.exp(-deltas * torch.relu(sigma + noise))
+    shifted = torch.cat([torch.ones_like(alphas[:, :1]), 1 - alphas + 1e-10], -1)
+    transparency = torch.cumprod(shifted, -1)[:, :-1]
+    return alphas * transparency, transparency
+
+
+def satnerf_inference(p, args, xyz, z, sun_d, t_emb, rng):
+    """``models/satnerf.inference`` (``models/satnerf.py:4-79``)."""
+    n, s = z.shape
+    sun_p = torch.repeat_interleave(sun_d, repeats=s, dim=0)
+    t_p = torch.repeat_interleave(t_emb, repeats=s, dim=0)
+    out = _chunked(lambda a, b, c: satnerf_mlp(p, a, b, c), args.chunk, xyz.reshape(-1, 3), sun_p, t_p)
+    out = out.view(n, s, 9)
+    albedo, sigma, sun_v, sky, beta = out[..., :3], out[..., 3], out[..., 4:5], out[..., 5:8], out[..., 8:9]
+    noise = rng.randn(sigma.shape, sigma.device) * args.noise_std  # :58 -- drawn even when noise_std == 0
+    weights, transparency = alpha_composite(z, sigma, noise)
+    depth = torch.sum(weights * z, -1)
+    irradiance = sun_v + (1 - sun_v) * sky  # :68
+    rgb = torch.clamp(torch.sum(weights.unsqueeze(-1) * albedo * irradiance, -2), min=0.0, max=1.0)
+    return {"rgb": rgb, "depth": depth, "weights": weights, "transparency": transparency,
+            "albedo": albedo, "sun": sun_v, "sky": sky, "beta": beta}
+
+
+def nerf_inference(p, args, xyz, z, rays_d, rng):
+    """Classic ``models/nerf.inference`` (``models/nerf.py:71-133``): no clamp, no irradiance."""
+    n, s = z.shape
+    d_p = torch.repeat_interleave(rays_d, repeats=s, dim=0)
+    out = _chunked(lambda a, b: nerf_mlp(p, a, b), args.chunk, xyz.reshape(-1, 3), d_p).view(n, s, 4)
+    rgbs, sigma = out[..., :3], out[..., 3]
+    noise = rng.randn(sigma.shape, sigma.device) * args.noise_std
+    weights, transparency = alpha_composite(z, sigma, noise)
+    return {"rgb": torch.sum(weights.unsqueeze(-1) * rgbs, -2), "depth": torch.sum(weights * z, -1),
+            "weights": weights, "transparency": transparency}
+
+
+# -------------------------------------------------------------------- render
+
+
+def render_rays(models, args, rays, ts, rng=None):
+    """``rendering.render_rays`` (``rendering.py:52-158``) for model in {sat-nerf, nerf}.
+
+    ``models``: {'coarse': params, ['fine': params], ['t': embedding weight (V,tau) or nn.Embedding]}.
+    Deviation (documented): with n_importance>0 AND sc_lambda>0 the reference
+    overwrites its accumulating dict (``rendering.py:149-152``); the oracle keeps the ``*_coarse``
+    keys and stores the fine solar-correction outputs under ``*_sc_fine``.
+    """
+    rng = rng or TorchRng()
+    s, n_imp = args.n_samples, args.n_importance
+    o, d = rays[:, 0:3], rays[:, 3:6]
+    z = stratified_depths(rays, s, rng.rand_like(torch.empty(rays.shape[0], s, device=rays.device)))
+    result = {}
+
+    def run(typ, z_cur):
+        p = params_of(models[typ])
+        xyz = points_along(o, d, z_cur)
+        if args.model == "sat-nerf":
+            if ts is None:
+                raise ValueError("sat-nerf needs per-ray image indices ts (rendering.py:100)")
+            emb = models["t"]
+            emb_w = emb if torch.is_tensor(emb) else emb.weight
+            sun_d, t_emb = rays[:, 8:11], emb_w[ts]
+            res = satnerf_inference(p, args, xyz, z_cur, sun_d, t_emb, rng)
+            if args.sc_lambda > 0:  # rendering.py:102-108
+                sc = satnerf_inference(p, args, points_along(o, sun_d, z_cur), z_cur, sun_d, t_emb, rng)
+                res["weights_sc"], res["transparency_sc"], res["sun_sc"] = sc["weights"], sc["transparency"], sc["sun"]
+        elif args.model == "nerf":
+            res = nerf_inference(p, args, xyz, z_cur, d, rng)
+        else:
+            raise ValueError(f"model {args.model} is not valid")
+        for k, v in res.items():
+            result[f"{k}_{typ}"] = v
+
+    run("coarse", z)
+    if n_imp > 0:  # rendering.py:118-156
+        mid = 0.5 * (z[:, :-1] + z[:, 1:])
+        u = rng.rand(rays.shape[0], n_imp, rays.device)
+        z_new = importance_depths(mid, result["weights_coarse"][:, 1:-1], u).detach()
+        z_fine, _ = torch.sort(torch.cat([z, z_new], -1), -1)
+        run("fine", z_fine)
+    return result
+
+
+def batched_inference(models, rays, ts, args, rng=None, grad=False):
+    """``eval_satnerf.batched_inference`` (``eval_satnerf.py:46-66``); ``grad=True`` is ``NeRF_pl.forward`` (``main.py:60-75``)."""
+    rng = rng or TorchRng()
+    results = defaultdict(list)
+    with torch.set_grad_enabled(grad):
+        for i in range(0, rays.shape[0], args.chunk):
+            r = render_rays(models, args, rays[i : i + args.chunk], ts[i : i + args.chunk] if ts is not None else None, rng)
+            for k, v in r.items():
+                results[k].append(v)
+    return {k: torch.cat(v, 0) for k, v in results.items()}
+
+
+# --------------------------------------------------------------------- losses
+
+
+def satnerf_loss(res, target, lambda_sc=0.0, beta_min=0.05):
+    """``metrics.SatNerfLoss`` (``metrics.py:21-34,56-73``), coarse only."""
+    beta = torch.sum(res["weights_coarse"].unsqueeze(-1) * res["beta_coarse"], -2) + beta_min
+    loss = ((res["rgb_coarse"] - target) ** 2 / (2 * beta**2)).mean() + (3 + torch.log(beta).mean()) / 2
+    if lambda_sc > 0:
+        loss = loss + solar_correction_loss(res, lambda_sc)
+    return loss
+
+
+def snerf_loss(res, target, lambda_sc=0.05):
+    """``metrics.SNerfLoss`` (``metrics.py:36-54``), coarse only -- used for the first 2 epochs (``main.py:128``)."""
+    loss = F.mse_loss(res["rgb_coarse"], target)
+    if lambda_sc > 0:
+        loss = loss + solar_correction_loss(res, lambda_sc)
+    return loss
+
+
+def solar_correction_loss(res, lambda_sc):
+    """``metrics.solar_correction`` (``metrics.py:27-34``): transparency_sc / weights_sc are detached."""
+    sun_sc = res["sun_sc_coarse"].squeeze()
+    term2 = torch.sum(torch.square(res["transparency_sc_coarse"].detach() - sun_sc), -1)
+    term3 = 1 - torch.sum(res["weights_sc_coarse"].detach() * sun_sc, -1)
+    return lambda_sc / 3.0 * torch.mean(term2) + lambda_sc / 3.0 * torch.mean(term3)
+
+
+def depth_loss(res, target, weights=1.0, lambda_ds=1.0):
+    """``metrics.DepthLoss`` (``metrics.py:75-92``), coarse only."""
+    return (lambda_ds / 3.0) * torch.mean(weights * (res["depth_coarse"] - target) ** 2)
+
+
+def default_args(**kw):
+    """The ``args`` attributes the hot path reads, with BASELINE config-2 defaults."""
+    a = dict(model="sat-nerf", n_samples=64, n_importance=0, chunk=5120, noise_std=0.0, sc_lambda=0.0,
+             fc_layers=8, fc_units=256, t_embbeding_tau=4, t_embbeding_vocab=30)
+    a.update(kw)
+    return SimpleNamespace(**a)

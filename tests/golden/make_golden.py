@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference, read-only).  The reference has no tests
+or known-answer vectors for this path, so these vectors -- outputs of
+``rendering.render_rays`` / ``models.satnerf.SatNeRF.forward`` / ``rendering.sample_pdf`` /
+``eval_satnerf.batched_inference`` / ``metrics.*Loss`` on fixed inputs -- are what pins the oracle.
+
+Only DATA is written (inputs, captured random draws, expected outputs).  Model weights are not
+stored: they are procedural (``oracle.satnerf_oracle.procedural_satnerf_params``: an integer hash
+mapped to the SIREN init ranges) and are loaded into the reference modules via ``load_state_dict``.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import argparse
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)  # reference first: it has top-level `models`, `datasets`, `rendering`
+
+
+class _Stub(types.ModuleType):
+    """Inert stand-in for an absent third-party import of eval_satnerf.py / metrics.py (never called)."""
+
+    def __init__(self, name):
+        super().__init__(name)
+        self.__path__ = []
+        self.__spec__ = importlib.machinery.ModuleSpec(name, None)
+
+    def __getattr__(self, item):
+        if item.startswith("__"):
+            raise AttributeError(item)
+        return _Stub(f"{self.__name__}.{item}")
+
+    def __call__(self, *a, **k):
+        return _Stub(self.__name__ + "()")
+
+
+for _m in ("kornia", "kornia.losses", "rasterio", "rpcm", "cv2", "torchvision", "torchvision.transforms", "numba",
+           "osgeo", "fire", "pytorch_lightning", "plyflatten", "utm", "pyproj", "srtm4", "affine", "PIL", "PIL.Image",
+           "rasterio.enums", "rasterio.warp", "plyflatten.utils", "osgeo.gdal"):
+    sys.modules.setdefault(_m, _Stub(_m))
+
+import rendering as ref_rendering  # noqa: E402
+from models import load_model as ref_load_model  # noqa: E402
+from models import satnerf as ref_satnerf  # noqa: E402
+
+from oracle import satnerf_oracle as O  # noqa: E402
+
+
+class Capture:
+    """Record every draw of the three RNG entry points on the path (rendering.py:33,77; models/*.py randn)."""
+
+    def __enter__(self):
+        self.draws = []
+        self._orig = (torch.rand_like, torch.randn, torch.rand)
+
+        def wrap(fn):
+            def inner(*a, **k):
+                out = fn(*a, **k)
+                self.draws.append(out.clone())
+                return out
+            return inner
+
+        torch.rand_like, torch.randn, torch.rand = (wrap(f) for f in self._orig)
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand_like, torch.randn, torch.rand = self._orig
+
+
+def ref_models(args, seed_coarse=1, seed_fine=2, emb_seed=7):
+    models = {}
+    if args.model == "sat-nerf":
+        mk = lambda s: O.procedural_satnerf_params(args.fc_units, args.t_embbeding_tau, seed=s)  # noqa: E731
+    else:
+        mk = lambda s: O.procedural_nerf_params(args.fc_units, seed=s)  # noqa: E731
+    m = ref_load_model(args)
+    m.load_state_dict(mk(seed_coarse))
+    models["coarse"] = m
+    if args.n_importance > 0:
+        f = ref_load_model(args)
+        f.load_state_dict(mk(seed_fine))
+        models["fine"] = f
+    if args.model == "sat-nerf":
+        emb = torch.nn.Embedding(args.t_embbeding_vocab, args.t_embbeding_tau)
+        emb.load_state_dict({"weight": O.procedural_uniform((args.t_embbeding_vocab, args.t_embbeding_tau), 1.0, emb_seed)})
+        models["t"] = emb
+    return models
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def render_case(name, n_rays, ray_seed, **kw):
+    args = O.default_args(**kw)
+    classic = args.model == "nerf"
+    rays, ts = O.synthetic_rays(n_rays, seed=ray_seed, classic=classic)
+    models = ref_models(args)
+    with torch.no_grad(), Capture() as cap:
+        res = ref_rendering.render_rays(models, args, rays, ts)
+    arrays = {"rays": rays, "cfg": np.array(repr(vars(args)))}
+    if ts is not None:
+        arrays["ts"] = ts
+    for i, d in enumerate(cap.draws):
+        arrays[f"draw{i}"] = d
+    for k, v in res.items():
+        arrays["out_" + k] = v.contiguous()
+    save(name, **arrays)
+
+
+def main():
+    argparse.ArgumentParser(description=__doc__).parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+
+    # full render_rays variants
+    render_case("satnerf_coarse", 96, 11)
+    render_case("satnerf_sc", 40, 12, sc_lambda=0.1)
+    render_case("satnerf_fine", 40, 13, n_importance=64)
+    render_case("satnerf_noise", 40, 14, noise_std=0.5)
+    render_case("satnerf_s128", 24, 15, n_samples=128)
+    render_case("satnerf_feat512", 24, 16, fc_units=512, t_embbeding_tau=16)
+    render_case("satnerf_s50_ragged", 37, 17, n_samples=50, chunk=999)
+    render_case("nerf_coarse_fine", 32, 18, model="nerf", n_importance=32)
+
+    # SatNeRF.forward alone on a ragged batch of points
+    args = O.default_args()
+    model = ref_models(args)["coarse"]
+    g = torch.Generator().manual_seed(21)
+    xyz = torch.rand(257, 3, generator=g) * 2 - 1
+    sun = torch.randn(257, 3, generator=g)
+    sun = sun / sun.norm(dim=1, keepdim=True)
+    t = torch.rand(257, 4, generator=g) * 2 - 1
+    with torch.no_grad():
+        out = model(xyz, input_sun_dir=sun, input_t=t)
+        sig = model(xyz, input_sun_dir=sun, input_t=t, sigma_only=True)
+    save("mlp_forward", xyz=xyz, sun=sun, t=t, out=out, sigma_only=sig)
+
+    # sample_pdf alone, random and deterministic
+    g = torch.Generator().manual_seed(22)
+    bins = torch.sort(torch.rand(33, 63, generator=g), -1)[0]
+    w = torch.rand(33, 62, generator=g) ** 4
+    w[3] = 0.0  # an all-zero row: every bin hits the eps floor
+    w[4, 10:40] = 0.0  # flat stretches inside the cdf (denom<eps branch)
+    with Capture() as cap:
+        z_rand = ref_rendering.sample_pdf(bins, w, 48, det=False)
+    z_det = ref_rendering.sample_pdf(bins, w, 48, det=True)
+    save("sample_pdf", bins=bins, weights=w, u=cap.draws[0], z_rand=z_rand, z_det=z_det)
+
+    # compositing alone with extreme sigmas, through the reference's inference() around a canned model
+    class Canned(torch.nn.Module):
+        number_of_outputs = 9
+
+        def __init__(self, table):
+            super().__init__()
+            self.table, self.pos = table, 0
+
+        def forward(self, x, input_dir=None, input_sun_dir=None, input_t=None):
+            out = self.table[self.pos : self.pos + x.shape[0]]
+            self.pos += x.shape[0]
+            return out
+
+    g = torch.Generator().manual_seed(23)
+    n, s = 29, 64
+    raw = torch.rand(n * s, 9, generator=g)
+    sig = torch.exp(torch.randn(n, s, generator=g) * 4)  # 1e-7 .. 1e7
+    sig[0] = 0.0
+    sig[1] = 1e-12
+    sig[2] = 1e9
+    sig[3, :32] = -5.0  # relu clips
+    raw[:, 3] = sig.reshape(-1)
+    z = torch.sort(torch.rand(n, s, generator=g), -1)[0]
+    z[5, 10] = z[5, 11]  # a zero-length interval
+    a2 = O.default_args(noise_std=0.7, chunk=1000)
+    with torch.no_grad(), Capture() as cap:
+        res = ref_satnerf.inference(Canned(raw), a2, torch.zeros(n, s, 3), z, sun_d=torch.zeros(n, 3), rays_t=torch.zeros(n, 4))
+    save("composite_extreme", raw=raw.view(n, s, 9), z=z, noise=cap.draws[0], noise_std=np.float32(0.7),
+         **{"out_" + k: v.contiguous() for k, v in res.items()})
+
+    # backward: grads of sum(rgb)+sum(depth)+sum(beta*w) wrt representative params + the embedding
+    args = O.default_args()
+    rays, ts = O.synthetic_rays(64, seed=24)
+    models = ref_models(args)
+    with Capture() as cap:
+        res = ref_rendering.render_rays(models, args, rays, ts)
+    loss = res["rgb_coarse"].sum() + res["depth_coarse"].sum() + (res["weights_coarse"].unsqueeze(-1) * res["beta_coarse"]).sum()
+    loss.backward()
+    grads = {"grad_" + k: v.grad for k, v in models["coarse"].named_parameters()
+             if k in ("fc_net.0.weight", "fc_net.0.bias", "fc_net.8.weight", "fc_net.14.bias", "sigma_from_xyz.0.weight",
+                      "feats_from_xyz.weight", "rgb_from_xyzdir.2.weight", "sun_v_net.0.weight", "sun_v_net.6.bias",
+                      "sky_color.0.weight", "sky_color.2.bias", "beta_from_xyz.0.weight", "beta_from_xyz.2.weight")}
+    save("backward", rays=rays, ts=ts, loss=loss.detach(), grad_embedding=models["t"].weight.grad,
+         **{f"draw{i}": d for i, d in enumerate(cap.draws)}, **grads)
+
+    # batched_inference with a ragged last chunk + the three losses and a few loss gradients
+    import eval_satnerf as ref_eval  # noqa: E402  (imports the stubs above)
+    import metrics as ref_metrics  # noqa: E402
+
+    args = O.default_args(chunk=100, sc_lambda=0.05)
+    rays, ts = O.synthetic_rays(250, seed=25)
+    models = ref_models(args)
+    with Capture() as cap:
+        res = ref_eval.batched_inference(models, rays, ts, args)
+    arrays = {"rays": rays, "ts": ts}
+    arrays.update({f"draw{i}": d for i, d in enumerate(cap.draws)})
+    arrays.update({"out_" + k: v for k, v in res.items() if k in ("rgb_coarse", "depth_coarse", "weights_coarse", "sun_sc_coarse")})
+    g = torch.Generator().manual_seed(26)
+    target = torch.rand(250, 3, generator=g)
+    dtarget, dweights = torch.rand(250, generator=g), torch.rand(250, generator=g)
+    # the train-time twin of batched_inference (main.py:60-75) = the same loop with grad
+
+    class Replay:
+        def __init__(self, draws):
+            self.d, self.i = list(draws), 0
+
+        def __enter__(self):
+            self._orig = (torch.rand_like, torch.randn, torch.rand)
+
+            def nxt(*a, **k):
+                out = self.d[self.i]
+                self.i += 1
+                return out.clone()
+
+            torch.rand_like = torch.randn = torch.rand = nxt
+            return self
+
+        def __exit__(self, *exc):
+            torch.rand_like, torch.randn, torch.rand = self._orig
+
+    with Replay(cap.draws):
+        outs = [ref_rendering.render_rays(models, args, rays[i:i + 100], ts[i:i + 100]) for i in range(0, 250, 100)]
+    resg = {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+    l_sat, _ = ref_metrics.SatNerfLoss(lambda_sc=0.05)(resg, target)
+    l_s, _ = ref_metrics.SNerfLoss(lambda_sc=0.05)(resg, target)
+    l_d, _ = ref_metrics.DepthLoss(lambda_ds=1000.0)(resg, dtarget, dweights)
+    (l_sat + l_d).backward()
+    arrays.update(target=target, dtarget=dtarget, dweights=dweights, loss_satnerf=l_sat.detach(), loss_snerf=l_s.detach(),
+                  loss_depth=l_d.detach(),
+                  grad_fc_net_6_weight=models["coarse"].fc_net[6].weight.grad,
+                  grad_beta_2_weight=models["coarse"].beta_from_xyz[2].weight.grad,
+                  grad_sun_v_0_bias=models["coarse"].sun_v_net[0].bias.grad,
+                  grad_embedding=models["t"].weight.grad)
+    save("batched_losses", **arrays)
+
+
+if __name__ == "__main__":
+    main()

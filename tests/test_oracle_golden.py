@@ -1,0 +1,114 @@
+"""Pins oracle/satnerf_oracle.py against outputs of the reference itself (tests/golden/*.npz).
+
+The reference has no tests for this path; these vectors were produced by tests/golden/make_golden.py
+importing /root/reference in the build container.  CPU only.
+"""
+import pytest
+import torch
+
+from oracle import satnerf_oracle as O
+from tests.helpers import golden_cfg, golden_draws, load_golden, make_models, maxnorm_rel
+
+TOL = 1e-6  # restatement vs reference on CPU: exact or <=1e-6
+
+RENDER_CASES = ["satnerf_coarse", "satnerf_sc", "satnerf_fine", "satnerf_noise", "satnerf_s128", "satnerf_feat512",
+                "satnerf_s50_ragged", "nerf_coarse_fine"]
+
+
+@pytest.mark.parametrize("name", RENDER_CASES)
+def test_render_rays_matches_reference(name):
+    g = load_golden(name)
+    args = golden_cfg(g)
+    models = make_models(args)
+    ts = g["ts"] if "ts" in g else None
+    with torch.no_grad():
+        res = O.render_rays(models, args, g["rays"], ts, O.ReplayRng(golden_draws(g)))
+    expected = {k[4:]: v for k, v in g.items() if k.startswith("out_")}
+    assert set(res) == set(expected)
+    for k, v in expected.items():
+        assert res[k].shape == v.shape, k
+        assert maxnorm_rel(res[k], v) <= TOL, (k, maxnorm_rel(res[k], v))
+
+
+def test_mlp_forward_matches_reference():
+    g = load_golden("mlp_forward")
+    p = O.procedural_satnerf_params(256, 4, seed=1)
+    with torch.no_grad():
+        out = O.satnerf_mlp(p, g["xyz"], g["sun"], g["t"])
+    assert out.shape == (257, 9)
+    assert maxnorm_rel(out, g["out"]) <= TOL
+    assert maxnorm_rel(out[:, 3:4], g["sigma_only"]) <= TOL
+
+
+def test_sample_pdf_matches_reference():
+    g = load_golden("sample_pdf")
+    z = O.importance_depths(g["bins"], g["weights"], g["u"])
+    assert maxnorm_rel(z, g["z_rand"]) <= TOL
+    u_det = torch.linspace(0, 1, 48).expand(33, 48)
+    assert maxnorm_rel(O.importance_depths(g["bins"], g["weights"], u_det), g["z_det"]) <= TOL
+
+
+def test_composite_extreme_matches_reference():
+    g = load_golden("composite_extreme")
+    raw, z = g["raw"], g["z"]
+    noise = g["noise"] * float(g["noise_std"])
+    w, t = O.alpha_composite(z, raw[..., 3], noise)
+    assert torch.equal(w, g["out_weights"]) or maxnorm_rel(w, g["out_weights"]) <= TOL
+    assert maxnorm_rel(t, g["out_transparency"]) <= TOL
+    depth = torch.sum(w * z, -1)
+    irr = raw[..., 4:5] + (1 - raw[..., 4:5]) * raw[..., 5:8]
+    rgb = torch.clamp(torch.sum(w.unsqueeze(-1) * raw[..., :3] * irr, -2), 0.0, 1.0)
+    assert maxnorm_rel(depth, g["out_depth"]) <= TOL
+    assert maxnorm_rel(rgb, g["out_rgb"]) <= TOL
+
+
+def test_backward_matches_reference():
+    g = load_golden("backward")
+    args = O.default_args()
+    models = make_models(args)
+    for v in models["coarse"].values():
+        v.requires_grad_(True)
+    models["t"].requires_grad_(True)
+    res = O.render_rays(models, args, g["rays"], g["ts"], O.ReplayRng(golden_draws(g)))
+    loss = res["rgb_coarse"].sum() + res["depth_coarse"].sum() + (res["weights_coarse"].unsqueeze(-1) * res["beta_coarse"]).sum()
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    checked = 0
+    for k, v in g.items():
+        if k.startswith("grad_") and k != "grad_embedding":
+            assert maxnorm_rel(models["coarse"][k[5:]].grad, v) <= 1e-5, k
+            checked += 1
+    assert checked == 13
+    assert maxnorm_rel(models["t"].grad, g["grad_embedding"]) <= 1e-5
+
+
+def test_batched_inference_and_losses_match_reference():
+    g = load_golden("batched_losses")
+    args = O.default_args(chunk=100, sc_lambda=0.05)
+    models = make_models(args)
+    res = O.batched_inference(models, g["rays"], g["ts"], args, O.ReplayRng(golden_draws(g)))
+    for k in ("rgb_coarse", "depth_coarse", "weights_coarse", "sun_sc_coarse"):
+        assert res[k].shape == g["out_" + k].shape
+        assert maxnorm_rel(res[k], g["out_" + k]) <= TOL, k
+    for v in models["coarse"].values():
+        v.requires_grad_(True)
+    models["t"].requires_grad_(True)
+    resg = O.batched_inference(models, g["rays"], g["ts"], args, O.ReplayRng(golden_draws(g)), grad=True)
+    l_sat = O.satnerf_loss(resg, g["target"], lambda_sc=0.05)
+    l_s = O.snerf_loss(resg, g["target"], lambda_sc=0.05)
+    l_d = O.depth_loss(resg, g["dtarget"], g["dweights"], lambda_ds=1000.0)
+    for got, want in ((l_sat, g["loss_satnerf"]), (l_s, g["loss_snerf"]), (l_d, g["loss_depth"])):
+        assert abs(got.item() - float(want)) <= 1e-5 * abs(float(want))
+    (l_sat + l_d).backward()
+    assert maxnorm_rel(models["coarse"]["fc_net.6.weight"].grad, g["grad_fc_net_6_weight"]) <= 1e-4
+    assert maxnorm_rel(models["coarse"]["beta_from_xyz.2.weight"].grad, g["grad_beta_2_weight"]) <= 1e-4
+    assert maxnorm_rel(models["coarse"]["sun_v_net.0.bias"].grad, g["grad_sun_v_0_bias"]) <= 1e-4
+    assert maxnorm_rel(models["t"].grad, g["grad_embedding"]) <= 1e-4
+
+
+def test_procedural_params_are_reproducible():
+    a = O.procedural_satnerf_params(256, 4, seed=1)
+    assert sum(v.numel() for v in a.values()) == 662537
+    assert abs(a["fc_net.0.weight"].abs().max().item() - 1 / 3) < 1e-3
+    b = O.procedural_satnerf_params(256, 4, seed=1)
+    assert all(torch.equal(a[k], b[k]) for k in a)
