@@ -1,0 +1,118 @@
+/*
+ * libsatrender -- C ABI of the MI355X-native Sat-NeRF volumetric-rendering hot path.
+ *
+ * The reference (centreborelli/satnerf) is pure Python/PyTorch and has no FFI; each entry point below
+ * replaces the ATen op sequence of the reference lines it cites (paths relative to the reference
+ * repository root).  The host side (the satnerf_amd Python package) binds these with ctypes; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into memory owned by the caller (PyTorch); the library
+ *     borrows it for the duration of the enqueue and allocates nothing;
+ *   - all tensors fp32, contiguous, row-major unless stated; `ts` is int64;
+ *   - `stream` is a hipStream_t (0 = default stream); calls only enqueue, they never synchronise;
+ *   - return value 0 = ok, non-zero = error, text via sr_last_error() (thread-local);
+ *   - gfx950 (MI355X) only.
+ */
+#ifndef SATRENDER_H
+#define SATRENDER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR_VERSION 100 /* major*10000 + minor*100 + patch */
+
+/* numeric modes of the fused MLP (SURVEY.md section 7 "Hard parts") */
+#define SR_MODE_BF16 1   /* single-pass bf16 MFMA, fp32 accumulate -- throughput mode            */
+#define SR_MODE_BF16X3 3 /* hi*hi + lo*hi + hi*lo split on the same MFMA pipe -- parity mode (~2e-6) */
+
+int sr_version(void);
+const char* sr_last_error(void);
+
+/* ---- stream geometry (host-side, no GPU needed) -------------------------------------------------
+ * The fused MLP consumes its weights as one linear "stream" of 1-KiB MFMA-A-fragment pieces in
+ * consumption order.  These return the element counts the host packer
+ * (satnerf_amd/packing.py) must produce for a given network shape; -1 on an unsupported shape. */
+int64_t sr_fwd_stream_elems(int feat, int tau);  /* bf16 elements of the forward stream (per hi/lo plane) */
+int64_t sr_bwd_stream_elems(int feat, int tau);  /* bf16 elements of the transposed (dX) stream          */
+int64_t sr_act_elems_per_tile(int feat);         /* bf16 elements saved per 32-point tile in training     */
+
+/* ---- weight packing:  replaces nothing in the reference (its weights feed addmm directly) ---------
+ * out_hi[i] = bf16_rne(src[idx[i]] * scale[i]);  out_lo[i] = bf16_rne(src[idx[i]]*scale[i] - out_hi[i])
+ * (out_lo may be NULL).  idx < 0 selects the constant 0. */
+int sr_pack_stream(const float* src, const int32_t* idx, const float* scale, int64_t n,
+                   uint16_t* out_hi, uint16_t* out_lo, void* stream);
+
+/* out[i] = src[idx[i]] * scale[i] in fp32 (idx < 0 -> 0): builds the fc_net.0 table `l0` of sr_satnerf_mlp_fwd */
+int sr_gather_scale_f32(const float* src, const int32_t* idx, const float* scale, int64_t n, float* out, void* stream);
+
+/* grad[e] (+)= gscale[e] * dstream[gidx[e]]  -- the inverse gather of sr_pack_stream for weight grads */
+int sr_unpack_grads(const float* dstream, const int32_t* gidx, const float* gscale, int64_t n_params,
+                    float* grad, int accumulate, void* stream);
+
+/* ---- stratified sampling: rendering.py:62-78 -----------------------------------------------------
+ * rays (N, ray_stride>=8) with near at column 6, far at column 7; u (N,S) in [0,1) -> z_vals (N,S). */
+int sr_ray_sample_fwd(const float* rays, int ray_stride, const float* u, int64_t n_rays, int n_samples,
+                      float* z_vals, void* stream);
+
+/* ---- sky-colour head, once per ray: models/satnerf.py:138-143,201 ---------------------------------
+ * sun (N, sun_stride) -> sky (N,3) = sigmoid(W2 relu(W1 sun + b1) + b2);  W1 (H,3) b1 (H) W2 (3,H) b2 (3) */
+int sr_sky_fwd(const float* sun, int sun_stride, int64_t n, int hidden, const float* w1, const float* b1,
+               const float* w2, const float* b2, float* sky, void* stream);
+
+/* ---- fused SatNeRF MLP over points: models/satnerf.py:20-40 (repeat_interleave + chunk loop) and
+ *      SatNeRF.forward models/satnerf.py:156-208 (+ Siren models/nerf.py:23-33) ------------------------
+ * point p (0 <= p < n_points) belongs to row r = p / n_samples of the per-ray arrays:
+ *   xyz   = org[r] + dir[r] * z[p]           (rendering.py:81; dir==NULL or z==NULL -> xyz = org[r])
+ *   sun_d = sun[r],  t = temb[ts ? ts[r] : r]  (rendering.py:99-100, nn.Embedding lookup)
+ * outputs (any may be NULL): albedo (P,3), sigma (P), sun_v (P), beta (P)   [models/satnerf.py:45-49]
+ * stream_hi/lo: packed forward stream from sr_pack_stream (lo required iff mode == SR_MODE_BF16X3)
+ * l0: (feat,4) fp32 rows [w_x, w_y, w_z, b] of fc_net.0, each multiplied by 30/(2*pi), in slot order
+ * acts: NULL, or training workspace of sr_act_elems_per_tile(feat) * ceil(P/32) bf16 elements. */
+typedef struct sr_mlp_inputs {
+  const float* org;
+  int org_stride;
+  const float* dir;
+  int dir_stride;
+  const float* sun;
+  int sun_stride;
+  const float* z;
+  const float* temb;
+  const int64_t* ts;
+  int64_t n_points;
+  int n_samples;
+} sr_mlp_inputs;
+
+int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, int mode, const uint16_t* stream_hi,
+                       const uint16_t* stream_lo, const float* l0, float* albedo, float* sigma, float* sun_v,
+                       float* beta, uint16_t* acts, void* stream);
+
+/* ---- sigma -> alpha compositing: models/satnerf.py:52-70 ------------------------------------------
+ * noise may be NULL (== noise_std 0).  sky is per ray (N,3).  Outputs: weights, transparency (N,S),
+ * depth (N), rgb (N,3) (clamped to [0,1] when clamp_rgb != 0; the classic nerf variant does not clamp,
+ * models/nerf.py:128, and passes sun_v = sky = NULL). */
+int sr_composite_fwd(const float* z_vals, const float* sigma, const float* noise, float noise_std,
+                     const float* albedo, const float* sun_v, const float* sky, int64_t n_rays, int n_samples,
+                     int clamp_rgb, float* weights, float* transparency, float* depth, float* rgb, void* stream);
+
+/* closed-form backward of sr_composite_fwd.  Upstream grads g_* may be NULL (=0).
+ * Produces d_sigma (N,S), d_albedo (N,S,3), d_sun_v (N,S), d_sky (N,3); any output may be NULL. */
+int sr_composite_bwd(const float* z_vals, const float* sigma, const float* noise, float noise_std,
+                     const float* albedo, const float* sun_v, const float* sky, const float* weights,
+                     const float* transparency, const float* rgb_unclamped_or_null, int64_t n_rays, int n_samples,
+                     int clamp_rgb, const float* g_rgb, const float* g_depth, const float* g_weights,
+                     const float* g_transparency, float* d_sigma, float* d_albedo, float* d_sun_v, float* d_sky,
+                     void* stream);
+
+/* ---- importance resampling + merge: rendering.py:10-49 and :121-125 -------------------------------
+ * z_coarse (N,S) sorted, weights_coarse (N,S), u (N,I) -> z_fine (N,S+I) = sort(cat(z_coarse, z_new)). */
+int sr_sample_pdf_merge(const float* z_coarse, const float* weights_coarse, const float* u, int64_t n_rays,
+                        int n_samples, int n_importance, float eps, float* z_fine, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SATRENDER_H */

@@ -1,0 +1,72 @@
+"""ctypes binding of libsatrender.so (the C ABI declared in include/satrender.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is NO fallback: if the
+shared object is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsatrender.so")
+
+MODE_BF16 = 1
+MODE_BF16X3 = 3
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class MlpInputs(C.Structure):
+    _fields_ = [("org", _vp), ("org_stride", _i), ("dir", _vp), ("dir_stride", _i), ("sun", _vp), ("sun_stride", _i),
+                ("z", _vp), ("temb", _vp), ("ts", _vp), ("n_points", _i64), ("n_samples", _i)]
+
+
+# name -> (restype, argtypes); must list every symbol of include/satrender.h (tests/test_cabi.py checks this)
+SIGNATURES = {
+    "sr_version": (_i, []),
+    "sr_last_error": (C.c_char_p, []),
+    "sr_fwd_stream_elems": (_i64, [_i, _i]),
+    "sr_bwd_stream_elems": (_i64, [_i, _i]),
+    "sr_act_elems_per_tile": (_i64, [_i]),
+    "sr_pack_stream": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "sr_unpack_grads": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _vp]),
+    "sr_gather_scale_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "sr_ray_sample_fwd": (_i, [_vp, _i, _vp, _i64, _i, _vp, _vp]),
+    "sr_sky_fwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sr_satnerf_mlp_fwd": (_i, [C.POINTER(MlpInputs), _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sr_composite_fwd": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sr_composite_bwd": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                              _vp, _vp, _vp]),
+    "sr_sample_pdf_merge": (_i, [_vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp]),
+}
+
+_lib = None
+
+
+class SatRenderError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SatRenderError(
+                f"{LIB_PATH} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "satnerf_amd has no CPU or PyTorch fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; non-zero status raises with sr_last_error()."""
+    handle = lib()
+    rc = getattr(handle, name)(*args)
+    if rc != 0:
+        raise SatRenderError(f"{name} failed (status {rc}): {handle.sr_last_error().decode(errors='replace')}")

@@ -1,0 +1,66 @@
+// Shared device/host helpers for libsatrender (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/satrender.h"
+
+namespace sr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define SR_REQUIRE(cond, ...)  \
+  do {                         \
+    if (!(cond)) {             \
+      sr::set_error(__VA_ARGS__); \
+      return 1;                \
+    }                          \
+  } while (0)
+
+// ---- bf16 helpers -----------------------------------------------------------------------------
+// Two fp32 -> one dword of two bf16 (RNE): element 0 in the low half.  Lowers to v_cvt_pk_bf16_f32.
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo_to_f32(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16_hi_to_f32(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// hi/lo split of a pair: hi = bf16(x), lo = bf16(x - hi).
+__device__ __forceinline__ void split_bf16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = pack_bf16x2(a, b);
+  lo = pack_bf16x2(a - bf16_lo_to_f32(hi), b - bf16_hi_to_f32(hi));
+}
+
+// sin(2*pi*x).  v_sin_f32 takes revolutions; valid for |x| <= 256.
+__device__ __forceinline__ float sin_rev_fast(float x) { return __builtin_amdgcn_sinf(x); }
+
+// sin(2*pi*x) to ~1 ulp-of-1: exact range reduction r = x - rint(x) in [-0.5,0.5], fold to
+// [-0.25,0.25] by symmetry, then an odd degree-11 Taylor polynomial in t = 2*pi*r.
+__device__ __forceinline__ float sin_rev_precise(float x) {
+  float r = x - __builtin_rintf(x);              // exact in fp32
+  float a = __builtin_fabsf(r);
+  float f = (a > 0.25f) ? (0.5f - a) : a;        // sin(pi - t) = sin(t); exact subtraction
+  f = __builtin_copysignf(f, r);
+  const float t = f * 6.28318530717958647692f;
+  const float t2 = t * t;
+  float p = -2.5052108385441718775e-8f;           // -1/11!
+  p = __builtin_fmaf(p, t2, 2.7557319223985890653e-6f);   // 1/9!
+  p = __builtin_fmaf(p, t2, -1.9841269841269841253e-4f);  // -1/7!
+  p = __builtin_fmaf(p, t2, 8.3333333333333332177e-3f);   // 1/5!
+  p = __builtin_fmaf(p, t2, -1.6666666666666665741e-1f);  // -1/3!
+  return __builtin_fmaf(p * t2, t, t);
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // torch Softplus(beta=1,threshold=20)
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+}  // namespace sr

@@ -1,0 +1,52 @@
+// C ABI of the fused forward MLP: argument checks + dispatch to the per-mode translation units.
+#include "common.h"
+#include "mlp_layout.h"
+#include "mlp_params.h"
+
+namespace sr {
+int launch_fwd_p1a1(const FwdParams&, bool, hipStream_t);
+int launch_fwd_p1a2(const FwdParams&, bool, hipStream_t);
+int launch_fwd_p3a1(const FwdParams&, bool, hipStream_t);
+int launch_fwd_p3a2(const FwdParams&, bool, hipStream_t);
+}  // namespace sr
+using namespace sr;
+extern "C" int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, int mode, const uint16_t* stream_hi,
+                                  const uint16_t* stream_lo, const float* l0, float* albedo, float* sigma, float* sun_v,
+                                  float* beta, uint16_t* acts, void* stream) {
+  SR_REQUIRE(in != nullptr, "sr_satnerf_mlp_fwd: null inputs");
+  SR_REQUIRE(feat == kFeat, "sr_satnerf_mlp_fwd: feat=%d unsupported (this build handles %d)", feat, kFeat);
+  SR_REQUIRE(tau >= 1 && tau <= 24, "sr_satnerf_mlp_fwd: tau=%d unsupported (1..24)", tau);
+  SR_REQUIRE(mode == SR_MODE_BF16 || mode == SR_MODE_BF16X3, "sr_satnerf_mlp_fwd: bad mode %d", mode);
+  SR_REQUIRE(stream_hi && l0 && in->org && in->sun && in->temb, "sr_satnerf_mlp_fwd: null pointer argument");
+  SR_REQUIRE(mode != SR_MODE_BF16X3 || stream_lo, "sr_satnerf_mlp_fwd: BF16X3 needs the lo plane");
+  SR_REQUIRE(in->n_samples >= 1, "sr_satnerf_mlp_fwd: n_samples must be >= 1");
+  if (in->n_points <= 0) return 0;
+  FwdParams p;
+  p.in = *in;
+  p.stream_hi = (const char*)stream_hi;
+  p.stream_lo = (const char*)stream_lo;
+  p.l0 = (const float4*)l0;
+  p.albedo = albedo, p.sigma = sigma, p.sun_v = sun_v, p.beta = beta;
+  p.acts = (uint4*)acts;
+  p.tau = tau;
+  hipStream_t st = (hipStream_t)stream;
+  const bool save = acts != nullptr;
+  const int auxs = aux_steps(tau);
+  if (mode == SR_MODE_BF16) return auxs == 1 ? launch_fwd_p1a1(p, save, st) : launch_fwd_p1a2(p, save, st);
+  return auxs == 1 ? launch_fwd_p3a1(p, save, st) : launch_fwd_p3a2(p, save, st);
+}
+
+extern "C" int64_t sr_fwd_stream_elems(int feat, int tau) {
+  if (feat != kFeat || tau < 1 || tau > 24) return -1;
+  return (aux_steps(tau) == 1 ? FwdStream<1>::total_pieces() : FwdStream<2>::total_pieces()) * 512;
+}
+
+extern "C" int64_t sr_act_elems_per_tile(int feat) {
+  if (feat != kFeat) return -1;
+  return (int64_t)act_ksteps(2) * 64 * 8;  // sized for the larger aux layout
+}
+
+extern "C" int64_t sr_bwd_stream_elems(int feat, int tau) {
+  (void)feat, (void)tau;
+  return -1;  // backward stream not built yet
+}

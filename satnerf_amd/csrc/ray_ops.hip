@@ -1,0 +1,482 @@
+// Per-ray kernels of the Sat-NeRF rendering path for gfx950: stratified sampling, the per-ray sky head,
+// sigma->alpha compositing (forward and closed-form backward), importance resampling + merge, and the
+// weight-stream pack/unpack helpers.  All are HBM-bound and tiny next to the fused MLP; they are written
+// one wavefront (64 lanes) per ray with lane = sample, wave scans/reductions through DPP shuffles, and
+// coalesced row accesses.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace sr {
+
+// ---- error plumbing -------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return 2;
+  }
+  return 0;
+}
+
+constexpr int kRaysPerBlock = 4;  // 4 waves = 256 threads
+
+// ---- wave primitives (64 lanes) ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+// inclusive scans across the wave
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_up(v, d, 64);
+    if (lane >= d) v *= o;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_scan_add(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_rscan_add(float v, int lane) {  // inclusive suffix sum
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_down(v, d, 64);
+    if (lane + d < 64) v += o;
+  }
+  return v;
+}
+
+// ---- stratified sampling: rendering.py:62-78 ---------------------------------------------------------------
+// torch.linspace(0,1,S) in fp32: step = 1/(S-1); i < S/2 ? i*step : 1 - (S-1-i)*step  (ATen RangeFactories).
+__device__ __forceinline__ float linspace01(int i, int n, float step) {
+#pragma clang fp contract(off)
+  return i < n / 2 ? (float)i * step : 1.0f - step * (float)(n - 1 - i);
+}
+__device__ __forceinline__ float lerp_near_far(float near, float far, float s) {
+#pragma clang fp contract(off)
+  const float a = near * (1.0f - s), b = far * s;  // rendering.py:67, this exact form
+  return a + b;
+}
+
+__global__ void __launch_bounds__(256) ray_sample_kernel(const float* __restrict__ rays, int ray_stride, const float* __restrict__ u,
+                                                        long n_rays, int S, float* __restrict__ z_out) {
+#pragma clang fp contract(off)
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n_rays * S) return;
+  const long r = idx / S;
+  const int j = (int)(idx - r * S);
+  const float near = rays[r * ray_stride + 6], far = rays[r * ray_stride + 7];
+  const float step = 1.0f / (float)(S - 1);
+  const float zj = lerp_near_far(near, far, linspace01(j, S, step));
+  float lower = zj, upper = zj;
+  if (j > 0) lower = 0.5f * (lerp_near_far(near, far, linspace01(j - 1, S, step)) + zj);
+  if (j < S - 1) upper = 0.5f * (zj + lerp_near_far(near, far, linspace01(j + 1, S, step)));
+  const float span = upper - lower;
+  const float jit = span * u[idx];
+  z_out[idx] = lower + jit;
+}
+
+// ---- sky colour head, one wave per ray: models/satnerf.py:138-143,201 --------------------------------------
+__global__ void __launch_bounds__(256) sky_kernel(const float* __restrict__ sun, int sun_stride, long n, int hidden,
+                                                 const float* __restrict__ w1, const float* __restrict__ b1,
+                                                 const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ sky) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const float sx = sun[r * sun_stride], sy = sun[r * sun_stride + 1], sz = sun[r * sun_stride + 2];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int k = lane; k < hidden; k += 64) {
+    float hk = __builtin_fmaf(w1[k * 3 + 2], sz, __builtin_fmaf(w1[k * 3 + 1], sy, __builtin_fmaf(w1[k * 3], sx, b1[k])));
+    hk = hk > 0.f ? hk : 0.f;
+    a0 = __builtin_fmaf(w2[k], hk, a0);
+    a1 = __builtin_fmaf(w2[hidden + k], hk, a1);
+    a2 = __builtin_fmaf(w2[2 * hidden + k], hk, a2);
+  }
+  a0 = wave_sum(a0), a1 = wave_sum(a1), a2 = wave_sum(a2);
+  if (lane == 0) {
+    sky[r * 3 + 0] = sigmoid_f(a0 + b2[0]);
+    sky[r * 3 + 1] = sigmoid_f(a1 + b2[1]);
+    sky[r * 3 + 2] = sigmoid_f(a2 + b2[2]);
+  }
+}
+
+// ---- compositing: models/satnerf.py:52-70 --------------------------------------------------------------------
+// One wave per ray; samples are processed in segments of 64 (lane = sample) with a running transmittance carry.
+__device__ __forceinline__ void alpha_of(const float* z, const float* sigma, const float* noise, float noise_std, long base,
+                                         int j, int S, float& delta, float& dens, float& alpha) {
+#pragma clang fp contract(off)
+  delta = (j < S - 1) ? (z[base + j + 1] - z[base + j]) : 1e10f;
+  float s = sigma[base + j];
+  if (noise) s = s + noise[base + j] * noise_std;
+  dens = s;
+  const float rl = s > 0.f ? s : 0.f;
+  alpha = 1.0f - expf(-delta * rl);
+}
+
+__global__ void __launch_bounds__(256) composite_fwd_kernel(const float* __restrict__ z, const float* __restrict__ sigma,
+                                                           const float* __restrict__ noise, float noise_std,
+                                                           const float* __restrict__ albedo, const float* __restrict__ sun_v,
+                                                           const float* __restrict__ sky, long n_rays, int S, int clamp_rgb,
+                                                           float* __restrict__ weights, float* __restrict__ transp,
+                                                           float* __restrict__ depth, float* __restrict__ rgb) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
+  if (r >= n_rays) return;
+  const long base = r * S;
+  float k0 = 1.f, k1 = 1.f, k2 = 1.f;
+  if (sky) k0 = sky[r * 3], k1 = sky[r * 3 + 1], k2 = sky[r * 3 + 2];
+  float carry = 1.f, dsum = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  for (int j0 = 0; j0 < S; j0 += 64) {
+    const int j = j0 + lane;
+    const bool on = j < S;
+    float delta, dens, alpha = 0.f;
+    if (on) alpha_of(z, sigma, noise, noise_std, base, j, S, delta, dens, alpha);
+    float f;
+    {
+#pragma clang fp contract(off)
+      f = on ? (1.0f - alpha) + 1e-10f : 1.f;
+    }
+    const float incl = wave_scan_mul(f, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.f;
+    const float T = carry * excl;
+    carry = carry * __shfl(incl, 63, 64);
+    if (on) {
+      const float w = alpha * T;
+      weights[base + j] = w;
+      transp[base + j] = T;
+      dsum += w * z[base + j];
+      if (albedo) {
+        const float* a = albedo + (base + j) * 3;
+        float i0 = 1.f, i1 = 1.f, i2 = 1.f;
+        if (sun_v) {
+          const float sv = sun_v[base + j];
+          i0 = sv + (1.f - sv) * k0, i1 = sv + (1.f - sv) * k1, i2 = sv + (1.f - sv) * k2;  // :68
+        }
+        c0 += w * a[0] * i0, c1 += w * a[1] * i1, c2 += w * a[2] * i2;
+      }
+    }
+  }
+  dsum = wave_sum(dsum), c0 = wave_sum(c0), c1 = wave_sum(c1), c2 = wave_sum(c2);
+  if (lane == 0) {
+    if (depth) depth[r] = dsum;
+    if (rgb) {
+      if (clamp_rgb) c0 = fminf(fmaxf(c0, 0.f), 1.f), c1 = fminf(fmaxf(c1, 0.f), 1.f), c2 = fminf(fmaxf(c2, 0.f), 1.f);
+      rgb[r * 3] = c0, rgb[r * 3 + 1] = c1, rgb[r * 3 + 2] = c2;
+    }
+  }
+}
+
+// Closed-form backward (extended with a transparency gradient):
+//   G_j   = g_w_j + g_depth z_j + sum_c ghat_c albedo_jc irr_jc
+//   dalpha_j = G_j T_j - ( sum_{k>j} (G_k w_k + gT_k T_k) ) / (1 - alpha_j + 1e-10)
+//   dsigma_j = dalpha_j * delta_j * exp(-delta_j relu(s_j)) * [s_j > 0]
+__global__ void __launch_bounds__(256) composite_bwd_kernel(
+    const float* __restrict__ z, const float* __restrict__ sigma, const float* __restrict__ noise, float noise_std,
+    const float* __restrict__ albedo, const float* __restrict__ sun_v, const float* __restrict__ sky,
+    const float* __restrict__ weights, const float* __restrict__ transp, long n_rays, int S, int clamp_rgb,
+    const float* __restrict__ g_rgb, const float* __restrict__ g_depth, const float* __restrict__ g_w, const float* __restrict__ g_T,
+    float* __restrict__ d_sigma, float* __restrict__ d_albedo, float* __restrict__ d_sun, float* __restrict__ d_sky) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
+  if (r >= n_rays) return;
+  const long base = r * S;
+  float k0 = 1.f, k1 = 1.f, k2 = 1.f;
+  if (sky) k0 = sky[r * 3], k1 = sky[r * 3 + 1], k2 = sky[r * 3 + 2];
+  float gr0 = 0.f, gr1 = 0.f, gr2 = 0.f;
+  if (g_rgb && albedo) {
+    gr0 = g_rgb[r * 3], gr1 = g_rgb[r * 3 + 1], gr2 = g_rgb[r * 3 + 2];
+    if (clamp_rgb) {  // torch.clamp passes the gradient where min <= x <= max: recompute the unclamped colour
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+      for (int j = lane; j < S; j += 64) {
+        const float w = weights[base + j];
+        const float* a = albedo + (base + j) * 3;
+        float i0 = 1.f, i1 = 1.f, i2 = 1.f;
+        if (sun_v) {
+          const float sv = sun_v[base + j];
+          i0 = sv + (1.f - sv) * k0, i1 = sv + (1.f - sv) * k1, i2 = sv + (1.f - sv) * k2;
+        }
+        c0 += w * a[0] * i0, c1 += w * a[1] * i1, c2 += w * a[2] * i2;
+      }
+      c0 = wave_sum(c0), c1 = wave_sum(c1), c2 = wave_sum(c2);
+      if (!(c0 >= 0.f && c0 <= 1.f)) gr0 = 0.f;
+      if (!(c1 >= 0.f && c1 <= 1.f)) gr1 = 0.f;
+      if (!(c2 >= 0.f && c2 <= 1.f)) gr2 = 0.f;
+    }
+  }
+  const float gd = g_depth ? g_depth[r] : 0.f;
+  float ks0 = 0.f, ks1 = 0.f, ks2 = 0.f;  // d_sky accumulators
+  float carry = 0.f;                       // suffix sum from later segments
+  const int nseg = (S + 63) / 64;
+  for (int seg = nseg - 1; seg >= 0; --seg) {
+    const int j = seg * 64 + lane;
+    const bool on = j < S;
+    float delta = 0.f, dens = 0.f, alpha = 0.f, w = 0.f, T = 0.f, G = 0.f, tail = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, i0 = 1.f, i1 = 1.f, i2 = 1.f, sv = 1.f;
+    if (on) {
+      alpha_of(z, sigma, noise, noise_std, base, j, S, delta, dens, alpha);
+      w = weights[base + j], T = transp[base + j];
+      G = (g_w ? g_w[base + j] : 0.f) + gd * z[base + j];
+      if (albedo) {
+        const float* a = albedo + (base + j) * 3;
+        a0 = a[0], a1 = a[1], a2 = a[2];
+        if (sun_v) {
+          sv = sun_v[base + j];
+          i0 = sv + (1.f - sv) * k0, i1 = sv + (1.f - sv) * k1, i2 = sv + (1.f - sv) * k2;
+        }
+        G += gr0 * a0 * i0 + gr1 * a1 * i1 + gr2 * a2 * i2;
+      }
+      tail = G * w + (g_T ? g_T[base + j] * T : 0.f);
+    }
+    const float incl = wave_rscan_add(tail, lane);  // sum_{k>=j} within the segment
+    const float after = incl - tail + carry;        // sum_{k>j} over the whole ray
+    carry += __shfl(incl, 0, 64);
+    if (on) {
+      const float f = (1.0f - alpha) + 1e-10f;
+      const float dalpha = G * T - after / f;
+      if (d_sigma) {
+        const float rl = dens > 0.f ? dens : 0.f;
+        d_sigma[base + j] = dens > 0.f ? dalpha * delta * expf(-delta * rl) : 0.f;
+      }
+      if (albedo) {
+        const float q0 = w * gr0, q1 = w * gr1, q2 = w * gr2;
+        if (d_albedo) {
+          float* da = d_albedo + (base + j) * 3;
+          da[0] = q0 * i0, da[1] = q1 * i1, da[2] = q2 * i2;
+        }
+        const float di0 = q0 * a0, di1 = q1 * a1, di2 = q2 * a2;  // d irradiance
+        if (d_sun) d_sun[base + j] = sun_v ? (di0 * (1.f - k0) + di1 * (1.f - k1) + di2 * (1.f - k2)) : 0.f;
+        ks0 += di0 * (1.f - sv), ks1 += di1 * (1.f - sv), ks2 += di2 * (1.f - sv);
+      }
+    }
+  }
+  if (d_sky) {
+    ks0 = wave_sum(ks0), ks1 = wave_sum(ks1), ks2 = wave_sum(ks2);
+    if (lane == 0) {
+      const bool has = sun_v != nullptr && sky != nullptr;
+      d_sky[r * 3] = has ? ks0 : 0.f, d_sky[r * 3 + 1] = has ? ks1 : 0.f, d_sky[r * 3 + 2] = has ? ks2 : 0.f;
+    }
+  }
+}
+
+// ---- importance resampling + merge: rendering.py:10-49,121-125 ----------------------------------------------
+constexpr int kMaxMerge = 1024;  // S + I rounded up to a power of two must fit
+
+__global__ void __launch_bounds__(256) sample_pdf_merge_kernel(const float* __restrict__ zc, const float* __restrict__ wc,
+                                                              const float* __restrict__ u, long n_rays, int S, int I, float eps,
+                                                              int npow2, float* __restrict__ z_fine) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long r = (long)blockIdx.x * kRaysPerBlock + wv;
+  if (r >= n_rays) return;
+  const int nb = S - 1;  // bins = cdf entries
+  float* cdf = reinterpret_cast<float*>(smem) + (size_t)wv * (2 * (size_t)S + npow2);
+  float* bins = cdf + S;
+  float* buf = bins + S;
+  const float* zr = zc + r * S;
+  const float* wr = wc + r * S;
+  // bins = interval mid points; pdf weights = w[1:-1] + eps
+  for (int j = lane; j < nb; j += 64) bins[j] = 0.5f * (zr[j] + zr[j + 1]);
+  const int nw = S - 2;
+  float tot = 0.f;
+  for (int j = lane; j < nw; j += 64) tot += wr[j + 1] + eps;
+  tot = wave_sum(tot);
+  // cdf[0] = 0, cdf[k] = sum_{j<k} pdf_j : segmented wave scan
+  float carry = 0.f;
+  for (int j0 = 0; j0 < nw; j0 += 64) {
+    const int j = j0 + lane;
+    const float p = j < nw ? (wr[j + 1] + eps) / tot : 0.f;
+    const float incl = wave_scan_add(p, lane);
+    if (j < nw) cdf[j + 1] = carry + incl;
+    carry += __shfl(incl, 63, 64);
+  }
+  if (lane == 0) cdf[0] = 0.f;
+  // merge buffer: coarse depths, then the new samples, padded with +inf
+  for (int j = lane; j < S; j += 64) buf[j] = zr[j];
+  for (int j = S + I + lane; j < npow2; j += 64) buf[j] = __builtin_inff();
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  for (int i = lane; i < I; i += 64) {
+    const float ui = u[r * I + i];
+    // searchsorted(cdf, u, right=True): number of entries <= u
+    int lo = 0, hi = nb;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] <= ui) lo = mid + 1;
+      else hi = mid;
+    }
+    const int below = lo - 1 > 0 ? lo - 1 : 0;
+    const int above = lo < nw ? lo : nw;
+    const float cb = cdf[below], ca = cdf[above], bb = bins[below], ba = bins[above];
+    float denom = ca - cb;
+    if (denom < eps) denom = 1.f;
+    {
+#pragma clang fp contract(off)
+      const float t = (ui - cb) / denom;
+      const float step = t * (ba - bb);
+      buf[S + i] = bb + step;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // bitonic sort of npow2 values by one wave
+  for (int k = 2; k <= npow2; k <<= 1) {
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      for (int t = lane; t < npow2 / 2; t += 64) {
+        const int lo_i = ((t / jj) * jj * 2) + (t % jj);
+        const int hi_i = lo_i + jj;
+        const bool up = (lo_i & k) == 0;
+        const float a = buf[lo_i], b = buf[hi_i];
+        if ((a > b) == up) buf[lo_i] = b, buf[hi_i] = a;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  for (int j = lane; j < S + I; j += 64) z_fine[r * (S + I) + j] = buf[j];
+}
+
+// ---- weight stream pack / gradient unpack ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_stream_kernel(const float* __restrict__ src, const int* __restrict__ idx,
+                                                         const float* __restrict__ scale, long n, uint16_t* __restrict__ hi,
+                                                         uint16_t* __restrict__ lo) {
+#pragma clang fp contract(off)
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= n) return;  // n is even (pieces are 512 elements)
+  const int i0 = idx[i], i1 = idx[i + 1];
+  const float v0 = i0 >= 0 ? src[i0] * scale[i] : 0.f;
+  const float v1 = i1 >= 0 ? src[i1] * scale[i + 1] : 0.f;
+  uint32_t h, l;
+  split_bf16x2(v0, v1, h, l);
+  reinterpret_cast<uint32_t*>(hi)[i >> 1] = h;
+  if (lo) reinterpret_cast<uint32_t*>(lo)[i >> 1] = l;
+}
+
+__global__ void __launch_bounds__(256) gather_scale_kernel(const float* __restrict__ src, const int* __restrict__ idx,
+                                                          const float* __restrict__ scale, long n, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int k = idx[i];
+  out[i] = k >= 0 ? src[k] * scale[i] : 0.f;
+}
+
+__global__ void __launch_bounds__(256) unpack_grads_kernel(const float* __restrict__ dstream, const int* __restrict__ gidx,
+                                                          const float* __restrict__ gscale, long n, float* __restrict__ grad,
+                                                          int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int k = gidx[i];
+  const float g = k >= 0 ? dstream[k] * gscale[i] : 0.f;
+  grad[i] = accumulate ? grad[i] + g : g;
+}
+
+}  // namespace sr
+
+using namespace sr;
+
+extern "C" int sr_version(void) { return SR_VERSION; }
+extern "C" const char* sr_last_error(void) { return sr::g_err; }
+
+extern "C" int sr_ray_sample_fwd(const float* rays, int ray_stride, const float* u, int64_t n_rays, int n_samples, float* z_vals,
+                                 void* stream) {
+  SR_REQUIRE(rays && u && z_vals, "sr_ray_sample_fwd: null pointer");
+  SR_REQUIRE(ray_stride >= 8 && n_samples >= 2, "sr_ray_sample_fwd: ray_stride>=8 and n_samples>=2 required (got %d, %d)", ray_stride, n_samples);
+  if (n_rays <= 0) return 0;
+  const long tot = (long)n_rays * n_samples;
+  hipLaunchKernelGGL(ray_sample_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rays, ray_stride, u,
+                     (long)n_rays, n_samples, z_vals);
+  return check_launch("ray_sample_kernel");
+}
+
+extern "C" int sr_sky_fwd(const float* sun, int sun_stride, int64_t n, int hidden, const float* w1, const float* b1, const float* w2,
+                          const float* b2, float* sky, void* stream) {
+  SR_REQUIRE(sun && w1 && b1 && w2 && b2 && sky, "sr_sky_fwd: null pointer");
+  SR_REQUIRE(sun_stride >= 3 && hidden >= 1, "sr_sky_fwd: bad sun_stride/hidden");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(sky_kernel, dim3((unsigned)((n + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(256), 0, (hipStream_t)stream, sun,
+                     sun_stride, (long)n, hidden, w1, b1, w2, b2, sky);
+  return check_launch("sky_kernel");
+}
+
+extern "C" int sr_composite_fwd(const float* z_vals, const float* sigma, const float* noise, float noise_std, const float* albedo,
+                                const float* sun_v, const float* sky, int64_t n_rays, int n_samples, int clamp_rgb, float* weights,
+                                float* transparency, float* depth, float* rgb, void* stream) {
+  SR_REQUIRE(z_vals && sigma && weights && transparency, "sr_composite_fwd: null pointer");
+  SR_REQUIRE(n_samples >= 1, "sr_composite_fwd: n_samples must be >= 1");
+  SR_REQUIRE((sun_v == nullptr) == (sky == nullptr), "sr_composite_fwd: sun_v and sky must be given together");
+  if (n_rays <= 0) return 0;
+  hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(256), 0,
+                     (hipStream_t)stream, z_vals, sigma, noise, noise_std, albedo, sun_v, sky, (long)n_rays, n_samples, clamp_rgb,
+                     weights, transparency, depth, rgb);
+  return check_launch("composite_fwd_kernel");
+}
+
+extern "C" int sr_composite_bwd(const float* z_vals, const float* sigma, const float* noise, float noise_std, const float* albedo,
+                                const float* sun_v, const float* sky, const float* weights, const float* transparency,
+                                const float* rgb_unclamped_or_null, int64_t n_rays, int n_samples, int clamp_rgb, const float* g_rgb,
+                                const float* g_depth, const float* g_weights, const float* g_transparency, float* d_sigma,
+                                float* d_albedo, float* d_sun_v, float* d_sky, void* stream) {
+  (void)rgb_unclamped_or_null;  // recomputed in-kernel
+  SR_REQUIRE(z_vals && sigma && weights && transparency, "sr_composite_bwd: null pointer");
+  SR_REQUIRE((sun_v == nullptr) == (sky == nullptr), "sr_composite_bwd: sun_v and sky must be given together");
+  if (n_rays <= 0) return 0;
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(256), 0,
+                     (hipStream_t)stream, z_vals, sigma, noise, noise_std, albedo, sun_v, sky, weights, transparency, (long)n_rays,
+                     n_samples, clamp_rgb, g_rgb, g_depth, g_weights, g_transparency, d_sigma, d_albedo, d_sun_v, d_sky);
+  return check_launch("composite_bwd_kernel");
+}
+
+extern "C" int sr_sample_pdf_merge(const float* z_coarse, const float* weights_coarse, const float* u, int64_t n_rays, int n_samples,
+                                   int n_importance, float eps, float* z_fine, void* stream) {
+  SR_REQUIRE(z_coarse && weights_coarse && u && z_fine, "sr_sample_pdf_merge: null pointer");
+  SR_REQUIRE(n_samples >= 3 && n_importance >= 1, "sr_sample_pdf_merge: need n_samples>=3, n_importance>=1");
+  int npow2 = 64;
+  while (npow2 < n_samples + n_importance) npow2 <<= 1;
+  SR_REQUIRE(npow2 <= kMaxMerge, "sr_sample_pdf_merge: n_samples+n_importance=%d too large (max %d)", n_samples + n_importance, kMaxMerge);
+  if (n_rays <= 0) return 0;
+  const size_t lds = (size_t)kRaysPerBlock * (2 * (size_t)n_samples + npow2) * sizeof(float);
+  hipLaunchKernelGGL(sample_pdf_merge_kernel, dim3((unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(256), lds,
+                     (hipStream_t)stream, z_coarse, weights_coarse, u, (long)n_rays, n_samples, n_importance, eps, npow2, z_fine);
+  return check_launch("sample_pdf_merge_kernel");
+}
+
+extern "C" int sr_pack_stream(const float* src, const int32_t* idx, const float* scale, int64_t n, uint16_t* out_hi, uint16_t* out_lo,
+                              void* stream) {
+  SR_REQUIRE(src && idx && scale && out_hi, "sr_pack_stream: null pointer");
+  SR_REQUIRE(n % 2 == 0, "sr_pack_stream: n must be even");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(pack_stream_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, idx, scale,
+                     (long)n, out_hi, out_lo);
+  return check_launch("pack_stream_kernel");
+}
+
+extern "C" int sr_gather_scale_f32(const float* src, const int32_t* idx, const float* scale, int64_t n, float* out, void* stream) {
+  SR_REQUIRE(src && idx && scale && out, "sr_gather_scale_f32: null pointer");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(gather_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, idx, scale, (long)n, out);
+  return check_launch("gather_scale_kernel");
+}
+
+extern "C" int sr_unpack_grads(const float* dstream, const int32_t* gidx, const float* gscale, int64_t n_params, float* grad,
+                               int accumulate, void* stream) {
+  SR_REQUIRE(dstream && gidx && gscale && grad, "sr_unpack_grads: null pointer");
+  if (n_params <= 0) return 0;
+  hipLaunchKernelGGL(unpack_grads_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dstream, gidx,
+                     gscale, (long)n_params, grad, accumulate);
+  return check_launch("unpack_grads_kernel");
+}

@@ -1,0 +1,161 @@
+"""Model containers with the reference's constructor signatures and ``state_dict`` layout.
+
+``SatNeRF`` mirrors ``models/satnerf.py:81-153`` (module tree, parameter names, shapes, construction order and
+therefore init RNG stream) so Lightning checkpoints written by the reference load unchanged
+(``eval_satnerf.py:82-90``).  The modules are parameter holders only: arithmetic runs in the HIP library.
+All parameters are views into ONE flat fp32 buffer (``flat_params()``) -- the unit the weight-stream packer,
+the fused optimizer and the data-parallel gradient all-reduce operate on.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops, packing
+
+
+class Siren(nn.Module):
+    """Placeholder for ``models/nerf.py:23-33`` (keeps the Sequential indices 0,2,4,... of the reference)."""
+
+    def __init__(self, w0=1.0):
+        super().__init__()
+        self.w0 = w0
+
+    def forward(self, x):  # pragma: no cover - never executed, the fused kernel applies sin(w0 x)
+        raise RuntimeError("satnerf_amd modules hold parameters only; call SatNeRF.forward / render_rays")
+
+
+def _sine_init(seq, first_only=False):
+    """``sine_init`` / ``first_layer_sine_init`` (models/nerf.py:9-21) applied the way ``Module.apply`` walks."""
+    with torch.no_grad():
+        for m in ([seq[0]] if first_only else list(seq)):
+            if hasattr(m, "weight"):
+                n_in = m.weight.size(-1)
+                if first_only:
+                    m.weight.uniform_(-1 / n_in, 1 / n_in)
+                else:
+                    m.weight.uniform_(-np.sqrt(6 / n_in), np.sqrt(6 / n_in))
+
+
+class _FlatParamModule(nn.Module):
+    """Keeps every parameter a view of one flat buffer; survives ``.to()/.cuda()/.float()``."""
+
+    def _flatten(self):
+        params = list(self.parameters())
+        flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=params[0].device)
+        off = 0
+        for p in params:
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+        self._flat = flat
+        self._pack_cache = {}
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._flatten()
+        return out
+
+    def weights_version(self):
+        """Changes whenever the weights are modified in place, through a parameter view OR through the flat buffer
+        (``p.data = view`` does not share version counters, so both are counted)."""
+        return self._flat._version + sum(p._version for p in self.parameters())
+
+    def flat_params(self):
+        params = list(self.parameters())
+        first, last = params[0], params[-1]
+        ok = (first.data_ptr() == self._flat.data_ptr()
+              and last.data_ptr() == self._flat.data_ptr() + (self._flat.numel() - last.numel()) * 4)
+        if not ok:  # someone re-pointed a .data: fold the parameters back into one buffer
+            self._flatten()
+        return self._flat
+
+
+class SatNeRF(_FlatParamModule):
+    number_of_outputs = 9  # rgb 3, sigma 1, sun visibility 1, sky rgb 3, beta 1 (models/satnerf.py:90)
+
+    def __init__(self, layers=8, feat=256, mapping=False, mapping_sizes=[10, 4], skips=[4], siren=True, t_embedding_dims=16):
+        super().__init__()
+        if mapping or not siren:
+            raise NotImplementedError("Sat-NeRF runs with mapping=False, siren=True (models/__init__.py:12); other variants are not built")
+        if layers != 8 or list(skips) != [4]:
+            raise NotImplementedError("the fused kernel is built for layers=8, skips=[4]")
+        self.layers, self.skips, self.feat = layers, list(skips), feat
+        self.t_embedding_dims = t_embedding_dims
+        self.mapping = [nn.Identity(), nn.Identity()]  # plain list, not registered (models/satnerf.py:101)
+        self.input_sizes = [3, 0]
+        self.rgb_padding = 0.001
+        half = feat // 2
+        nl = Siren()
+        fc = [nn.Linear(3, feat), Siren(w0=30.0)]
+        for i in range(1, layers):
+            fc += [nn.Linear(feat + 3 if i in skips else feat, feat), nl]
+        self.fc_net = nn.Sequential(*fc)
+        self.sigma_from_xyz = nn.Sequential(nn.Linear(feat, 1), nn.Softplus())
+        self.feats_from_xyz = nn.Linear(feat, feat)
+        self.rgb_from_xyzdir = nn.Sequential(nn.Linear(feat, half), nl, nn.Linear(half, 3), nn.Sigmoid())
+        self.sun_v_net = nn.Sequential(nn.Linear(feat + 3, half), Siren(), nn.Linear(half, half), nl, nn.Linear(half, half), nl,
+                                       nn.Linear(half, 1), nn.Sigmoid())
+        self.sky_color = nn.Sequential(nn.Linear(3, half), nn.ReLU(), nn.Linear(half, 3), nn.Sigmoid())
+        _sine_init(self.fc_net)
+        _sine_init(self.fc_net, first_only=True)
+        _sine_init(self.sun_v_net)
+        _sine_init(self.sun_v_net, first_only=True)
+        self.beta_from_xyz = nn.Sequential(nn.Linear(t_embedding_dims + feat, half), nl, nn.Linear(half, 1), nn.Softplus())
+        self._flatten()
+
+    # ---- weight stream ------------------------------------------------------------------------------------
+    def packed(self, mode):
+        """(stream_hi, stream_lo | None, l0) for the current weights; rebuilt only when the flat buffer changed."""
+        flat = self.flat_params()
+        if not flat.is_cuda:
+            raise RuntimeError("SatNeRF parameters are on the CPU: move the model to the GPU (.cuda()); there is no CPU path")
+        key = (mode == "bf16x3")
+        ent = self._pack_cache.get(key)
+        version = self.weights_version()
+        if ent is not None and ent[0] == version and ent[1] == flat.data_ptr():
+            return ent[2]
+        maps = self._device_maps()
+        hi, lo = ops.pack_stream(flat, maps["idx"], maps["scale"], want_lo=key)
+        l0 = ops.gather_scale(flat, maps["l0_idx"], maps["l0_scale"])
+        self._pack_cache[key] = (version, flat.data_ptr(), (hi, lo, l0))
+        return hi, lo, l0
+
+    def _device_maps(self):
+        dev = self._flat.device
+        ent = self._pack_cache.get("maps")
+        if ent is None or ent["idx"].device != dev:
+            m = packing.forward_maps(self.feat, self.t_embedding_dims)
+            ent = {k: torch.from_numpy(m[k]).to(dev) for k in ("idx", "scale", "l0_idx", "l0_scale")}
+            self._pack_cache["maps"] = ent
+        return ent
+
+    # ---- SatNeRF.forward (models/satnerf.py:156-208): points in, (B,9) out ---------------------------------
+    def forward(self, input_xyz, input_dir=None, input_sun_dir=None, input_t=None, sigma_only=False, mlp_mode=None):
+        from .rendering import default_mode
+
+        if input_sun_dir is None or input_t is None:
+            raise TypeError("SatNeRF.forward needs input_sun_dir and input_t (models/satnerf.py:199,204)")
+        mode = mlp_mode or default_mode()
+        xyz = input_xyz.contiguous().float()
+        sun = input_sun_dir.contiguous().float()
+        t = input_t.contiguous().float()
+        b = xyz.shape[0]
+        hi, lo, l0 = self.packed(mode)
+        albedo, sigma, sun_v, beta = ops.satnerf_mlp(xyz, None, sun, None, t, None, b, 1, self.feat, self.t_embedding_dims, mode, hi, lo, l0)
+        if sigma_only:
+            return sigma.unsqueeze(1)
+        sk = self.sky_color
+        sky = ops.sky(sun, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data)
+        return torch.cat([albedo, sigma.unsqueeze(1), sun_v.unsqueeze(1), sky, beta.unsqueeze(1)], 1)
+
+
+def load_model(args):
+    """``models.load_model`` (models/__init__.py:6-15)."""
+    if args.model == "sat-nerf":
+        return SatNeRF(layers=args.fc_layers, feat=args.fc_units, t_embedding_dims=args.t_embbeding_tau)
+    if args.model in ("nerf", "s-nerf"):
+        raise NotImplementedError(f"model {args.model}: only the sat-nerf variant of the hot path is built (SURVEY.md section 8)")
+    raise ValueError(f"model {args.model} is not valid")

@@ -1,0 +1,141 @@
+"""Typed Python wrappers over the C ABI (one function per entry point of include/satrender.h).
+
+Every wrapper validates device / dtype / contiguity (the library itself sees only raw pointers), enqueues on
+torch's current HIP stream and returns torch tensors it allocated.  No arithmetic happens here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+MODES = {"bf16": _lib.MODE_BF16, "bf16x3": _lib.MODE_BF16X3}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, name, dtype=torch.float32, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise ValueError(f"{name} is required")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (got {t.device}); satnerf_amd has no CPU path")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def _rows(t, name, min_cols):
+    """A 2-D fp32 view whose rows may be strided (e.g. rays[:, 3:6]): returns (tensor, row stride in elements)."""
+    if t.dim() != 2 or t.shape[1] < min_cols or t.dtype != torch.float32 or not t.is_cuda or t.stride(1) != 1:
+        raise ValueError(f"{name} must be a GPU fp32 (N,>={min_cols}) tensor with unit inner stride")
+    return t, t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
+
+def pack_stream(flat, idx, scale, want_lo):
+    n = idx.numel()
+    hi = torch.empty(n, dtype=torch.int16, device=flat.device)
+    lo = torch.empty(n, dtype=torch.int16, device=flat.device) if want_lo else None
+    _lib.call("sr_pack_stream", _p(_chk(flat, "flat")), _p(_chk(idx, "idx", torch.int32)), _p(_chk(scale, "scale")), n, _p(hi), _p(lo),
+              _stream())
+    return hi, lo
+
+
+def gather_scale(flat, idx, scale):
+    out = torch.empty(idx.numel(), dtype=torch.float32, device=flat.device)
+    _lib.call("sr_gather_scale_f32", _p(_chk(flat, "flat")), _p(_chk(idx, "idx", torch.int32)), _p(_chk(scale, "scale")), idx.numel(), _p(out),
+              _stream())
+    return out
+
+
+def ray_sample(rays, u, n_samples):
+    rays, stride = _rows(rays, "rays", 8)
+    n = rays.shape[0]
+    _chk(u, "u")
+    if tuple(u.shape) != (n, n_samples):
+        raise ValueError(f"u must be ({n},{n_samples}), got {tuple(u.shape)}")
+    z = torch.empty(n, n_samples, dtype=torch.float32, device=rays.device)
+    _lib.call("sr_ray_sample_fwd", _p(rays), stride, _p(u), n, n_samples, _p(z), _stream())
+    return z
+
+
+def sky(sun, w1, b1, w2, b2):
+    sun, stride = _rows(sun, "sun", 3)
+    n, hidden = sun.shape[0], w1.shape[0]
+    out = torch.empty(n, 3, dtype=torch.float32, device=sun.device)
+    _lib.call("sr_sky_fwd", _p(sun), stride, n, hidden, _p(_chk(w1, "w1")), _p(_chk(b1, "b1")), _p(_chk(w2, "w2")), _p(_chk(b2, "b2")), _p(out),
+              _stream())
+    return out
+
+
+def satnerf_mlp(org, direction, sun, z, temb, ts, n_points, n_samples, feat, tau, mode, stream_hi, stream_lo, l0, acts=None):
+    """Fused MLP over n_points sample points; returns (albedo (P,3), sigma (P), sun_v (P), beta (P))."""
+    org, so = _rows(org, "org", 3)
+    sun, ss = _rows(sun, "sun", 3)
+    sd = 0
+    if direction is not None:
+        direction, sd = _rows(direction, "dir", 3)
+    if z is not None:
+        _chk(z, "z")
+    _chk(temb, "temb")
+    if ts is not None:
+        _chk(ts, "ts", torch.int64)
+    dev = org.device
+    albedo = torch.empty(n_points, 3, dtype=torch.float32, device=dev)
+    sigma = torch.empty(n_points, dtype=torch.float32, device=dev)
+    sun_v = torch.empty(n_points, dtype=torch.float32, device=dev)
+    beta = torch.empty(n_points, dtype=torch.float32, device=dev)
+    inp = _lib.MlpInputs(_p(org), so, _p(direction), sd, _p(sun), ss, _p(z), _p(temb), _p(ts), n_points, n_samples)
+    _lib.call("sr_satnerf_mlp_fwd", C.byref(inp), feat, tau, MODES[mode], _p(stream_hi), _p(stream_lo), _p(_chk(l0, "l0")), _p(albedo), _p(sigma),
+              _p(sun_v), _p(beta), _p(acts), _stream())
+    return albedo, sigma, sun_v, beta
+
+
+def composite(z, sigma, noise, noise_std, albedo, sun_v, sky_rgb, clamp_rgb=True):
+    n, s = z.shape
+    dev = z.device
+    _chk(z, "z"), _chk(sigma, "sigma")
+    weights = torch.empty(n, s, dtype=torch.float32, device=dev)
+    transp = torch.empty(n, s, dtype=torch.float32, device=dev)
+    depth = torch.empty(n, dtype=torch.float32, device=dev)
+    rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    _lib.call("sr_composite_fwd", _p(z), _p(sigma), _p(_chk(noise, "noise", allow_none=True)), float(noise_std), _p(_chk(albedo, "albedo")),
+              _p(_chk(sun_v, "sun_v", allow_none=True)), _p(_chk(sky_rgb, "sky", allow_none=True)), n, s, int(clamp_rgb), _p(weights), _p(transp),
+              _p(depth), _p(rgb), _stream())
+    return weights, transp, depth, rgb
+
+
+def composite_bwd(z, sigma, noise, noise_std, albedo, sun_v, sky_rgb, weights, transp, g_rgb, g_depth, g_weights, g_transp, clamp_rgb=True):
+    n, s = z.shape
+    dev = z.device
+    d_sigma = torch.empty(n, s, dtype=torch.float32, device=dev)
+    d_albedo = torch.empty(n, s, 3, dtype=torch.float32, device=dev)
+    d_sun = torch.empty(n, s, dtype=torch.float32, device=dev)
+    d_sky = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    opt = lambda t, nm: _p(_chk(t, nm, allow_none=True))  # noqa: E731
+    _lib.call("sr_composite_bwd", _p(z), _p(sigma), opt(noise, "noise"), float(noise_std), _p(albedo), opt(sun_v, "sun_v"), opt(sky_rgb, "sky"),
+              _p(weights), _p(transp), None, n, s, int(clamp_rgb), opt(g_rgb, "g_rgb"), opt(g_depth, "g_depth"), opt(g_weights, "g_weights"),
+              opt(g_transp, "g_transparency"), _p(d_sigma), _p(d_albedo), _p(d_sun), _p(d_sky), _stream())
+    return d_sigma, d_albedo, d_sun, d_sky
+
+
+def sample_pdf_merge(z_coarse, weights_coarse, u, eps=1e-5):
+    n, s = z_coarse.shape
+    i = u.shape[1]
+    _chk(z_coarse, "z_coarse"), _chk(weights_coarse, "weights_coarse"), _chk(u, "u")
+    if tuple(weights_coarse.shape) != (n, s) or u.shape[0] != n:
+        raise ValueError("sample_pdf_merge: shape mismatch")
+    z_fine = torch.empty(n, s + i, dtype=torch.float32, device=z_coarse.device)
+    _lib.call("sr_sample_pdf_merge", _p(z_coarse), _p(weights_coarse), _p(u), n, s, i, float(eps), _p(z_fine), _stream())
+    return z_fine

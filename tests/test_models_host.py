@@ -1,0 +1,58 @@
+"""Host-side model container: reference-compatible state_dict layout, flat parameter buffer, error behaviour (CPU)."""
+import pytest
+import torch
+
+from oracle import satnerf_oracle as O
+from satnerf_amd import rendering
+from satnerf_amd.models import SatNeRF, load_model
+
+
+def test_state_dict_keys_shapes_and_order_match_reference():
+    m = SatNeRF(feat=256, t_embedding_dims=4)
+    want = O.satnerf_param_shapes(256, 4)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(want.keys())
+    assert all(tuple(sd[k].shape) == want[k] for k in want)
+    assert m.number_of_outputs == 9
+
+
+def test_parameters_alias_one_flat_buffer_and_survive_load_and_to():
+    m = load_model(O.default_args())
+    flat = m.flat_params()
+    assert flat.numel() == 662537
+    p = O.procedural_satnerf_params(256, 4, seed=1)
+    v0 = m.weights_version()
+    m.load_state_dict(p)
+    assert m.weights_version() > v0  # the pack cache keys on this
+    v1 = m.weights_version()
+    m.flat_params().mul_(1.0)  # a fused optimizer updates the flat buffer directly
+    assert m.weights_version() > v1
+    assert torch.equal(m.flat_params()[:768], p["fc_net.0.weight"].reshape(-1))
+    m2 = m.double().float()
+    assert m2.flat_params().data_ptr() == next(m2.parameters()).data_ptr()
+    assert torch.equal(m2.state_dict()["beta_from_xyz.2.bias"], p["beta_from_xyz.2.bias"])
+
+
+def test_init_ranges_follow_siren_init():
+    torch.manual_seed(0)
+    m = SatNeRF(feat=256, t_embedding_dims=4)
+    sd = m.state_dict()
+    assert sd["fc_net.0.weight"].abs().max() <= 1 / 3
+    assert sd["fc_net.2.weight"].abs().max() <= (6 / 256) ** 0.5
+    assert sd["fc_net.8.weight"].abs().max() <= (6 / 259) ** 0.5
+    assert sd["sun_v_net.0.weight"].abs().max() <= 1 / 259
+    assert sd["feats_from_xyz.weight"].abs().max() <= (1 / 256) ** 0.5 + 1e-6
+
+
+def test_cpu_inputs_fail_loudly_no_fallback():
+    args = O.default_args()
+    m = load_model(args)
+    rays, ts = O.synthetic_rays(8)
+    with pytest.raises(RuntimeError):
+        rendering.render_rays({"coarse": m, "t": torch.nn.Embedding(30, 4)}, args, rays, ts)
+    with pytest.raises(TypeError):
+        rendering.render_rays({"coarse": m, "t": torch.nn.Embedding(30, 4)}, args, rays, None)
+    with pytest.raises(NotImplementedError):
+        load_model(O.default_args(model="s-nerf"))
+    with pytest.raises(ValueError):
+        load_model(O.default_args(model="bogus"))

@@ -1,0 +1,51 @@
+"""Host logic of the weight-stream packer, validated on CPU through a lane-accurate emulation of the kernel."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import satnerf_oracle as O
+from satnerf_amd import packing
+from tests.mfma_emulator import Emulator
+
+
+def test_slot_permutation_is_a_bijection_per_32_block():
+    f = packing.slot_to_feat(np.arange(256))
+    assert sorted(f.tolist()) == list(range(256))
+    for b in range(8):
+        assert sorted(f[32 * b:32 * b + 32].tolist()) == list(range(32 * b, 32 * b + 32))
+
+
+def test_param_shapes_match_reference_state_dict_layout():
+    want = O.satnerf_param_shapes(256, 4)
+    got = packing.satnerf_param_shapes(256, 4)
+    assert list(want.items()) == [(k, tuple(v)) for k, v in got.items()]
+    assert packing.forward_maps(256, 4)["n_params"] == 662537
+
+
+def test_every_mlp_parameter_appears_exactly_once():
+    m = packing.forward_maps(256, 4)
+    used = np.concatenate([m["idx"][m["idx"] >= 0], m["l0_idx"]])
+    counts = np.bincount(used, minlength=m["n_params"])
+    off = m["offsets"]
+    sky = np.zeros(m["n_params"], bool)
+    for k in ("sky_color.0.weight", "sky_color.0.bias", "sky_color.2.weight", "sky_color.2.bias"):
+        o, shp = off[k]
+        sky[o:o + int(np.prod(shp))] = True
+    assert (counts[~sky] == 1).all() and (counts[sky] == 0).all()  # the sky head runs per ray in its own kernel
+
+
+@pytest.mark.parametrize("tau,bf16,tol", [(4, False, 2e-6), (16, False, 2e-6), (4, True, 2e-2)])
+def test_emulated_kernel_dataflow_matches_oracle(tau, bf16, tol):
+    p = O.procedural_satnerf_params(256, tau, seed=3)
+    flat = torch.cat([p[k].reshape(-1) for k in packing.satnerf_param_shapes(256, tau)]).numpy()
+    g = torch.Generator().manual_seed(4)
+    xyz = torch.rand(32, 3, generator=g) * 2 - 1
+    sun = torch.randn(32, 3, generator=g)
+    sun = sun / sun.norm(dim=1, keepdim=True)
+    t = torch.rand(32, tau, generator=g) * 2 - 1
+    ref = O.satnerf_mlp({k: v.double() for k, v in p.items()}, xyz.double(), sun.double(), t.double()).numpy()
+    alb, sig, sv, beta = Emulator(flat, 256, tau, bf16).forward_tile(xyz.double().numpy(), sun.double().numpy(), t.double().numpy())
+    assert np.abs(alb - ref[:, :3]).max() < tol
+    assert np.abs(sig - ref[:, 3]).max() < tol
+    assert np.abs(sv - ref[:, 4]).max() < tol
+    assert np.abs(beta - ref[:, 8]).max() < tol
