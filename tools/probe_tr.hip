@@ -9,9 +9,8 @@ __global__ void probe(uint32_t* out, int mode) {
   int lane = threadIdx.x;
   // every lane points at its own 8-byte chunk: lane L -> halfwords [4L, 4L+4)
   uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)lds + (mode == 0 ? lane * 8 : (lane & 15) * 8 + (lane >> 4) * 512);
-  uint32_t r0, r1;
-  asm volatile("ds_read_b64_tr_b16 %0, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(*(uint64_t*)&r0) , "=v"(r1) : "v"(addr));
-  uint64_t v = *(uint64_t*)&r0;
+  uint64_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
   out[lane * 2] = (uint32_t)v;
   out[lane * 2 + 1] = (uint32_t)(v >> 32);
 }
