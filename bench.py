@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/s of the Sat-NeRF rendering hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 200 --warmup 50
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload = BASELINE.json configs[1]: sat-nerf, fc_units 256, tau 4, 1024 rays x 64 samples PER GPU (weak scaling),
+synthetic GPU-resident rays, reference init weights, noise_std 0, sc_lambda 0, single-pass bf16 MFMA.
+A step = one pass of the hot path over one ray batch:
+  --phase train   : render_rays with grad + SatNerf loss + backward + gradient all-reduce + Adam      (the metric)
+  --phase forward : render_rays under no_grad (the batched_inference path)
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the fused MLP) from HIP events recorded around
+its launches inside the timed region; `cpu_baseline` times the CPU oracle (a port of the reference's PyTorch path) on the
+host cores for a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_POINT = 1318912          # 2 x 659,456 MAC, every Linear layer of SatNeRF(feat 256, tau 4)
+MFMA_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step")
+    ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--mode", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--phase", default=None, choices=["train", "forward"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(phase, n_rays, n_samples, budget_s=12.0):
+    """The oracle (port of the reference's CPU PyTorch path) on this box's host cores, bounded sample."""
+    from oracle import satnerf_oracle as O
+
+    cores = os.cpu_count() or 1
+    args = O.default_args(n_samples=n_samples)
+    n = min(n_rays, 256)
+    rays, ts = O.synthetic_rays(n)
+    params = O.procedural_satnerf_params(256, 4, seed=1)
+    emb = O.procedural_uniform((30, 4), 1.0, 7)
+    if phase == "train":
+        for v in params.values():
+            v.requires_grad_(True)
+        emb.requires_grad_(True)
+    target = torch.rand(n, 3)
+
+    def one():
+        if phase == "train":
+            res = O.render_rays({"coarse": params, "t": emb}, args, rays, ts)
+            O.satnerf_loss(res, target).backward()
+        else:
+            with torch.no_grad():
+                O.render_rays({"coarse": params, "t": emb}, args, rays, ts)
+
+    # torch's intra-op pool does not scale to hundreds of threads on 5120x256 GEMMs: probe a few pool sizes briefly
+    # and time the best one (the thread count actually used is what "cores" reports)
+    best_thr, best_t = 1, float("inf")
+    for thr in sorted({min(cores, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(thr)
+        one()
+        t0 = time.time()
+        one()
+        t = time.time() - t0
+        if t < best_t:
+            best_thr, best_t = thr, t
+    torch.set_num_threads(best_thr)
+    t0, it = time.time(), 0
+    while time.time() - t0 < budget_s and it < 50:
+        one()
+        it += 1
+    dt = (time.time() - t0) / it
+    return {"value": n / dt, "unit": "rays/s", "cores": best_thr, "host_cpus": cores, "kind": "port",
+            "sample": f"{it} x {n} rays x {n_samples} samples, {phase}, torch {torch.__version__} CPU fp32"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from satnerf_amd import ops, rendering
+    from satnerf_amd.models import load_model
+    from oracle import satnerf_oracle as O  # synthetic-ray recipe only
+
+    try:
+        from satnerf_amd import train as train_mod
+    except ImportError:
+        train_mod = None
+    phase = a.phase or ("train" if train_mod is not None else "forward")
+    if phase == "train" and train_mod is None:
+        raise SystemExit("training phase not built")
+
+    args = O.default_args(n_samples=a.samples, mlp_mode=a.mode)
+    torch.manual_seed(0)  # identical init on every rank
+    model = load_model(args).to(dev)
+    emb = torch.nn.Embedding(args.t_embbeding_vocab, args.t_embbeding_tau).to(dev)
+    models = {"coarse": model, "t": emb}
+    # GPU-resident synthetic ray bank, different rays per rank and per step
+    bank_rays, bank_ts = O.synthetic_rays(a.rays * 8, seed=20240628 + rank)
+    bank_rays, bank_ts = bank_rays.to(dev), bank_ts.to(dev)
+    bank_rgb = torch.rand(a.rays * 8, 3, generator=torch.Generator().manual_seed(rank)).to(dev)
+    torch.manual_seed(1234 + rank)  # per-rank sampling jitter
+
+    if phase == "train":
+        stepper = train_mod.Trainer(models, args, world_size=world)
+
+        def step(i):
+            s = (i % 8) * a.rays
+            stepper.step(bank_rays[s:s + a.rays], bank_ts[s:s + a.rays], bank_rgb[s:s + a.rays])
+    else:
+        def step(i):
+            s = (i % 8) * a.rays
+            with torch.no_grad():
+                rendering.render_rays(models, args, bank_rays[s:s + a.rays], bank_ts[s:s + a.rays])
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    timer = ops.KernelTimer()
+    ops.kernel_timer = timer
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    ops.kernel_timer = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    if rank != 0:
+        return
+
+    ms_step = dt / a.steps * 1e3
+    value = a.rays * world * a.steps / dt
+    points = a.rays * a.samples
+    k_ms = timer.mean_ms("mlp_fwd")
+    achieved = points * FLOP_PER_POINT / (k_ms * 1e-3) / 1e12
+    out = {
+        "metric": "training rays/sec (64 samples/ray)" if phase == "train" else "inference rays/sec (64 samples/ray, render_rays no_grad)",
+        "value": value, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.mode == "bf16" else "bf16x3",
+        "data": "synthetic", "phase": phase,
+        "config": {"workload": f"BASELINE configs[1]: sat-nerf fc_units=256 tau=4, {a.rays} rays x {a.samples} samples per GPU, "
+                               f"noise_std=0 sc_lambda=0 n_importance=0, mlp_mode={a.mode}", "rays_per_gpu": a.rays,
+                   "n_samples": a.samples, "parallelism": f"dp{world}"},
+        "roofline": {"bound": "mfma", "kernel": "satnerf_fwd_kernel (fused MLP forward)", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                     "flop_per_launch": points * FLOP_PER_POINT, "kernel_ms": k_ms},
+    }
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(phase, a.rays, a.samples)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

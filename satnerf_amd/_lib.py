@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsatrender.so")
+LIB_PATH = os.environ.get("SATRENDER_LIB") or os.path.join(_HERE, "csrc", "libsatrender.so")  # env override: A/B builds
 
 MODE_BF16 = 1
 MODE_BF16X3 = 3

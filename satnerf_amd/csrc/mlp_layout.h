@@ -34,36 +34,42 @@ constexpr int kMTH = kHalf / 32;  // output tiles of a head-wide layer (4)
 
 constexpr int aux_steps(int tau) { return (8 + ((tau + 7) / 8) * 8 + 15) / 16; }  // tau<=8 -> 1, tau<=24 -> 2
 
-// forward stream: chunk list in consumption order
+// forward stream: chunk list in consumption order.  After the trunk each 128-wide hidden vector is folded into the
+// 5-row output head right after it is produced, so at most one hidden vector is live beside `feats`:
+//   G1 (feats, sigma) | G2r (rgb hidden) | Hr | G2s (sun hidden 1) | S2 | S3 | Hs | G2b (beta hidden) | Hb (+aux: biases)
 template <int AUXS>
 struct FwdStream {
   static constexpr int SLOTP = 16 + AUXS;  // pieces per ring slot
+  static constexpr int NSTAGE = 10;
   static constexpr int N_TRUNK = kTrunkLayers * kMT;
-  static constexpr int N_G1 = kMT + 1;       // feats (8 tiles) + sigma tile
-  static constexpr int N_G2 = 3 * kMTH;      // rgb1 | sun1 | beta1
-  static constexpr int N_S = kMTH;           // sun2, sun3
-  static constexpr int H_PIECES = 3 * kHS + AUXS;
-  static constexpr int N_H = (H_PIECES + SLOTP - 1) / SLOTP;
-  static constexpr int G_G1 = N_TRUNK, G_G2 = G_G1 + N_G1, G_S2 = G_G2 + N_G2, G_S3 = G_S2 + N_S, G_H = G_S3 + N_S;
-  static constexpr int NCH = G_H + N_H;
+  static constexpr int cnt(int st) {
+    constexpr int c[NSTAGE] = {kTrunkLayers * kMT, kMT + 1, kMTH, 1, kMTH, kMTH, kMTH, 1, kMTH, 1};
+    return c[st];
+  }
+  static constexpr int size(int st) {
+    constexpr int z[NSTAGE] = {16 + AUXS, 16 + AUXS, 16 + AUXS, kHS, 16 + AUXS, kHS + AUXS, kHS + AUXS, kHS, 16 + AUXS, kHS + AUXS};
+    return z[st];
+  }
+  static constexpr int first(int st) {  // global index of the stage's first chunk
+    int g = 0;
+    for (int k = 0; k < st; ++k) g += cnt(k);
+    return g;
+  }
+  static constexpr int G_G1 = N_TRUNK, G_G2R = G_G1 + kMT + 1, G_HR = G_G2R + kMTH, G_G2S = G_HR + 1, G_S2 = G_G2S + kMTH,
+                       G_S3 = G_S2 + kMTH, G_HS = G_S3 + kMTH, G_G2B = G_HS + 1, G_HB = G_G2B + kMTH;
+  static constexpr int NCH = G_HB + 1;
   static constexpr int np(int g) {
     if (g < 0 || g >= NCH) return 0;
-    if (g < G_S2) return SLOTP;
-    if (g < G_H) return kHS + AUXS;
-    int k = g - G_H;
-    int left = H_PIECES - k * SLOTP;
-    return left > SLOTP ? SLOTP : left;
+    int st = 0;
+    while (g >= first(st) + cnt(st)) ++st;
+    return size(st);
   }
   static constexpr long offset_pieces(int g) {  // pieces preceding chunk g in the stream
     long n = 0;
     for (int c = 0; c < g; ++c) n += np(c);
     return n;
   }
-  static constexpr long total_pieces() {
-    long n = 0;
-    for (int g = 0; g < NCH; ++g) n += np(g);
-    return n;
-  }
+  static constexpr long total_pieces() { return offset_pieces(NCH); }
 };
 
 // activations saved per 32-point tile in training mode, as whole B-fragment registers

@@ -14,6 +14,25 @@ from . import _lib
 MODES = {"bf16": _lib.MODE_BF16, "bf16x3": _lib.MODE_BF16X3}
 
 
+class KernelTimer:
+    """Brackets selected kernel launches with HIP events on torch's current stream (bench.py's roofline leg)."""
+
+    def __init__(self):
+        self.spans = []
+
+    def span(self, name):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.spans.append((name, e0, e1))
+        return e0, e1
+
+    def mean_ms(self, name):
+        t = [a.elapsed_time(b) for n, a, b in self.spans if n == name]
+        return sum(t) / len(t) if t else None
+
+
+kernel_timer = None  # set to a KernelTimer to time the fused-MLP launches
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -97,8 +116,13 @@ def satnerf_mlp(org, direction, sun, z, temb, ts, n_points, n_samples, feat, tau
     sun_v = torch.empty(n_points, dtype=torch.float32, device=dev)
     beta = torch.empty(n_points, dtype=torch.float32, device=dev)
     inp = _lib.MlpInputs(_p(org), so, _p(direction), sd, _p(sun), ss, _p(z), _p(temb), _p(ts), n_points, n_samples)
+    ev = kernel_timer.span("mlp_fwd") if kernel_timer is not None else None
+    if ev:
+        ev[0].record()
     _lib.call("sr_satnerf_mlp_fwd", C.byref(inp), feat, tau, MODES[mode], _p(stream_hi), _p(stream_lo), _p(_chk(l0, "l0")), _p(albedo), _p(sigma),
               _p(sun_v), _p(beta), _p(acts), _stream())
+    if ev:
+        ev[1].record()
     return albedo, sigma, sun_v, beta
 
 

@@ -146,29 +146,34 @@ def forward_maps(feat=256, tau=4):
     g1.put_block(feat, "sigma_from_xyz.0.weight", 1, 0, feat, 0, 1.0)
     g1.put_aux(feat, "sigma_from_xyz.0.bias", 1, _Mat.AUX_ONE, None, 1.0)
     mats.append(g1)
-    g2 = _Mat(3 * half, feat, auxs, offsets)  # rgb hidden | sun hidden 1 | beta hidden
-    g2.put_block(0, "rgb_from_xyzdir.0.weight", half, 0, feat, 0, c)
-    g2.put_aux(0, "rgb_from_xyzdir.0.bias", half, _Mat.AUX_ONE, None, c)
-    g2.put_block(half, "sun_v_net.0.weight", half, 0, feat, 0, c)
-    g2.put_aux(half, "sun_v_net.0.bias", half, _Mat.AUX_ONE, None, c)
-    g2.put_aux(half, "sun_v_net.0.weight", half, _Mat.AUX_SUN, [feat, feat + 1, feat + 2], c)  # cat([feats, sun]) :199
-    g2.put_block(2 * half, "beta_from_xyz.0.weight", half, 0, feat, 0, c)
-    g2.put_aux(2 * half, "beta_from_xyz.0.bias", half, _Mat.AUX_ONE, None, c)
-    g2.put_aux(2 * half, "beta_from_xyz.0.weight", half, _Mat.AUX_T, [feat + i for i in range(tau)], c)  # cat([feats, t]) :204
-    mats.append(g2)
+    def hidden(name, aux_col=None, aux_cols=None):  # a 128-row hidden layer on [feats; aux]
+        m = _Mat(half, feat, auxs, offsets)
+        m.put_block(0, name + ".weight", half, 0, feat, 0, c)
+        m.put_aux(0, name + ".bias", half, _Mat.AUX_ONE, None, c)
+        if aux_col is not None:
+            m.put_aux(0, name + ".weight", half, aux_col, aux_cols, c)
+        return m
+
+    def head(name, row0, n_rows, with_bias):  # rows of the 5-row output tile fed by one hidden vector
+        m = _Mat(32, half, auxs if with_bias else 0, offsets)
+        m.put_block(row0, name + ".weight", n_rows, 0, half, 0, 1.0)
+        return m
+
+    mats.append(hidden("rgb_from_xyzdir.0"))
+    mats.append(head("rgb_from_xyzdir.2", 0, 3, False))  # rows 0..2: albedo logits
+    mats.append(hidden("sun_v_net.0", _Mat.AUX_SUN, [feat, feat + 1, feat + 2]))  # cat([feats, sun]) :199
     for j in (2, 4):  # sun_v_net.2, sun_v_net.4
         m = _Mat(half, half, auxs, offsets)
         m.put_block(0, f"sun_v_net.{j}.weight", half, 0, half, 0, c)
         m.put_aux(0, f"sun_v_net.{j}.bias", half, _Mat.AUX_ONE, None, c)
         mats.append(m)
-    hm = _Mat(32, 3 * half, auxs, offsets)  # rows 0..2 albedo logits, 3 sun-visibility logit, 4 beta pre-softplus
-    hm.put_block(0, "rgb_from_xyzdir.2.weight", 3, 0, half, 0, 1.0)
-    hm.put_aux(0, "rgb_from_xyzdir.2.bias", 3, _Mat.AUX_ONE, None, 1.0)
-    hm.put_block(3, "sun_v_net.6.weight", 1, half, half, 0, 1.0)
-    hm.put_aux(3, "sun_v_net.6.bias", 1, _Mat.AUX_ONE, None, 1.0)
-    hm.put_block(4, "beta_from_xyz.2.weight", 1, 2 * half, half, 0, 1.0)
-    hm.put_aux(4, "beta_from_xyz.2.bias", 1, _Mat.AUX_ONE, None, 1.0)
-    mats.append(hm)
+    mats.append(head("sun_v_net.6", 3, 1, False))  # row 3: sun-visibility logit
+    mats.append(hidden("beta_from_xyz.0", _Mat.AUX_T, [feat + i for i in range(tau)]))  # cat([feats, t]) :204
+    hb = head("beta_from_xyz.2", 4, 1, True)  # row 4: beta pre-softplus; the aux k-step carries all five biases
+    hb.put_aux(0, "rgb_from_xyzdir.2.bias", 3, _Mat.AUX_ONE, None, 1.0)
+    hb.put_aux(3, "sun_v_net.6.bias", 1, _Mat.AUX_ONE, None, 1.0)
+    hb.put_aux(4, "beta_from_xyz.2.bias", 1, _Mat.AUX_ONE, None, 1.0)
+    mats.append(hb)
     parts = [_serialize(m) for m in mats]
     idx = np.concatenate([p[0] for p in parts]).astype(np.int32)
     scale = np.concatenate([p[1] for p in parts]).astype(np.float32)

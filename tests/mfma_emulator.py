@@ -81,10 +81,15 @@ class Emulator:
         softplus = lambda v: np.where(v > 20, v, np.log1p(np.exp(np.minimum(v, 20))))  # noqa: E731
         sigmoid = lambda v: 1 / (1 + np.exp(-v))  # noqa: E731
         sigma = softplus(sig_acc[:32, 0])
-        hid = self._stage(feats, aux, 12, sin_rev)
-        s2 = self._stage(hid[8:16], aux, 4, sin_rev)
+        c = np.zeros((64, 16))
+        rgbh = self._stage(feats, aux, 4, sin_rev)
+        c += self._tile(rgbh)
+        s1 = self._stage(feats, aux, 4, sin_rev)
+        s2 = self._stage(s1, aux, 4, sin_rev)
         s3 = self._stage(s2, aux, 4, sin_rev)
-        acc = self._tile(hid[0:8] + s3 + hid[16:24] + aux)
+        c += self._tile(s3)
+        e1 = self._stage(feats, aux, 4, sin_rev)
+        acc = c + self._tile(e1 + aux)
         assert self.cur == self.stream.shape[0], (self.cur, self.stream.shape)
         albedo = sigmoid(acc[:32, 0:3]) * 1.002 - 0.001
         return albedo, sigma, sigmoid(acc[:32, 3]), softplus(acc[32:, 0])
