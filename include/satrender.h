@@ -39,6 +39,7 @@ const char* sr_last_error(void);
 int64_t sr_fwd_stream_elems(int feat, int tau);  /* bf16 elements of the forward stream (per hi/lo plane) */
 int64_t sr_bwd_stream_elems(int feat, int tau);  /* bf16 elements of the transposed (dX) stream          */
 int64_t sr_act_elems_per_tile(int feat);         /* bf16 elements saved per 32-point tile in training     */
+int64_t sr_dpre_elems_per_tile(int feat);        /* bf16 elements of pre-activation gradients per tile    */
 
 /* ---- weight packing:  replaces nothing in the reference (its weights feed addmm directly) ---------
  * out_hi[i] = bf16_rne(src[idx[i]] * scale[i]);  out_lo[i] = bf16_rne(src[idx[i]]*scale[i] - out_hi[i])
@@ -49,9 +50,10 @@ int sr_pack_stream(const float* src, const int32_t* idx, const float* scale, int
 /* out[i] = src[idx[i]] * scale[i] in fp32 (idx < 0 -> 0): builds the fc_net.0 table `l0` of sr_satnerf_mlp_fwd */
 int sr_gather_scale_f32(const float* src, const int32_t* idx, const float* scale, int64_t n, float* out, void* stream);
 
-/* grad[e] (+)= gscale[e] * dstream[gidx[e]]  -- the inverse gather of sr_pack_stream for weight grads */
-int sr_unpack_grads(const float* dstream, const int32_t* gidx, const float* gscale, int64_t n_params,
-                    float* grad, int accumulate, void* stream);
+/* grad[e] (+)= gscale[e] * sum_s partial[s*split_stride + gidx[e]]  (gidx < 0: left untouched) -- reduces the split-K
+ * slices of sr_satnerf_wgrad and scatters into the flat parameter-gradient buffer (inverse of sr_pack_stream's gather) */
+int sr_unpack_grads(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, int n_split,
+                    int64_t split_stride, float* grad, int accumulate, void* stream);
 
 /* ---- stratified sampling: rendering.py:62-78 -----------------------------------------------------
  * rays (N, ray_stride>=8) with near at column 6, far at column 7; u (N,S) in [0,1) -> z_vals (N,S). */
@@ -89,6 +91,25 @@ typedef struct sr_mlp_inputs {
 int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, int mode, const uint16_t* stream_hi,
                        const uint16_t* stream_lo, const float* l0, float* albedo, float* sigma, float* sun_v,
                        float* beta, uint16_t* acts, void* stream);
+
+/* ---- backward of the fused MLP: replaces autograd through SatNeRF.forward (models/satnerf.py:156-208) ------------
+ * sr_satnerf_mlp_bwd: data-gradient chain.  Inputs: the forward's saved `acts`, its four outputs and the gradients of
+ * those outputs (g_* may be NULL = 0); bwd_stream = packed transposed weights (sr_pack_stream with
+ * packing.backward_maps).  Outputs: dpre (sr_dpre_elems_per_tile(feat) * ceil(P/32) bf16) and d_t (P,tau) fp32, the
+ * gradient w.r.t. each point's embedding vector (NULL to skip).
+ * sr_satnerf_wgrad: weight-gradient GEMMs dpre x acts over all points, 128x128 blocks listed in `blocks`
+ * (n_blocks x 8 int32) x n_split point slices -> partial (n_split, n_blocks, 128, 128) fp32; reduce with sr_unpack_grads. */
+int sr_satnerf_mlp_bwd(int feat, int tau, int64_t n_points, const uint16_t* bwd_stream, const uint16_t* acts,
+                       const float* albedo, const float* sigma, const float* sun_v, const float* beta, const float* g_albedo,
+                       const float* g_sigma, const float* g_sun_v, const float* g_beta, uint16_t* dpre, float* d_t, void* stream);
+int sr_satnerf_wgrad(int feat, int tau, int64_t n_points, const uint16_t* dpre, const uint16_t* acts, const int32_t* blocks,
+                     int n_blocks, int n_split, float* partial, void* stream);
+
+/* parameter gradients of the sky head (atomicAdd into g_*; zero them first) and of the embedding table
+ * g_emb[ts[r]] += sum_j d_t[r*S + j] (nn.Embedding backward, rendering.py:100) */
+int sr_sky_bwd(const float* sun, int sun_stride, int64_t n, int hidden, const float* w1, const float* b1, const float* w2,
+               const float* sky, const float* d_sky, float* g_w1, float* g_b1, float* g_w2, float* g_b2, void* stream);
+int sr_embedding_bwd(const float* d_t, const int64_t* ts, int64_t n_rays, int n_samples, int tau, float* g_emb, void* stream);
 
 /* ---- sigma -> alpha compositing: models/satnerf.py:52-70 ------------------------------------------
  * noise may be NULL (== noise_std 0).  sky is per ray (N,3).  Outputs: weights, transparency (N,S),

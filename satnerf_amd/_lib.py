@@ -30,7 +30,12 @@ SIGNATURES = {
     "sr_bwd_stream_elems": (_i64, [_i, _i]),
     "sr_act_elems_per_tile": (_i64, [_i]),
     "sr_pack_stream": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
-    "sr_unpack_grads": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _vp]),
+    "sr_dpre_elems_per_tile": (_i64, [_i]),
+    "sr_unpack_grads": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _vp, _i, _vp]),
+    "sr_satnerf_mlp_bwd": (_i, [_i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sr_satnerf_wgrad": (_i, [_i, _i, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "sr_sky_bwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sr_embedding_bwd": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "sr_gather_scale_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "sr_ray_sample_fwd": (_i, [_vp, _i, _vp, _i64, _i, _vp, _vp]),
     "sr_sky_fwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -45,8 +45,3 @@ extern "C" int64_t sr_act_elems_per_tile(int feat) {
   if (feat != kFeat) return -1;
   return (int64_t)act_ksteps(2) * 64 * 8;  // sized for the larger aux layout
 }
-
-extern "C" int64_t sr_bwd_stream_elems(int feat, int tau) {
-  (void)feat, (void)tau;
-  return -1;  // backward stream not built yet
-}

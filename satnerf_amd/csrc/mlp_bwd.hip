@@ -1,0 +1,248 @@
+// Fused Sat-NeRF MLP backward, data-gradient chain ("dX") for gfx950.
+//
+// Replaces autograd's backward through SatNeRF.forward (models/satnerf.py:156-208) for every sample point: starting
+// from the gradients of the four per-point outputs it walks the network in reverse, register-resident exactly like the
+// forward kernel (swapped orientation, 32 points per wave, transposed weights streamed L2 -> LDS ring, see mlp_layout.h),
+// and writes the gradient of EVERY pre-activation, as bf16 B fragments, to the `dpre` workspace; the weight-gradient GEMMs
+// (wgrad.hip) then contract dpre with the activations the forward pass saved.  No gradient flows to xyz / z / rays
+// (inputs are data, rendering.py:122-124 detaches the resampled depths), so fc_net.0 needs no dX.
+//
+// sin stages: the forward saved the pre-activation PHASE (unorm16 revolutions); d pre = d out * cos(2 pi phase) (for
+// fc_net.0 the factor w0 = 30 is applied to its weight gradient by the gather scale, packing.backward_maps).
+// Arithmetic: single-pass bf16 MFMA with fp32 accumulation (mixed-precision backward) in both numeric modes.
+#include "mlp_device.h"
+#include "mlp_params.h"
+
+namespace sr {
+
+using BS = BwdStream;
+constexpr int kBSlot = BS::SLOTP * 1024;  // ring slot bytes
+
+template <int G>
+__device__ __forceinline__ void bchunk_enter(char* ring, const char* stream, int wave, int lane) {
+  constexpr int later = [] {
+    int n = 0;
+    for (int c = 1; c < kD; ++c) n += min_loads<1>(BS::np(G + c));
+    return n;
+  }();
+  wait_then_barrier<later>();
+  if constexpr (G + kD < BS::NCH) {
+    constexpr long off = BS::offset_pieces(G + kD) * 1024L;
+    constexpr int slot = (G + kD) % kNSLOT;
+    issue_chunk<1, BS::np(G + kD)>(stream, nullptr, off, ring + slot * kBSlot, wave, lane);
+  }
+}
+
+__device__ __forceinline__ float phase_cos(uint32_t w, int half) {
+  const uint32_t u = half ? (w >> 16) : (w & 0xffffu);
+  return __builtin_amdgcn_cosf((float)u * (1.0f / 65535.0f));  // v_cos_f32 takes revolutions
+}
+
+// 16 accumulator values (fragments 2T, 2T+1 of the stage's input vector) -> [x cos(phase)] -> two bf16 fragments
+template <bool COS>
+__device__ __forceinline__ void bpack(const f32x16& acc, const uint4& p0, const uint4& p1, uint4& o0, uint4& o1) {
+  float v[16];
+  const uint32_t pw[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+  for (int g = 0; g < 16; ++g) v[g] = COS ? acc[g] * phase_cos(pw[g >> 1], g & 1) : acc[g];
+  o0 = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+  o1 = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15]));
+}
+
+// one output tile: acc = sum_i A(piece P0+i of the slot) x in[i]
+template <int KIN>
+__device__ __forceinline__ f32x16 btile(const char* slot, int p0, const uint4 (&in)[KIN], int lane) {
+  f32x16 acc = {0};
+#pragma unroll
+  for (int i = 0; i < KIN; ++i) {
+    const uint4 a = *reinterpret_cast<const uint4*>(slot + (p0 + i) * 1024 + lane * 16);
+    acc = mfma(a, in[i], acc);
+  }
+  return acc;
+}
+
+// generic transposed stage: NCHUNK chunks of TPC tiles, each KIN pieces; tile t -> out[O0+2t], out[O0+2t+1], stored to dst
+template <int KIN, int TPC, int NCHUNK, int G0, bool COS, int NOUT, int O0 = 0>
+__device__ __forceinline__ void bstage(const uint4 (&in)[KIN], uint4 (&out)[NOUT], char* ring, const char* stream, int wave, int lane,
+                                       const uint4* phase, uint4* dst) {
+  static_for<NCHUNK>([&](auto cc) {
+    constexpr int c = decltype(cc)::value, g = G0 + c;
+    static_assert(BS::np(g) == TPC * KIN, "backward stream geometry mismatch");
+    bchunk_enter<g>(ring, stream, wave, lane);
+    const char* slot = ring + (g % kNSLOT) * kBSlot;
+    static_for<TPC>([&](auto tc) {
+      constexpr int tt = decltype(tc)::value, t = c * TPC + tt, o = O0 + 2 * t;
+      uint4 p0 = {}, p1 = {};
+      if constexpr (COS) p0 = phase[(2 * t) * 64], p1 = phase[(2 * t + 1) * 64];
+      const f32x16 acc = btile<KIN>(slot, tt * KIN, in, lane);
+      bpack<COS>(acc, p0, p1, out[o], out[o + 1]);
+      dst[(2 * t) * 64] = out[o];
+      dst[(2 * t + 1) * 64] = out[o + 1];
+    });
+  });
+}
+
+__global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, pl = lane & 31;
+  const char* stream = prm.stream;
+  const int A = prm.auxs, AK = act_ksteps(prm.auxs);
+
+#pragma unroll
+  for (int g = 0; g < kD; ++g) {
+    if (g == 0) issue_chunk<1, BS::np(0)>(stream, nullptr, 0, ring, wave, lane);
+    if (g == 1) issue_chunk<1, BS::np(1)>(stream, nullptr, BS::offset_pieces(1) * 1024L, ring + kBSlot, wave, lane);
+    if (g == 2) issue_chunk<1, BS::np(2)>(stream, nullptr, BS::offset_pieces(2) * 1024L, ring + 2 * kBSlot, wave, lane);
+  }
+
+  const long tile = (long)blockIdx.x * 8 + wave;
+  const long pt = tile * 32 + pl;
+  const bool valid = pt < prm.n_points;
+  const uint4* acts = prm.acts + tile * AK * 64 + lane;   // + fragment * 64
+  uint4* dpre = prm.dpre + tile * kDpFrags * 64 + lane;   // + fragment * 64
+
+  // ---- gradients of the head pre-activations (rows 0..2 albedo logits, 3 sun logit, 4 beta; sigma separately) ----------
+  uint4 dhead[1], dsig;
+  {
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sg = 0.f;
+    if (valid) {
+      if (h == 0) {
+        if (prm.g_albedo) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float s = (prm.albedo[pt * 3 + c] + 0.001f) * (1.0f / 1.002f);  // sigmoid output before the rgb_padding affine
+            v[c] = prm.g_albedo[pt * 3 + c] * 1.002f * s * (1.0f - s);
+          }
+        }
+        if (prm.g_sun) {
+          const float s = prm.sun_v[pt];
+          v[3] = prm.g_sun[pt] * s * (1.0f - s);
+        }
+        if (prm.g_sigma) sg = prm.g_sigma[pt] * (1.0f - expf(-prm.sigma[pt]));  // softplus' = 1 - exp(-softplus)
+      } else if (prm.g_beta) {
+        v[0] = prm.g_beta[pt] * (1.0f - expf(-prm.beta[pt]));
+      }
+    }
+    dhead[0] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    dsig = make_uint4(pack_bf16x2(sg, 0.f), 0u, 0u, 0u);
+    dpre[kDpHead * 64] = dhead[0];
+    dpre[kDpSigma * 64] = dsig;
+  }
+
+  // ---- bH: d_head -> d rgb-hidden | d sun-hidden-3 | d beta-hidden (12 tiles x 1 piece, one chunk) --------------------
+  uint4 d_rgbh[kHS], d_s3[kHS], d_e1[kHS];
+  {
+    bchunk_enter<BS::G_H>(ring, stream, wave, lane);
+    const char* slot = ring + (BS::G_H % kNSLOT) * kBSlot;
+    static_for<3 * kMTH>([&](auto tc) {
+      constexpr int T = decltype(tc)::value, part = T / kMTH, t = T % kMTH;
+      constexpr int act0 = part == 0 ? kActRgbh : (part == 1 ? kActS3 : kActE1);
+      constexpr int dp0 = part == 0 ? kDpRgbh : (part == 1 ? kDpS3 : kDpE1);
+      const uint4 p0 = acts[(A + act0 + 2 * t) * 64], p1 = acts[(A + act0 + 2 * t + 1) * 64];
+      const f32x16 acc = btile<1>(slot, T, dhead, lane);
+      uint4 o0, o1;
+      bpack<true>(acc, p0, p1, o0, o1);
+      if constexpr (part == 0) d_rgbh[2 * t] = o0, d_rgbh[2 * t + 1] = o1;
+      else if constexpr (part == 1) d_s3[2 * t] = o0, d_s3[2 * t + 1] = o1;
+      else d_e1[2 * t] = o0, d_e1[2 * t + 1] = o1;
+      dpre[(dp0 + 2 * t) * 64] = o0;
+      dpre[(dp0 + 2 * t + 1) * 64] = o1;
+    });
+  }
+  // ---- sun chain: bS3 (d s3 -> d s2), bS2 (d s2 -> d s1) -------------------------------------------------------------
+  uint4 d_g2[3 * kHS];  // [d rgbh | d s1 | d e1] : the input of bG2
+  {
+    uint4 d_s2[kHS], d_s1[kHS];
+    bstage<kHS, 2, 2, BS::G_S3, true, kHS>(d_s3, d_s2, ring, stream, wave, lane, acts + (A + kActS2) * 64, dpre + kDpS2 * 64);
+    bstage<kHS, 2, 2, BS::G_S2, true, kHS>(d_s2, d_s1, ring, stream, wave, lane, acts + (A + kActS1) * 64, dpre + kDpS1 * 64);
+#pragma unroll
+    for (int i = 0; i < kHS; ++i) d_g2[i] = d_rgbh[i], d_g2[kHS + i] = d_s1[i], d_g2[2 * kHS + i] = d_e1[i];
+  }
+  // ---- bG2: -> d feats (identity stage), bDT: d beta-hidden -> d t (embedding columns) ------------------------------
+  uint4 d_g1[kKS + 1];  // [d feats (16) | d sigma_pre (1)] : the input of bG1
+  {
+    uint4 d_feats[kKS];
+    bstage<3 * kHS, 1, kMT, BS::G_G2, false, kKS>(d_g2, d_feats, ring, stream, wave, lane, nullptr, dpre + kDpFeats * 64);
+    bchunk_enter<BS::G_DT>(ring, stream, wave, lane);
+    const f32x16 acc = btile<kHS>(ring + (BS::G_DT % kNSLOT) * kBSlot, 0, d_e1, lane);
+    if (valid && prm.d_t) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int row = (g & 3) + 8 * (g >> 2) + 4 * h;  // = embedding component
+        if (row < prm.tau) prm.d_t[pt * prm.tau + row] = acc[g];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kKS; ++i) d_g1[i] = d_feats[i];
+    d_g1[kKS] = dsig;
+  }
+  // ---- bG1: -> d a7, x cos(phase a7) = d pre_7 ----------------------------------------------------------------------
+  uint4 cur[kKS], nxt[kKS];
+  bstage<kKS + 1, 1, kMT, BS::G_G1, true, kKS>(d_g1, cur, ring, stream, wave, lane, acts + (A + kActA0 + 7 * kKS) * 64,
+                                               dpre + (kDpL + 7 * kKS) * 64);
+  // ---- bL7 .. bL2 (runtime loop), bL1 (peeled: its chunks are the tail of the stream) --------------------------------
+  constexpr long offL = BS::offset_pieces(BS::G_L);
+#pragma unroll 1
+  for (int l = 7; l >= 2; --l) {
+    const long cbase = (long)(7 - l) * kMT;
+    const uint4* ph = acts + (A + kActA0 + (l - 1) * kKS) * 64;
+    uint4* dst = dpre + (kDpL + (l - 1) * kKS) * 64;
+    static_for<kMT>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      wait_then_barrier<(kD - 1) * min_loads<1>(kKS)>();
+      issue_chunk<1, kKS>(stream, nullptr, (offL + (cbase + t + kD) * kKS) * 1024L, ring + ((BS::G_L + t + kD) % kNSLOT) * kBSlot, wave, lane);
+      const uint4 p0 = ph[(2 * t) * 64], p1 = ph[(2 * t + 1) * 64];
+      const f32x16 acc = btile<kKS>(ring + ((BS::G_L + t) % kNSLOT) * kBSlot, 0, cur, lane);
+      bpack<true>(acc, p0, p1, nxt[2 * t], nxt[2 * t + 1]);
+      dst[(2 * t) * 64] = nxt[2 * t];
+      dst[(2 * t + 1) * 64] = nxt[2 * t + 1];
+    });
+#pragma unroll
+    for (int i = 0; i < kKS; ++i) cur[i] = nxt[i];
+  }
+  bstage<kKS, 1, kMT, BS::G_L + 6 * kMT, true, kKS>(cur, nxt, ring, stream, wave, lane, acts + (A + kActA0) * 64, dpre + kDpL * 64);
+}
+
+}  // namespace sr
+
+using namespace sr;
+
+extern "C" int sr_satnerf_mlp_bwd(int feat, int tau, int64_t n_points, const uint16_t* bwd_stream, const uint16_t* acts, const float* albedo,
+                                  const float* sigma, const float* sun_v, const float* beta, const float* g_albedo, const float* g_sigma,
+                                  const float* g_sun_v, const float* g_beta, uint16_t* dpre, float* d_t, void* stream) {
+  SR_REQUIRE(feat == kFeat, "sr_satnerf_mlp_bwd: feat=%d unsupported (this build handles %d)", feat, kFeat);
+  SR_REQUIRE(tau >= 1 && tau <= 24, "sr_satnerf_mlp_bwd: tau=%d unsupported (1..24)", tau);
+  SR_REQUIRE(bwd_stream && acts && dpre && albedo && sigma && sun_v && beta, "sr_satnerf_mlp_bwd: null pointer argument");
+  if (n_points <= 0) return 0;
+  BwdParams p;
+  p.g_albedo = g_albedo, p.g_sigma = g_sigma, p.g_sun = g_sun_v, p.g_beta = g_beta;
+  p.albedo = albedo, p.sigma = sigma, p.sun_v = sun_v, p.beta = beta;
+  p.acts = (const uint4*)acts, p.dpre = (uint4*)dpre, p.d_t = d_t;
+  p.stream = (const char*)bwd_stream;
+  p.n_points = n_points, p.tau = tau, p.auxs = aux_steps(tau);
+  const size_t lds = (size_t)kNSLOT * kBSlot;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)satnerf_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  const long tiles = (n_points + 31) / 32;
+  hipLaunchKernelGGL(satnerf_bwd_kernel, dim3((unsigned)((tiles + 7) / 8)), dim3(512), lds, (hipStream_t)stream, p);
+  return check_launch("satnerf_bwd_kernel");
+}
+
+extern "C" int64_t sr_bwd_stream_elems(int feat, int tau) {
+  if (feat != kFeat || tau < 1 || tau > 24) return -1;
+  return BwdStream::total_pieces() * 512;
+}
+
+extern "C" int64_t sr_dpre_elems_per_tile(int feat) {
+  if (feat != kFeat) return -1;
+  return (int64_t)kDpFrags * 64 * 8;
+}

@@ -1,0 +1,103 @@
+// Device-side building blocks shared by the fused forward and backward (dX) MLP kernels: the LDS ring fed by
+// asm LDS-DMA, the counted-vmcnt chunk protocol, MFMA wrappers and compile-time loops.
+#pragma once
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include "mlp_layout.h"
+
+namespace sr {
+
+constexpr int kD = 3;      // prefetch distance, chunks
+constexpr int kNSLOT = 4;  // LDS ring slots (= kD + 1)
+// A/B on MI355X (profiles/r01_ab_variants.txt): batching the A-fragment reads ahead of the MFMAs does not pay at two
+// waves per SIMD (82.7 us un-batched vs 84.7 us with 9-deep batches), so the default leaves scheduling to hipcc.
+#ifndef SR_TRUNK_BATCH
+#define SR_TRUNK_BATCH 1
+#endif
+#ifndef SR_HEAD_BATCH
+#define SR_HEAD_BATCH 1
+#endif
+#ifndef SR_SCHEDBAR
+#define SR_SCHED_BARRIER() ((void)0)
+#else
+#define SR_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+constexpr int kBatchTrunk = SR_TRUNK_BATCH;  // A fragments fetched per batch in the trunk
+constexpr int kBatchHead = SR_HEAD_BATCH;   // ... and in the head stages (register pressure is higher there)
+
+template <int NPASS>
+struct Mode {
+  static constexpr int NW = NPASS == 1 ? 8 : 4;   // waves per workgroup
+  static constexpr int NPA = NPASS == 1 ? 1 : 2;  // A planes (hi[, lo])
+  static constexpr int PIECE_BYTES = 1024 * NPA;
+};
+
+template <int NPASS, int N>
+struct Frags {  // N B-fragments (k-steps) of the wave's 32 points
+  uint4 hi[N];
+  uint4 lo[NPASS == 3 ? N : 1];
+};
+
+
+// LDS-DMA through inline asm: hipcc then does not know an LDS write is in flight and does not drain vmcnt before
+// every ds_read (it cannot tell ring slots apart); ordering is ours: counted vmcnt + s_barrier in wait_then_barrier().
+// lds_addr is the wave-uniform LDS byte address (goes to M0); the 64 lanes land at lds_addr + lane*16.
+__device__ __forceinline__ void glds16(const char* gsrc, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_addr)
+      : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+// ---- weight stream: L2 -> LDS ring ------------------------------------------------------------------
+template <int NPASS, int NP>
+__device__ __forceinline__ void issue_chunk(const char* hi, const char* lo, long off, char* slot, int wave, int lane) {
+  constexpr int NW = Mode<NPASS>::NW, NT = NP * Mode<NPASS>::NPA, PER = (NT + NW - 1) / NW;
+  const uint32_t slot_addr = __builtin_amdgcn_readfirstlane(lds_addr_of(slot));
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = wave + k * NW;  // wave-uniform
+    if (i < NT) {
+      const int piece = NPASS == 1 ? i : (i >> 1), plane = NPASS == 1 ? 0 : (i & 1);
+      const char* src = (plane ? lo : hi) + off + piece * 1024 + lane * 16;
+      glds16(src, slot_addr + piece * Mode<NPASS>::PIECE_BYTES + plane * 1024);
+    }
+  }
+}
+
+// loads this wave has certainly issued for a chunk of NP pieces (lower bound over waves)
+template <int NPASS>
+constexpr int min_loads(int np) { return np * Mode<NPASS>::NPA / Mode<NPASS>::NW; }
+
+template <int N>
+__device__ __forceinline__ void wait_then_barrier() {
+  // own LDS-DMA for the chunk about to be consumed has landed (all but the N newest VMEM ops done), every
+  // ds_read of the slot about to be refilled has returned; then rendezvous.
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N > 63 ? 63 : N) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ f32x16 mfma(const uint4& a, const uint4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(integral_constant<int, N-1>{})
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+
+}  // namespace sr

@@ -72,8 +72,57 @@ struct FwdStream {
   static constexpr long total_pieces() { return offset_pieces(NCH); }
 };
 
-// activations saved per 32-point tile in training mode, as whole B-fragment registers
-// (uint4 per (k-step, lane)): aux | a0..a7 (trunk) | feats | rgb_hid sun1 beta_hid | sun2 | sun3
+// activations saved per 32-point tile in training mode, as whole B-fragment registers (uint4 per (fragment, lane)):
+//   aux | a0..a7 (trunk) | feats | rgb_hid sun1 beta_hid | sun2 | sun3
+// sin stages are saved as the unorm16 PHASE of their pre-activation, feats and aux as bf16 values.
 constexpr int act_ksteps(int auxs) { return auxs + 8 * kKS + kKS + 3 * kHS + 2 * kHS; }
+constexpr int kActA0 = 0;                       // + auxs: fragment index of a0 (a_l at kActA0 + 16 l)
+constexpr int kActFeats = 8 * kKS;              // + auxs
+constexpr int kActRgbh = kActFeats + kKS, kActS1 = kActRgbh + kHS, kActE1 = kActS1 + kHS, kActS2 = kActE1 + kHS, kActS3 = kActS2 + kHS;
+
+// pre-activation gradients written by the dX kernel per 32-point tile (bf16 B fragments, forward row-slot order):
+//   d_pre_0..d_pre_7 | d_feats | d_sigma_pre | d_rgbh d_s1 d_e1 | d_s2 | d_s3 | d_head
+constexpr int kDpL = 0, kDpFeats = 8 * kKS, kDpSigma = kDpFeats + kKS, kDpRgbh = kDpSigma + 1, kDpS1 = kDpRgbh + kHS,
+              kDpE1 = kDpS1 + kHS, kDpS2 = kDpE1 + kHS, kDpS3 = kDpS2 + kHS, kDpHead = kDpS3 + kHS, kDpFrags = kDpHead + 1;
+
+// backward (dX) stream: transposed weights, scale 1, chunk list in consumption order.  A chunk is `tiles(st)` output
+// tiles of `ppt(st)` pieces each (pieces of a tile are contiguous); every chunk fits one 24-piece ring slot.
+//   bH (d_head -> d rgbh | d s3 | d e1) | bS3 | bS2 | bG2 ([d rgbh, d s1, d e1] -> d feats) | bDT (d e1 -> d t) |
+//   bG1 ([d feats, d sigma] -> d a7) | bL7 .. bL1 (d pre_l -> d a_{l-1})
+struct BwdStream {
+  static constexpr int SLOTP = 3 * kHS;  // 24 pieces per ring slot
+  static constexpr int NSTAGE = 7;
+  static constexpr int cnt(int st) {
+    constexpr int c[NSTAGE] = {1, 2, 2, kMT, 1, kMT, kTrunkLayers * kMT};
+    return c[st];
+  }
+  static constexpr int tiles(int st) {
+    constexpr int t[NSTAGE] = {3 * kMTH, 2, 2, 1, 1, 1, 1};
+    return t[st];
+  }
+  static constexpr int ppt(int st) {
+    constexpr int z[NSTAGE] = {1, kHS, kHS, 3 * kHS, kHS, kKS + 1, kKS};
+    return z[st];
+  }
+  static constexpr int first(int st) {
+    int g = 0;
+    for (int k = 0; k < st; ++k) g += cnt(k);
+    return g;
+  }
+  static constexpr int G_H = 0, G_S3 = 1, G_S2 = 3, G_G2 = 5, G_DT = G_G2 + kMT, G_G1 = G_DT + 1, G_L = G_G1 + kMT;
+  static constexpr int NCH = G_L + kTrunkLayers * kMT;
+  static constexpr int np(int g) {
+    if (g < 0 || g >= NCH) return 0;
+    int st = 0;
+    while (g >= first(st) + cnt(st)) ++st;
+    return tiles(st) * ppt(st);
+  }
+  static constexpr long offset_pieces(int g) {
+    long n = 0;
+    for (int c = 0; c < g; ++c) n += np(c);
+    return n;
+  }
+  static constexpr long total_pieces() { return offset_pieces(NCH); }
+};
 
 }  // namespace sr

@@ -17,4 +17,22 @@ struct FwdParams {
   int tau;
 };
 
+struct BwdParams {
+  const float* g_albedo;  // upstream gradients of the per-point outputs (any may be null = 0)
+  const float* g_sigma;
+  const float* g_sun;
+  const float* g_beta;
+  const float* albedo;    // forward outputs (activation derivatives of the heads)
+  const float* sigma;
+  const float* sun_v;
+  const float* beta;
+  const uint4* acts;      // saved activations, act_ksteps(auxs) fragments per 32-point tile
+  uint4* dpre;            // out: pre-activation gradients, kDpFrags fragments per tile
+  float* d_t;             // out: (P, tau) gradient of the embedding vector per point (may be null)
+  const char* stream;     // transposed weight stream (bf16)
+  long n_points;
+  int tau;
+  int auxs;
+};
+
 }  // namespace sr

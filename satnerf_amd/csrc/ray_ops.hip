@@ -375,14 +375,57 @@ __global__ void __launch_bounds__(256) gather_scale_kernel(const float* __restri
   out[i] = k >= 0 ? src[k] * scale[i] : 0.f;
 }
 
-__global__ void __launch_bounds__(256) unpack_grads_kernel(const float* __restrict__ dstream, const int* __restrict__ gidx,
-                                                          const float* __restrict__ gscale, long n, float* __restrict__ grad,
-                                                          int accumulate) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int k = gidx[i];
-  const float g = k >= 0 ? dstream[k] * gscale[i] : 0.f;
-  grad[i] = accumulate ? grad[i] + g : g;
+// ---- backward of the per-ray sky head (models/satnerf.py:138-143): parameter gradients only ----------------------------
+// Each block reduces 64 rays in registers (thread = hidden unit) and issues one atomicAdd per parameter.
+__global__ void __launch_bounds__(256) sky_bwd_kernel(const float* __restrict__ sun, int sun_stride, long n, int hidden,
+                                                     const float* __restrict__ w1, const float* __restrict__ b1,
+                                                     const float* __restrict__ w2, const float* __restrict__ sky,
+                                                     const float* __restrict__ d_sky, float* __restrict__ g_w1, float* __restrict__ g_b1,
+                                                     float* __restrict__ g_w2, float* __restrict__ g_b2) {
+  const long r0 = (long)blockIdx.x * 64;
+  const long r1 = r0 + 64 < n ? r0 + 64 : n;
+  for (int k = threadIdx.x; k < hidden; k += 256) {
+    const float wx = w1[k * 3], wy = w1[k * 3 + 1], wz = w1[k * 3 + 2], bb = b1[k];
+    const float v0 = w2[k], v1 = w2[hidden + k], v2 = w2[2 * hidden + k];
+    float a_wx = 0.f, a_wy = 0.f, a_wz = 0.f, a_b = 0.f, a_v0 = 0.f, a_v1 = 0.f, a_v2 = 0.f;
+    for (long r = r0; r < r1; ++r) {
+      const float sx = sun[r * sun_stride], sy = sun[r * sun_stride + 1], sz = sun[r * sun_stride + 2];
+      const float hk = __builtin_fmaf(wz, sz, __builtin_fmaf(wy, sy, __builtin_fmaf(wx, sx, bb)));
+      const float s0 = sky[r * 3], s1 = sky[r * 3 + 1], s2 = sky[r * 3 + 2];
+      const float z0 = d_sky[r * 3] * s0 * (1.f - s0), z1 = d_sky[r * 3 + 1] * s1 * (1.f - s1), z2 = d_sky[r * 3 + 2] * s2 * (1.f - s2);
+      if (hk > 0.f) {
+        a_v0 += z0 * hk, a_v1 += z1 * hk, a_v2 += z2 * hk;
+        const float dh = z0 * v0 + z1 * v1 + z2 * v2;
+        a_b += dh, a_wx += dh * sx, a_wy += dh * sy, a_wz += dh * sz;
+      }
+    }
+    atomicAdd(&g_w1[k * 3], a_wx), atomicAdd(&g_w1[k * 3 + 1], a_wy), atomicAdd(&g_w1[k * 3 + 2], a_wz), atomicAdd(&g_b1[k], a_b);
+    atomicAdd(&g_w2[k], a_v0), atomicAdd(&g_w2[hidden + k], a_v1), atomicAdd(&g_w2[2 * hidden + k], a_v2);
+  }
+  if (threadIdx.x < 3) {
+    const int c = threadIdx.x;
+    float a = 0.f;
+    for (long r = r0; r < r1; ++r) {
+      const float sc = sky[r * 3 + c];
+      a += d_sky[r * 3 + c] * sc * (1.f - sc);
+    }
+    atomicAdd(&g_b2[c], a);
+  }
+}
+
+// ---- embedding gradient (nn.Embedding backward, rendering.py:100): d_emb[ts[r]] += sum_j d_t[r, j, :] ----------------------
+__global__ void __launch_bounds__(256) embedding_bwd_kernel(const float* __restrict__ d_t, const long long* __restrict__ ts, long n_rays,
+                                                           int S, int tau, float* __restrict__ g_emb) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
+  if (r >= n_rays) return;
+  const long row = ts[r];
+  for (int i = 0; i < tau; ++i) {
+    float a = 0.f;
+    for (int j = lane; j < S; j += 64) a += d_t[(r * S + j) * tau + i];
+    a = wave_sum(a);
+    if (lane == 0) atomicAdd(&g_emb[row * tau + i], a);
+  }
 }
 
 }  // namespace sr
@@ -472,11 +515,19 @@ extern "C" int sr_gather_scale_f32(const float* src, const int32_t* idx, const f
   return check_launch("gather_scale_kernel");
 }
 
-extern "C" int sr_unpack_grads(const float* dstream, const int32_t* gidx, const float* gscale, int64_t n_params, float* grad,
-                               int accumulate, void* stream) {
-  SR_REQUIRE(dstream && gidx && gscale && grad, "sr_unpack_grads: null pointer");
-  if (n_params <= 0) return 0;
-  hipLaunchKernelGGL(unpack_grads_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dstream, gidx,
-                     gscale, (long)n_params, grad, accumulate);
-  return check_launch("unpack_grads_kernel");
+extern "C" int sr_sky_bwd(const float* sun, int sun_stride, int64_t n, int hidden, const float* w1, const float* b1, const float* w2,
+                          const float* sky, const float* d_sky, float* g_w1, float* g_b1, float* g_w2, float* g_b2, void* stream) {
+  SR_REQUIRE(sun && w1 && b1 && w2 && sky && d_sky && g_w1 && g_b1 && g_w2 && g_b2, "sr_sky_bwd: null pointer");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(sky_bwd_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, sun, sun_stride, (long)n, hidden, w1,
+                     b1, w2, sky, d_sky, g_w1, g_b1, g_w2, g_b2);
+  return check_launch("sky_bwd_kernel");
+}
+
+extern "C" int sr_embedding_bwd(const float* d_t, const int64_t* ts, int64_t n_rays, int n_samples, int tau, float* g_emb, void* stream) {
+  SR_REQUIRE(d_t && ts && g_emb, "sr_embedding_bwd: null pointer");
+  if (n_rays <= 0) return 0;
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(256), 0, (hipStream_t)stream,
+                     d_t, (const long long*)ts, (long)n_rays, n_samples, tau, g_emb);
+  return check_launch("embedding_bwd_kernel");
 }

@@ -41,9 +41,13 @@ def _sine_init(seq, first_only=False):
 class _FlatParamModule(nn.Module):
     """Keeps every parameter a view of one flat buffer; survives ``.to()/.cuda()/.float()``."""
 
-    def _flatten(self):
+    def _flatten(self, buffer=None):
+        """Re-point every parameter into one flat fp32 buffer (``buffer`` = a caller-owned 1-D tensor to adopt, e.g. the
+        trainer's combined [model | embedding] buffer)."""
         params = list(self.parameters())
-        flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=params[0].device)
+        n = sum(p.numel() for p in params)
+        flat = torch.empty(n, dtype=torch.float32, device=params[0].device) if buffer is None else buffer
+        assert flat.numel() == n and flat.dtype == torch.float32
         off = 0
         for p in params:
             n = p.numel()
@@ -51,7 +55,9 @@ class _FlatParamModule(nn.Module):
             p.data = flat[off:off + n].view(p.shape)
             off += n
         self._flat = flat
+        self._flat_grad = None
         self._pack_cache = {}
+        self._bumps = 0
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -61,7 +67,30 @@ class _FlatParamModule(nn.Module):
     def weights_version(self):
         """Changes whenever the weights are modified in place, through a parameter view OR through the flat buffer
         (``p.data = view`` does not share version counters, so both are counted)."""
-        return self._flat._version + sum(p._version for p in self.parameters())
+        return self._bumps + self._flat._version + sum(p._version for p in self.parameters())
+
+    def mark_weights_changed(self):
+        """For updaters that write the flat buffer through an alias autograd cannot see (fused optimizers)."""
+        self._bumps += 1
+
+    def flat_grads(self, buffer=None):
+        """The flat gradient buffer; every ``p.grad`` is (re)bound as a view of it.  A parameter whose ``.grad`` was set
+        to None (``zero_grad(set_to_none=True)``) gets its slice zeroed, which is what a fresh gradient means."""
+        self.flat_params()
+        if buffer is not None or self._flat_grad is None or self._flat_grad.device != self._flat.device:
+            self._flat_grad = torch.zeros_like(self._flat) if buffer is None else buffer
+            for p in self.parameters():
+                p.grad = None
+        off = 0
+        base = self._flat_grad.data_ptr()
+        for p in self.parameters():
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != base + 4 * off:
+                view = self._flat_grad[off:off + n].view(p.shape)
+                view.zero_()
+                p.grad = view
+            off += n
+        return self._flat_grad
 
     def flat_params(self):
         params = list(self.parameters())
@@ -131,6 +160,22 @@ class SatNeRF(_FlatParamModule):
             ent = {k: torch.from_numpy(m[k]).to(dev) for k in ("idx", "scale", "l0_idx", "l0_scale")}
             self._pack_cache["maps"] = ent
         return ent
+
+    def packed_backward(self):
+        """Transposed (dX) weight stream for the current weights + the weight-gradient job table / scatter maps."""
+        flat = self.flat_params()
+        ent = self._pack_cache.get("bmaps")
+        if ent is None or ent["idx"].device != flat.device:
+            m = packing.backward_maps(self.feat, self.t_embedding_dims)
+            ent = {k: torch.from_numpy(m[k]).to(flat.device) for k in ("idx", "scale", "blocks", "gidx", "gscale")}
+            self._pack_cache["bmaps"] = ent
+        cached = self._pack_cache.get("bstream")
+        version = self.weights_version()
+        if cached is None or cached[0] != version or cached[1] != flat.data_ptr():
+            hi, _ = ops.pack_stream(flat, ent["idx"], ent["scale"], want_lo=False)
+            cached = (version, flat.data_ptr(), hi)
+            self._pack_cache["bstream"] = cached
+        return cached[2], ent
 
     # ---- SatNeRF.forward (models/satnerf.py:156-208): points in, (B,9) out ---------------------------------
     def forward(self, input_xyz, input_dir=None, input_sun_dir=None, input_t=None, sigma_only=False, mlp_mode=None):

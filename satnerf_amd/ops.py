@@ -163,3 +163,52 @@ def sample_pdf_merge(z_coarse, weights_coarse, u, eps=1e-5):
     z_fine = torch.empty(n, s + i, dtype=torch.float32, device=z_coarse.device)
     _lib.call("sr_sample_pdf_merge", _p(z_coarse), _p(weights_coarse), _p(u), n, s, i, float(eps), _p(z_fine), _stream())
     return z_fine
+
+
+# ------------------------------------------------------------------------------------------------ backward
+def acts_workspace(n_points, feat, device):
+    per_tile = _lib.lib().sr_act_elems_per_tile(feat)
+    return torch.empty(((n_points + 31) // 32) * per_tile, dtype=torch.int16, device=device)
+
+
+def satnerf_mlp_bwd(feat, tau, n_points, bwd_stream, acts, albedo, sigma, sun_v, beta, g_albedo, g_sigma, g_sun_v, g_beta, want_dt=True):
+    """dX chain: returns (dpre workspace, d_t (P,tau) or None)."""
+    dev = albedo.device
+    per_tile = _lib.lib().sr_dpre_elems_per_tile(feat)
+    dpre = torch.empty(((n_points + 31) // 32) * per_tile, dtype=torch.int16, device=dev)
+    d_t = torch.empty(n_points, tau, dtype=torch.float32, device=dev) if want_dt else None
+    opt = lambda t, nm: _p(_chk(t, nm, allow_none=True))  # noqa: E731
+    ev = kernel_timer.span("mlp_bwd") if kernel_timer is not None else None
+    if ev:
+        ev[0].record()
+    _lib.call("sr_satnerf_mlp_bwd", feat, tau, n_points, _p(bwd_stream), _p(acts), _p(_chk(albedo, "albedo")), _p(_chk(sigma, "sigma")),
+              _p(_chk(sun_v, "sun_v")), _p(_chk(beta, "beta")), opt(g_albedo, "g_albedo"), opt(g_sigma, "g_sigma"), opt(g_sun_v, "g_sun_v"),
+              opt(g_beta, "g_beta"), _p(dpre), _p(d_t), _stream())
+    if ev:
+        ev[1].record()
+    return dpre, d_t
+
+
+def satnerf_wgrad(feat, tau, n_points, dpre, acts, blocks, n_split, gidx, gscale, grad_flat, accumulate=True):
+    """Weight-gradient GEMMs + split-K reduction + scatter into the flat gradient buffer."""
+    n_blocks = blocks.shape[0]
+    partial = torch.empty(n_split * n_blocks * 128 * 128, dtype=torch.float32, device=dpre.device)
+    ev = kernel_timer.span("wgrad") if kernel_timer is not None else None
+    if ev:
+        ev[0].record()
+    _lib.call("sr_satnerf_wgrad", feat, tau, n_points, _p(dpre), _p(acts), _p(_chk(blocks, "blocks", torch.int32)), n_blocks, n_split, _p(partial),
+              _stream())
+    if ev:
+        ev[1].record()
+    _lib.call("sr_unpack_grads", _p(partial), _p(_chk(gidx, "gidx", torch.int32)), _p(_chk(gscale, "gscale")), gidx.numel(), n_split,
+              n_blocks * 128 * 128, _p(_chk(grad_flat, "grad_flat")), int(accumulate), _stream())
+
+
+def sky_bwd(sun, w1, b1, w2, sky_rgb, d_sky, g_w1, g_b1, g_w2, g_b2):
+    sun, stride = _rows(sun, "sun", 3)
+    _lib.call("sr_sky_bwd", _p(sun), stride, sun.shape[0], w1.shape[0], _p(w1), _p(b1), _p(w2), _p(_chk(sky_rgb, "sky")), _p(_chk(d_sky, "d_sky")),
+              _p(g_w1), _p(g_b1), _p(g_w2), _p(g_b2), _stream())
+
+
+def embedding_bwd(d_t, ts, n_rays, n_samples, tau, g_emb):
+    _lib.call("sr_embedding_bwd", _p(_chk(d_t, "d_t")), _p(_chk(ts, "ts", torch.int64)), n_rays, n_samples, tau, _p(_chk(g_emb, "g_emb")), _stream())

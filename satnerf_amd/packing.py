@@ -185,3 +185,155 @@ def forward_maps(feat=256, tau=4):
     l0_scale = np.full(l0_idx.shape, np.float32(W0_FIRST) * INV_2PI, np.float32)
     return dict(idx=idx, scale=scale, l0_idx=l0_idx.reshape(-1).astype(np.int32), l0_scale=l0_scale.reshape(-1),
                 n_params=n_params, auxs=auxs, offsets=offsets)
+
+
+# ------------------------------------------------------------------------------------------------ backward
+KIND_BF16, KIND_PHASE = 0, 1
+WG_BLOCK = 8  # the weight-gradient kernel computes (8 row fragments) x (8 column fragments) = 128 x 128 per workgroup
+
+
+def feat_to_slot(n):
+    """Inverse of slot_to_feat over n features (n a multiple of 32)."""
+    inv = np.empty(n, np.int64)
+    inv[slot_to_feat(np.arange(n))] = np.arange(n)
+    return inv
+
+
+class _Job:
+    """One weight-gradient GEMM  dW[row slot][col slot] = sum_points dpre[row] * act[col], tiled into 128x128 blocks."""
+
+    def __init__(self, blocks, row_frag0, n_row, segs):
+        self.row_frag0, self.n_row, self.segs = row_frag0, n_row, segs
+        self.base = {}
+        for rb in range((n_row + WG_BLOCK - 1) // WG_BLOCK):
+            for si, (cf0, ncol, kind) in enumerate(segs):
+                for cb in range((ncol + WG_BLOCK - 1) // WG_BLOCK):
+                    self.base[(rb, si, cb)] = len(blocks)
+                    blocks.append([row_frag0 + rb * WG_BLOCK, min(WG_BLOCK, n_row - rb * WG_BLOCK), cf0 + cb * WG_BLOCK,
+                                   min(WG_BLOCK, ncol - cb * WG_BLOCK), kind, 0, 0, 0])
+
+    def pos(self, row_slot, seg, col_slot):
+        row_slot, col_slot = np.asarray(row_slot), np.asarray(col_slot)
+        rb, cb = row_slot // 128, col_slot // 128
+        base = np.vectorize(lambda a, b: self.base[(int(a), seg, int(b))])(rb, cb) if row_slot.ndim or col_slot.ndim else \
+            self.base[(int(rb), seg, int(cb))]
+        return np.asarray(base) * (128 * 128) + (row_slot % 128) * 128 + (col_slot % 128)
+
+
+@functools.lru_cache(maxsize=8)
+def backward_maps(feat=256, tau=4):
+    """Gather maps of the transposed (dX) stream, the weight-gradient job table and the gradient scatter map.
+
+    Returns dict(idx, scale: bwd stream;  blocks int32 [n_blocks, 8] = (row_frag0, n_row, col_frag0, n_col, col_kind, 0,0,0);
+    gidx int32 [n_params] position of each parameter's gradient in the block-partial buffer (-1: not produced here),
+    gscale fp32 [n_params]).
+    """
+    if feat != 256:
+        raise ValueError(f"feat={feat} unsupported by this build (256)")
+    half, auxs = feat // 2, aux_steps(tau)
+    offsets, n_params = param_offsets(satnerf_param_shapes(feat, tau))
+
+    def transposed(n_in, parts, in_col0=0):
+        """rows = natural input index i < n_in; K slots = concatenated row-slot spaces of `parts` [(weight name, n_out_slots, row_of_slot)]."""
+        k = sum(p[1] for p in parts)
+        m = _Mat(n_in, k, 0, offsets)
+        s0 = 0
+        for name, nslots, rows in parts:
+            rows = np.asarray(rows)  # forward output row held by each slot, -1 = none
+            ok = rows >= 0
+            i = np.arange(n_in)[:, None]
+            m.idx[:, s0:s0 + nslots] = np.where(ok[None, :], m._flat(name, np.maximum(rows, 0)[None, :], in_col0 + i), -1)
+            m.scl[:, s0:s0 + nslots] = np.where(ok[None, :], 1.0, 0.0)
+            s0 += nslots
+        return m
+
+    phi128, phi256, phi16 = slot_to_feat(np.arange(128)), slot_to_feat(np.arange(256)), slot_to_feat(np.arange(16))
+    head_rows = lambda lo, hi: np.where((phi16 >= lo) & (phi16 < hi), phi16 - lo, -1)  # noqa: E731
+    mats = []
+    # bH: d_head (16 slots, rows 0..4 live) -> d rgb hidden | d sun hidden 3 | d beta hidden (12 tiles x 1 piece)
+    for name, lo, hi in (("rgb_from_xyzdir.2.weight", 0, 3), ("sun_v_net.6.weight", 3, 4), ("beta_from_xyz.2.weight", 4, 5)):
+        mats.append(transposed(half, [(name, 16, head_rows(lo, hi))]))
+    mats.append(transposed(half, [("sun_v_net.4.weight", 128, phi128)]))  # bS3
+    mats.append(transposed(half, [("sun_v_net.2.weight", 128, phi128)]))  # bS2
+    mats.append(transposed(feat, [("rgb_from_xyzdir.0.weight", 128, phi128), ("sun_v_net.0.weight", 128, phi128),
+                                  ("beta_from_xyz.0.weight", 128, phi128)]))  # bG2
+    dt = transposed(32, [("beta_from_xyz.0.weight", 128, phi128)], in_col0=feat)  # bDT: rows = t index
+    dt.idx[tau:, :] = -1
+    dt.scl[tau:, :] = 0.0
+    mats.append(dt)
+    sig_rows = np.where(phi16 == 0, 0, -1)
+    mats.append(transposed(feat, [("feats_from_xyz.weight", 256, phi256), ("sigma_from_xyz.0.weight", 16, sig_rows)]))  # bG1
+    for l in range(7, 0, -1):
+        mats.append(transposed(feat, [(f"fc_net.{2 * l}.weight", 256, phi256)], in_col0=3 if l == 4 else 0))
+    parts = [_serialize(m) for m in mats]
+    idx = np.concatenate([p[0] for p in parts]).astype(np.int32)
+    scale = np.concatenate([p[1] for p in parts]).astype(np.float32)
+
+    # ---- weight-gradient jobs: rows = fragments of the dpre workspace, cols = fragments of the saved activations
+    A = auxs  # activation fragment offsets (mlp_layout.h)
+    a_frag = lambda l: A + 16 * l  # noqa: E731
+    ACT_FEATS, ACT_RGBH, ACT_S1, ACT_E1, ACT_S2, ACT_S3 = A + 128, A + 144, A + 152, A + 160, A + 168, A + 176
+    DP_FEATS, DP_SIGMA, DP_RGBH, DP_S2, DP_S3, DP_HEAD = 128, 144, 145, 169, 177, 185
+    aux_seg = (0, auxs, KIND_BF16)
+    blocks = []
+    jobs = {"L0": _Job(blocks, 0, 16, [aux_seg])}
+    for l in range(1, 8):
+        jobs[f"L{l}"] = _Job(blocks, 16 * l, 16, [(a_frag(l - 1), 16, KIND_PHASE), aux_seg])
+    jobs["G1"] = _Job(blocks, DP_FEATS, 17, [(a_frag(7), 16, KIND_PHASE), aux_seg])
+    jobs["G2"] = _Job(blocks, DP_RGBH, 24, [(ACT_FEATS, 16, KIND_BF16), aux_seg])
+    jobs["S2"] = _Job(blocks, DP_S2, 8, [(ACT_S1, 8, KIND_PHASE), aux_seg])
+    jobs["S3"] = _Job(blocks, DP_S3, 8, [(ACT_S2, 8, KIND_PHASE), aux_seg])
+    jobs["H"] = _Job(blocks, DP_HEAD, 1, [(ACT_RGBH, 8, KIND_PHASE), (ACT_S3, 8, KIND_PHASE), (ACT_E1, 8, KIND_PHASE), aux_seg])
+
+    gidx = np.full(n_params, -1, np.int64)
+    gscale = np.zeros(n_params, np.float32)
+    inv256, inv128, inv16 = feat_to_slot(256), feat_to_slot(128), feat_to_slot(32)[:16]
+
+    def put(name, job, row_slots, seg, col_slots, scale_=1.0, cols=None):
+        """grad of W[name][r, cols[c]] (or bias[r] when 1-D) lives at job.pos(row_slots[r], seg, col_slots[c])."""
+        off, shp = offsets[name]
+        row_slots, col_slots = np.asarray(row_slots), np.asarray(col_slots)
+        if len(shp) == 1:
+            gidx[off + np.arange(shp[0])] = job.pos(row_slots, seg, np.full_like(row_slots, int(col_slots)))
+            gscale[off:off + shp[0]] = scale_
+            return
+        cols = np.arange(shp[1]) if cols is None else np.asarray(cols)
+        r = np.arange(shp[0])[:, None]
+        flat = off + r * shp[1] + cols[None, :]
+        gidx[flat] = job.pos(np.broadcast_to(row_slots[:, None], flat.shape), seg, np.broadcast_to(col_slots[None, :], flat.shape))
+        gscale[flat] = scale_
+
+    AUXC = _Mat
+    put("fc_net.0.weight", jobs["L0"], inv256, 0, AUXC.AUX_XYZ + np.arange(3), W0_FIRST)
+    put("fc_net.0.bias", jobs["L0"], inv256, 0, AUXC.AUX_ONE, W0_FIRST)
+    for l in range(1, 8):
+        name, job = f"fc_net.{2 * l}", jobs[f"L{l}"]
+        if l == 4:
+            put(name + ".weight", job, inv256, 1, AUXC.AUX_XYZ + np.arange(3), cols=[0, 1, 2])
+            put(name + ".weight", job, inv256, 0, inv256, cols=3 + np.arange(256))
+        else:
+            put(name + ".weight", job, inv256, 0, inv256)
+        put(name + ".bias", job, inv256, 1, AUXC.AUX_ONE)
+    put("feats_from_xyz.weight", jobs["G1"], inv256, 0, inv256)
+    put("feats_from_xyz.bias", jobs["G1"], inv256, 1, AUXC.AUX_ONE)
+    put("sigma_from_xyz.0.weight", jobs["G1"], np.array([256 + inv16[0]]), 0, inv256)
+    put("sigma_from_xyz.0.bias", jobs["G1"], np.array([256 + inv16[0]]), 1, AUXC.AUX_ONE)
+    for k, (name, aux0) in enumerate((("rgb_from_xyzdir.0", None), ("sun_v_net.0", AUXC.AUX_SUN), ("beta_from_xyz.0", AUXC.AUX_T))):
+        rows = 128 * k + inv128
+        put(name + ".weight", jobs["G2"], rows, 0, inv256, cols=np.arange(256))
+        put(name + ".bias", jobs["G2"], rows, 1, AUXC.AUX_ONE)
+        if aux0 is not None:
+            extra = offsets[name + ".weight"][1][1] - 256
+            put(name + ".weight", jobs["G2"], rows, 1, aux0 + np.arange(extra), cols=256 + np.arange(extra))
+    put("sun_v_net.2.weight", jobs["S2"], inv128, 0, inv128)
+    put("sun_v_net.2.bias", jobs["S2"], inv128, 1, AUXC.AUX_ONE)
+    put("sun_v_net.4.weight", jobs["S3"], inv128, 0, inv128)
+    put("sun_v_net.4.bias", jobs["S3"], inv128, 1, AUXC.AUX_ONE)
+    put("rgb_from_xyzdir.2.weight", jobs["H"], inv16[[0, 1, 2]], 0, inv128)
+    put("rgb_from_xyzdir.2.bias", jobs["H"], inv16[[0, 1, 2]], 3, AUXC.AUX_ONE)
+    put("sun_v_net.6.weight", jobs["H"], inv16[[3]], 1, inv128)
+    put("sun_v_net.6.bias", jobs["H"], inv16[[3]], 3, AUXC.AUX_ONE)
+    put("beta_from_xyz.2.weight", jobs["H"], inv16[[4]], 2, inv128)
+    put("beta_from_xyz.2.bias", jobs["H"], inv16[[4]], 3, AUXC.AUX_ONE)
+    return dict(idx=idx, scale=scale, blocks=np.asarray(blocks, np.int32), gidx=gidx.astype(np.int32), gscale=gscale,
+                n_params=n_params, auxs=auxs, offsets=offsets)
