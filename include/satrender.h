@@ -111,6 +111,17 @@ int sr_sky_bwd(const float* sun, int sun_stride, int64_t n, int hidden, const fl
                const float* sky, const float* d_sky, float* g_w1, float* g_b1, float* g_w2, float* g_b2, void* stream);
 int sr_embedding_bwd(const float* d_t, const int64_t* ts, int64_t n_rays, int n_samples, int tau, float* g_emb, void* stream);
 
+/* ---- training-step kernels --------------------------------------------------------------
+ * sr_satnerf_loss: metrics.SatNerfLoss for the coarse model (metrics.py:21-25,56-73): loss_out[0] = value, and
+ * grad_scale * dLoss/d{rgb (N,3), weights (N,S), beta (N,S)} in g_*.
+ * sr_adam_step: torch.optim.Adam update (main.py:84) over a flat buffer; step_count is a 1-float DEVICE counter the call
+ * increments (graph-replayable); grads are multiplied by grad_scale first and zeroed afterwards when zero_grad != 0. */
+int sr_satnerf_loss(const float* rgb, const float* weights, const float* beta, const float* target, int64_t n_rays,
+                    int n_samples, float beta_min, float grad_scale, float* loss_out, float* g_rgb, float* g_weights,
+                    float* g_beta, void* stream);
+int sr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float grad_scale, float* step_count, int zero_grad, void* stream);
+
 /* ---- sigma -> alpha compositing: models/satnerf.py:52-70 ------------------------------------------
  * noise may be NULL (== noise_std 0).  sky is per ray (N,3).  Outputs: weights, transparency (N,S),
  * depth (N), rgb (N,3) (clamped to [0,1] when clamp_rgb != 0; the classic nerf variant does not clamp,

@@ -376,14 +376,15 @@ __global__ void __launch_bounds__(256) gather_scale_kernel(const float* __restri
 }
 
 // ---- backward of the per-ray sky head (models/satnerf.py:138-143): parameter gradients only ----------------------------
-// Each block reduces 64 rays in registers (thread = hidden unit) and issues one atomicAdd per parameter.
+// Each block reduces kSkyRays rays in registers (thread = hidden unit) and issues one atomicAdd per parameter.
+constexpr int kSkyRays = 8;  // rays per block: 1024 rays -> 128 blocks
 __global__ void __launch_bounds__(256) sky_bwd_kernel(const float* __restrict__ sun, int sun_stride, long n, int hidden,
                                                      const float* __restrict__ w1, const float* __restrict__ b1,
                                                      const float* __restrict__ w2, const float* __restrict__ sky,
                                                      const float* __restrict__ d_sky, float* __restrict__ g_w1, float* __restrict__ g_b1,
                                                      float* __restrict__ g_w2, float* __restrict__ g_b2) {
-  const long r0 = (long)blockIdx.x * 64;
-  const long r1 = r0 + 64 < n ? r0 + 64 : n;
+  const long r0 = (long)blockIdx.x * kSkyRays;
+  const long r1 = r0 + kSkyRays < n ? r0 + kSkyRays : n;
   for (int k = threadIdx.x; k < hidden; k += 256) {
     const float wx = w1[k * 3], wy = w1[k * 3 + 1], wz = w1[k * 3 + 2], bb = b1[k];
     const float v0 = w2[k], v1 = w2[hidden + k], v2 = w2[2 * hidden + k];
@@ -420,11 +421,19 @@ __global__ void __launch_bounds__(256) embedding_bwd_kernel(const float* __restr
   const long r = (long)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
   if (r >= n_rays) return;
   const long row = ts[r];
-  for (int i = 0; i < tau; ++i) {
+  const float* src = d_t + r * (long)S * tau;  // the ray's S x tau block is contiguous
+  if (64 % tau == 0) {  // lane k always meets component k % tau: coalesced sweep, then reduce lanes of equal k % tau
     float a = 0.f;
-    for (int j = lane; j < S; j += 64) a += d_t[(r * S + j) * tau + i];
-    a = wave_sum(a);
-    if (lane == 0) atomicAdd(&g_emb[row * tau + i], a);
+    for (int k = lane; k < S * tau; k += 64) a += src[k];
+    for (int m = 32; m >= tau; m >>= 1) a += __shfl_xor(a, m, 64);
+    if (lane < tau) atomicAdd(&g_emb[row * tau + lane], a);
+  } else {
+    for (int i = 0; i < tau; ++i) {
+      float a = 0.f;
+      for (int j = lane; j < S; j += 64) a += src[j * tau + i];
+      a = wave_sum(a);
+      if (lane == 0) atomicAdd(&g_emb[row * tau + i], a);
+    }
   }
 }
 
@@ -519,7 +528,7 @@ extern "C" int sr_sky_bwd(const float* sun, int sun_stride, int64_t n, int hidde
                           const float* sky, const float* d_sky, float* g_w1, float* g_b1, float* g_w2, float* g_b2, void* stream) {
   SR_REQUIRE(sun && w1 && b1 && w2 && sky && d_sky && g_w1 && g_b1 && g_w2 && g_b2, "sr_sky_bwd: null pointer");
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(sky_bwd_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, sun, sun_stride, (long)n, hidden, w1,
+  hipLaunchKernelGGL(sky_bwd_kernel, dim3((unsigned)((n + kSkyRays - 1) / kSkyRays)), dim3(256), 0, (hipStream_t)stream, sun, sun_stride, (long)n, hidden, w1,
                      b1, w2, sky, d_sky, g_w1, g_b1, g_w2, g_b2);
   return check_launch("sky_bwd_kernel");
 }

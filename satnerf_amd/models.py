@@ -152,6 +152,31 @@ class SatNeRF(_FlatParamModule):
         self._pack_cache[key] = (version, flat.data_ptr(), (hi, lo, l0))
         return hi, lo, l0
 
+    def repack(self, mode, backward=False):
+        """Re-run the pack kernels unconditionally INTO THE SAME device buffers (hipGraph-capturable: fixed addresses,
+        no version checks on the captured path) and refresh the caches that ``packed`` / ``packed_backward`` consult."""
+        flat = self.flat_params()
+        key = (mode == "bf16x3")
+        maps = self._device_maps()
+        bufs = self._pack_cache.get(("buf", key))
+        if bufs is None or bufs[0].device != flat.device:
+            n = maps["idx"].numel()
+            bufs = (torch.empty(n, dtype=torch.int16, device=flat.device), torch.empty(n, dtype=torch.int16, device=flat.device) if key else None,
+                    torch.empty(maps["l0_idx"].numel(), dtype=torch.float32, device=flat.device))
+            self._pack_cache[("buf", key)] = bufs
+        ops.pack_stream_into(flat, maps["idx"], maps["scale"], bufs[0], bufs[1])
+        ops.gather_scale_into(flat, maps["l0_idx"], maps["l0_scale"], bufs[2])
+        version = self.weights_version()
+        self._pack_cache[key] = (version, flat.data_ptr(), bufs)
+        if backward:
+            _, ent = self.packed_backward() if "bmaps" not in self._pack_cache else (None, self._pack_cache["bmaps"])
+            bbuf = self._pack_cache.get("bbuf")
+            if bbuf is None or bbuf.device != flat.device:
+                bbuf = torch.empty(ent["idx"].numel(), dtype=torch.int16, device=flat.device)
+                self._pack_cache["bbuf"] = bbuf
+            ops.pack_stream_into(flat, ent["idx"], ent["scale"], bbuf, None)
+            self._pack_cache["bstream"] = (version, flat.data_ptr(), bbuf)
+
     def _device_maps(self):
         dev = self._flat.device
         ent = self._pack_cache.get("maps")

@@ -71,6 +71,16 @@ def pack_stream(flat, idx, scale, want_lo):
     return hi, lo
 
 
+def pack_stream_into(flat, idx, scale, hi, lo):
+    _lib.call("sr_pack_stream", _p(_chk(flat, "flat")), _p(_chk(idx, "idx", torch.int32)), _p(_chk(scale, "scale")), idx.numel(), _p(hi), _p(lo),
+              _stream())
+
+
+def gather_scale_into(flat, idx, scale, out):
+    _lib.call("sr_gather_scale_f32", _p(_chk(flat, "flat")), _p(_chk(idx, "idx", torch.int32)), _p(_chk(scale, "scale")), idx.numel(), _p(out),
+              _stream())
+
+
 def gather_scale(flat, idx, scale):
     out = torch.empty(idx.numel(), dtype=torch.float32, device=flat.device)
     _lib.call("sr_gather_scale_f32", _p(_chk(flat, "flat")), _p(_chk(idx, "idx", torch.int32)), _p(_chk(scale, "scale")), idx.numel(), _p(out),
@@ -212,3 +222,22 @@ def sky_bwd(sun, w1, b1, w2, sky_rgb, d_sky, g_w1, g_b1, g_w2, g_b2):
 
 def embedding_bwd(d_t, ts, n_rays, n_samples, tau, g_emb):
     _lib.call("sr_embedding_bwd", _p(_chk(d_t, "d_t")), _p(_chk(ts, "ts", torch.int64)), n_rays, n_samples, tau, _p(_chk(g_emb, "g_emb")), _stream())
+
+
+def satnerf_loss(rgb, weights, beta, target, beta_min=0.05, grad_scale=1.0):
+    """Fused SatNerfLoss forward + gradient: returns (loss (1,), g_rgb (N,3), g_weights (N,S), g_beta (N,S))."""
+    n, s = weights.shape
+    dev = rgb.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    g_rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    g_w = torch.empty(n, s, dtype=torch.float32, device=dev)
+    g_b = torch.empty(n, s, dtype=torch.float32, device=dev)
+    _lib.call("sr_satnerf_loss", _p(_chk(rgb, "rgb")), _p(_chk(weights, "weights")), _p(_chk(beta, "beta")), _p(_chk(target, "target")), n, s,
+              float(beta_min), float(grad_scale), _p(loss), _p(g_rgb), _p(g_w), _p(g_b), _stream())
+    return loss, g_rgb, g_w, g_b
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, step_count, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, zero_grad=True):
+    _lib.call("sr_adam_step", _p(_chk(params, "params")), _p(_chk(grads, "grads")), _p(_chk(exp_avg, "exp_avg")), _p(_chk(exp_avg_sq, "exp_avg_sq")),
+              params.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), float(grad_scale), _p(_chk(step_count, "step_count")),
+              int(zero_grad), _stream())

@@ -77,26 +77,108 @@ def shard_rays(n_total, rank, world_size):
 
 
 class Trainer:
-    def __init__(self, models, args, world_size=1, lr=5e-4, loss_fn=None):
-        self.models, self.args, self.world = models, args, world_size
+    """One training step = main.py:119-154 for the sat-nerf colour batch.
+
+    Fast path (default loss, no solar correction, no fine model): the step calls the HIP kernels directly -- no autograd
+    graph, fused loss+gradient kernel, fused Adam over the flat buffer -- and, when ``noise_std == 0``, replays the whole
+    forward+backward from ONE hipGraph (the step is ~25 launches of 5-350 us; eager launch gaps would dominate).
+    Anything else goes through ``render_rays`` + autograd + the same flat buffers.
+    """
+
+    def __init__(self, models, args, world_size=1, lr=5e-4, loss_fn=None, use_graph=True):
+        self.models, self.args, self.world, self.lr = models, args, world_size, lr
         mods = [models["coarse"]] + ([models["fine"]] if "fine" in models else []) + [models["t"]]
         self.state = FlatState(mods)
-        self._leaf = torch.nn.Parameter(self.state.params)  # shares storage with every module's parameters
-        self._leaf.grad = self.state.grads
-        fused = self.state.params.is_cuda
-        self.opt = torch.optim.Adam([self._leaf], lr=lr, fused=fused)  # main.py:84
-        self.loss_fn = loss_fn or (lambda res, tgt: satnerf_loss(res, tgt, getattr(args, "sc_lambda", 0.0)))
+        p = self.state.params
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(p), torch.zeros_like(p)
+        self.step_count = torch.zeros(1, dtype=torch.float32, device=p.device)
+        self.loss_fn = loss_fn
+        self.direct = (loss_fn is None and p.is_cuda and getattr(args, "sc_lambda", 0.0) == 0 and args.n_importance == 0
+                       and args.model == "sat-nerf")
+        self.use_graph = use_graph and self.direct
+        self._graph, self._static = None, None
         self.last_loss = None
 
-    def step(self, rays, ts, rgbs):
-        from .rendering import render_rays
+    # ---- forward + loss + backward on the current stream, gradients accumulate into the flat buffer -------------------
+    def _forward_backward(self, rays, ts, rgbs):
+        from . import ops
+        from .rendering import _mode_of
 
+        model, emb = self.models["coarse"], self.models["t"]
+        args = self.args
+        n, s = rays.shape[0], args.n_samples
+        mode = _mode_of(args)
+        feat, tau = model.feat, model.t_embedding_dims
+        model.repack(mode, backward=True)
+        hi, lo, l0 = model.packed(mode)
+        bstream, maps = model.packed_backward()
+        z = ops.ray_sample(rays, torch.rand(n, s, device=rays.device), s)  # rendering.py:77
+        noise = torch.randn(n, s, device=rays.device)                      # models/satnerf.py:58 (drawn even when unused)
+        noise_std = float(args.noise_std)
+        acts = ops.acts_workspace(n * s, feat, rays.device)
+        albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, 3:6], rays[:, 8:11], z, emb.weight.data, ts, n * s, s, feat, tau, mode,
+                                                     hi, lo, l0, acts=acts)
+        sk = model.sky_color
+        sky = ops.sky(rays[:, 8:11], sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data)
+        nz = noise if noise_std != 0 else None
+        weights, transp, depth, rgb = ops.composite(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky)
+        loss, g_rgb, g_w, g_beta = ops.satnerf_loss(rgb, weights, beta.view(n, s), rgbs)
+        d_sigma, d_albedo, d_sun, d_sky = ops.composite_bwd(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky, weights,
+                                                           transp, g_rgb, None, g_w, None)
+        dpre, d_t = ops.satnerf_mlp_bwd(feat, tau, n * s, bstream, acts, albedo, sigma, sun_v, beta, d_albedo, d_sigma, d_sun, g_beta.view(-1))
+        from .autograd import _N_SPLIT
+
+        ops.satnerf_wgrad(feat, tau, n * s, dpre, acts, maps["blocks"], _N_SPLIT, maps["gidx"], maps["gscale"], model.flat_grads(), accumulate=True)
+        ops.sky_bwd(rays[:, 8:11], sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sky, d_sky, sk[0].weight.grad, sk[0].bias.grad,
+                    sk[2].weight.grad, sk[2].bias.grad)
+        ops.embedding_bwd(d_t, ts, n, s, tau, emb.weight.grad)
+        return loss
+
+    def _capture(self, rays, ts, rgbs):
+        self._static = (rays.clone(), ts.clone(), rgbs.clone())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up on a side stream: lazy inits (LDS attributes, maps) happen outside capture
+            for _ in range(2):
+                self._forward_backward(*self._static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
         self.state.zero_grad()
-        res = render_rays(self.models, self.args, rays, ts)
-        loss = self.loss_fn(res, rgbs)
-        loss.backward()
-        self.state.allreduce_mean_(self.world)
-        self.opt.step()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_loss = self._forward_backward(*self._static)
+        self.state.zero_grad()  # capture does not execute
+
+    def step(self, rays, ts, rgbs):
+        from . import ops
+
+        if self.direct:
+            if self.use_graph and float(self.args.noise_std) == 0.0:
+                if self._graph is None or self._static[0].shape != rays.shape:
+                    self._capture(rays, ts, rgbs)
+                self._static[0].copy_(rays), self._static[1].copy_(ts), self._static[2].copy_(rgbs)
+                self._graph.replay()
+                loss = self._static_loss
+            else:
+                loss = self._forward_backward(rays.contiguous(), ts.contiguous(), rgbs.contiguous())
+            if self.world > 1:
+                dist.all_reduce(self.state.grads, op=dist.ReduceOp.SUM)
+            ops.adam_step(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.step_count, lr=self.lr,
+                          grad_scale=1.0 / self.world, zero_grad=True)
+        else:
+            from .rendering import render_rays
+
+            res = render_rays(self.models, self.args, rays, ts)
+            loss_fn = self.loss_fn or (lambda r, t: satnerf_loss(r, t, getattr(self.args, "sc_lambda", 0.0)))
+            loss = loss_fn(res, rgbs)
+            loss.backward()
+            if self.world > 1:
+                dist.all_reduce(self.state.grads, op=dist.ReduceOp.SUM)
+            if self.state.params.is_cuda:
+                ops.adam_step(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.step_count, lr=self.lr,
+                              grad_scale=1.0 / self.world, zero_grad=True)
+            else:
+                raise RuntimeError("training needs a GPU: satnerf_amd has no CPU path")
         for m in self.state.modules:
             if hasattr(m, "mark_weights_changed"):
                 m.mark_weights_changed()
