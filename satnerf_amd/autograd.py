@@ -16,7 +16,7 @@ import torch
 
 from . import ops
 
-_N_SPLIT = 8  # split-K slices of the weight-gradient GEMMs (70 blocks x 8 = 560 workgroups on 256 CUs)
+_N_SPLIT = 15  # split-K slices of the weight-gradient GEMMs (17 blocks x 15 = 255 sixteen-wave workgroups on 256 CUs)
 
 
 class _InferenceFn(torch.autograd.Function):

@@ -7,10 +7,12 @@
 // is done by the LDS: fragments are staged point-major and read back with ds_read_b64_tr_b16 (a 16-lane group reads a
 // 4-point x 16-slot block and each lane receives one slot's 4 points), two reads per 32x32x16 MFMA operand.
 //
-// Grid = (job blocks, split-K slices).  A workgroup (4 waves) owns one 128 x 128 block of one job (8 row fragments of
-// dpre x 8 column fragments of the saved activations, packing.backward_maps lists them) over a contiguous slice of
-// 32-point tiles; phase-coded activation fragments are decoded to bf16 sin() on the way into LDS.  fp32 partial blocks
-// go to `partial[slice][block][128][128]`; sr_unpack_grads sums the slices and scatters into the flat gradient.
+// Grid = (job blocks, split-K slices).  A workgroup (16 waves) owns one job block of up to 256 x 256 (16 row fragments of
+// dpre x 16 column fragments of the saved activations, packing.backward_maps lists them) PLUS the block's aux columns
+// (biases, skip / sun / embedding columns) over a contiguous slice of 32-point tiles, so every operand fragment is read
+// from HBM once per job.  Phase-coded activation fragments are decoded to bf16 sin() on the way into LDS.  fp32 partial
+// blocks go to `partial[slice][block][256*256 + 256*32]`; sr_unpack_grads sums the slices and scatters into the flat
+// gradient.
 #include "common.h"
 #include "mlp_layout.h"
 
@@ -19,12 +21,13 @@ namespace sr {
 struct WgradParams {
   const uint4* dpre;
   const uint4* acts;
-  const int* blocks;  // 8 ints per block: row_frag0, n_row, col_frag0, n_col, col_kind, -, -, -
+  const int* blocks;  // 8 ints per block: row_frag0, n_row (<=16), col_frag0, n_col (0..16), col_kind, -, -, -
   float* partial;
   long n_tiles;
   long tiles_per_split;
   long split_stride;  // floats between slices
   int ak;             // activation fragments per tile
+  int auxs;           // aux fragments (1 or 2) at the head of each activation tile
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -33,7 +36,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // lanes of a transposed read on 64 distinct banks (point*16 + half*8 covers 64 B, hslot adds 128 B, fragment parity 64 B).
 constexpr int kHslotStride = 640;
 constexpr int kFragStride = 1344;
-constexpr int kBufBytes = 16 * kFragStride;
+constexpr int kWgFrags = 34;  // 16 row + 16 column + 2 aux fragments
+constexpr int kBufBytes = kWgFrags * kFragStride;
+constexpr int kBlockFloats = 256 * 256 + 256 * 32;  // main block + aux columns
 
 __device__ __forceinline__ uint32_t phase_pair_to_bf16(uint32_t w) {
   const float a = __builtin_amdgcn_sinf((float)(w & 0xffffu) * (1.0f / 65535.0f));
@@ -41,8 +46,11 @@ __device__ __forceinline__ uint32_t phase_pair_to_bf16(uint32_t w) {
   return pack_bf16x2(a, b);
 }
 
-__global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams prm) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * kBufBytes];
+// Workgroup = 16 waves in a 4 x 4 grid; wave (wr, wc) owns rows 64*wr.. and columns 64*wc.. of the 256 x 256 block
+// (2 x 2 MFMA tiles) plus ONE aux MFMA per point tile: row tile (wc >> 1) of its rows against the aux fragment for k-step
+// (wc & 1); the two k-step halves are added through LDS once at the end.
+__global__ void __launch_bounds__(1024) wgrad_kernel(const WgradParams prm) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int* d = prm.blocks + blockIdx.x * 8;
@@ -51,33 +59,32 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams prm) {
   long t_end = t_begin + prm.tiles_per_split;
   if (t_end > prm.n_tiles) t_end = prm.n_tiles;
 
-  // staging: this thread moves 4 units per tile: fragments wave, wave+4 (rows) and wave+8, wave+12 (columns)
-  const int fr0 = rf0 + (wave < nr ? wave : nr - 1), fr1 = rf0 + (wave + 4 < nr ? wave + 4 : nr - 1);
-  const int fc0 = cf0 + (wave < nc ? wave : nc - 1), fc1 = cf0 + (wave + 4 < nc ? wave + 4 : nc - 1);
+  // staging: wave w moves row fragment w and column fragment w; waves 0,1 also move the aux fragments
+  const int fr = rf0 + (wave < nr ? wave : nr - 1);
+  const int fc = nc > 0 ? cf0 + (wave < nc ? wave : nc - 1) : 0;
+  const int fa = wave < prm.auxs ? wave : prm.auxs - 1;  // aux fragments are the first fragments of the activation tile
   const int unit_off = (lane >> 5) * kHslotStride + (lane & 31) * 16;
-  uint4 st[4];
+  uint4 st0, st1, st2;
   auto fetch = [&](long tile) {
     const uint4* dp = prm.dpre + tile * kDpFrags * 64 + lane;
     const uint4* ac = prm.acts + tile * prm.ak * 64 + lane;
-    st[0] = dp[fr0 * 64], st[1] = dp[fr1 * 64], st[2] = ac[fc0 * 64], st[3] = ac[fc1 * 64];
+    st0 = dp[fr * 64];
+    st1 = ac[fc * 64];
+    if (wave < 2) st2 = ac[fa * 64];
   };
   auto stash = [&](int buf) {
     char* base = lds + buf * kBufBytes + unit_off;
-    if (kind == 1) {  // phase-coded sin stage -> bf16 activation values
-#pragma unroll
-      for (int k = 2; k < 4; ++k)
-        st[k] = make_uint4(phase_pair_to_bf16(st[k].x), phase_pair_to_bf16(st[k].y), phase_pair_to_bf16(st[k].z), phase_pair_to_bf16(st[k].w));
-    }
-    *reinterpret_cast<uint4*>(base + (wave)*kFragStride) = st[0];
-    *reinterpret_cast<uint4*>(base + (wave + 4) * kFragStride) = st[1];
-    *reinterpret_cast<uint4*>(base + (wave + 8) * kFragStride) = st[2];
-    *reinterpret_cast<uint4*>(base + (wave + 12) * kFragStride) = st[3];
+    if (kind == 1)  // phase-coded sin stage -> bf16 activation values
+      st1 = make_uint4(phase_pair_to_bf16(st1.x), phase_pair_to_bf16(st1.y), phase_pair_to_bf16(st1.z), phase_pair_to_bf16(st1.w));
+    *reinterpret_cast<uint4*>(base + wave * kFragStride) = st0;
+    *reinterpret_cast<uint4*>(base + (16 + wave) * kFragStride) = st1;
+    if (wave < 2) *reinterpret_cast<uint4*>(base + (32 + wave) * kFragStride) = st2;
   };
 
   // transposed operand reads: lane = (hh, rh, m, q): MFMA row/col = 16*rh + 4*q + e, k = 8*hh + 4*rd + m
   const int hh = lane >> 5, rh = (lane >> 4) & 1, m = (lane >> 2) & 3, q = lane & 3;
   const int rd_off = rh * kFragStride + (q >> 1) * kHslotStride + (8 * hh + m) * 16 + (q & 1) * 8;
-  const int wr = wave >> 1, wc = wave & 1;  // this wave's 64 x 64 quadrant
+  const int wr = wave >> 2, wc = wave & 3;
   auto operand = [&](const char* buf, int frag_pair, int ks) {
     const char* p = buf + frag_pair * 2 * kFragStride + ks * 256 + rd_off;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
@@ -85,8 +92,13 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams prm) {
     const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
     return make_uint4(a.x, a.y, b.x, b.y);
   };
+  auto mma = [](const uint4& a, const uint4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  };
+  const bool main_on = nc > 0;
+  const int aux_rt = wc >> 1, aux_ks = wc & 1;
 
-  f32x16 acc[2][2] = {};
+  f32x16 acc[2][2] = {}, acc_aux = {};
   if (t_begin < t_end) fetch(t_begin);
   int buf = 0;
   for (long tile = t_begin; tile < t_end; ++tile) {
@@ -96,29 +108,53 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams prm) {
     const char* b = lds + buf * kBufBytes;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      uint4 a_op[2], b_op[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a_op[i] = operand(b, 2 * wr + i, ks), b_op[i] = operand(b, 4 + 2 * wc + i, ks);
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-          acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_op[rt]), __builtin_bit_cast(bf16x8, b_op[ct]),
-                                                                 acc[rt][ct], 0, 0, 0);
+      const uint4 a0 = operand(b, 2 * wr, ks), a1 = operand(b, 2 * wr + 1, ks);
+      if (main_on) {
+        const uint4 b0 = operand(b, 8 + 2 * wc, ks), b1 = operand(b, 8 + 2 * wc + 1, ks);
+        acc[0][0] = mma(a0, b0, acc[0][0]);
+        acc[0][1] = mma(a0, b1, acc[0][1]);
+        acc[1][0] = mma(a1, b0, acc[1][0]);
+        acc[1][1] = mma(a1, b1, acc[1][1]);
+      }
+      if (aux_ks == ks) {  // wave-uniform: this wave's one aux MFMA of the tile
+        const uint4 bx = operand(b, 16, ks);  // aux fragments 32, 33 = fragment pair 16
+        if (aux_rt) acc_aux = mma(a1, bx, acc_aux);
+        else acc_aux = mma(a0, bx, acc_aux);
+      }
     }
     buf ^= 1;
   }
-  float* out = prm.partial + (long)blockIdx.y * prm.split_stride + (long)blockIdx.x * (128 * 128);
+
+  float* out = prm.partial + (long)blockIdx.y * prm.split_stride + (long)blockIdx.x * kBlockFloats;
+  const int n_rows = 16 * nr, n_cols = 16 * nc;
+  if (main_on) {
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int row = 64 * wr + 32 * rt + (g & 3) + 8 * (g >> 2) + 4 * hh;
-        const int col = 64 * wc + 32 * ct + (lane & 31);
-        out[row * 128 + col] = acc[rt][ct][g];
-      }
+        for (int g = 0; g < 16; ++g) {
+          const int row = 64 * wr + 32 * rt + (g & 3) + 8 * (g >> 2) + 4 * hh;
+          const int col = 64 * wc + 32 * ct + (lane & 31);
+          if (row < n_rows && col < n_cols) out[row * 256 + col] = acc[rt][ct][g];
+        }
+  }
+  // aux columns: add the k-step-1 half to the k-step-0 half through LDS, then store rows [64 wr + 32 aux_rt ..) x 32 columns
+  __syncthreads();
+  float* scratch = reinterpret_cast<float*>(lds) + ((wr * 2 + aux_rt) * 64 + lane) * 16;
+  if (aux_ks == 1) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) scratch[g] = acc_aux[g];
+  }
+  __syncthreads();
+  if (aux_ks == 0) {
+    float* oa = out + 256 * 256;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int row = 64 * wr + 32 * aux_rt + (g & 3) + 8 * (g >> 2) + 4 * hh;
+      if (row < n_rows) oa[row * 32 + (lane & 31)] = acc_aux[g] + scratch[g];
+    }
+  }
 }
 
 // grad[e] (+)= gscale[e] * sum_s partial[s * split_stride + gidx[e]]
@@ -148,9 +184,19 @@ extern "C" int sr_satnerf_wgrad(int feat, int tau, int64_t n_points, const uint1
   p.dpre = (const uint4*)dpre, p.acts = (const uint4*)acts, p.blocks = blocks, p.partial = partial;
   p.n_tiles = (n_points + 31) / 32;
   p.tiles_per_split = (p.n_tiles + n_split - 1) / n_split;
-  p.split_stride = (long)n_blocks * 128 * 128;
-  p.ak = act_ksteps(aux_steps(tau));
-  hipLaunchKernelGGL(wgrad_kernel, dim3(n_blocks, n_split), dim3(256), 0, (hipStream_t)stream, p);
+  p.split_stride = (long)n_blocks * kBlockFloats;
+  p.auxs = aux_steps(tau);
+  p.ak = act_ksteps(p.auxs);
+  const size_t lds = 2 * (size_t)kBufBytes;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad_kernel, dim3(n_blocks, n_split), dim3(1024), lds, (hipStream_t)stream, p);
   return check_launch("wgrad_kernel");
 }
 

@@ -202,7 +202,8 @@ def satnerf_mlp_bwd(feat, tau, n_points, bwd_stream, acts, albedo, sigma, sun_v,
 def satnerf_wgrad(feat, tau, n_points, dpre, acts, blocks, n_split, gidx, gscale, grad_flat, accumulate=True):
     """Weight-gradient GEMMs + split-K reduction + scatter into the flat gradient buffer."""
     n_blocks = blocks.shape[0]
-    partial = torch.empty(n_split * n_blocks * 128 * 128, dtype=torch.float32, device=dpre.device)
+    block_floats = 256 * 256 + 256 * 32  # csrc/wgrad.hip kBlockFloats
+    partial = torch.empty(n_split * n_blocks * block_floats, dtype=torch.float32, device=dpre.device)
     ev = kernel_timer.span("wgrad") if kernel_timer is not None else None
     if ev:
         ev[0].record()
@@ -211,7 +212,7 @@ def satnerf_wgrad(feat, tau, n_points, dpre, acts, blocks, n_split, gidx, gscale
     if ev:
         ev[1].record()
     _lib.call("sr_unpack_grads", _p(partial), _p(_chk(gidx, "gidx", torch.int32)), _p(_chk(gscale, "gscale")), gidx.numel(), n_split,
-              n_blocks * 128 * 128, _p(_chk(grad_flat, "grad_flat")), int(accumulate), _stream())
+              n_blocks * block_floats, _p(_chk(grad_flat, "grad_flat")), int(accumulate), _stream())
 
 
 def sky_bwd(sun, w1, b1, w2, sky_rgb, d_sky, g_w1, g_b1, g_w2, g_b2):

@@ -189,7 +189,8 @@ def forward_maps(feat=256, tau=4):
 
 # ------------------------------------------------------------------------------------------------ backward
 KIND_BF16, KIND_PHASE = 0, 1
-WG_BLOCK = 8  # the weight-gradient kernel computes (8 row fragments) x (8 column fragments) = 128 x 128 per workgroup
+WG_ROWS = 16   # the weight-gradient kernel computes up to (16 row fragments) x (16 column fragments) = 256 x 256 per workgroup
+WG_BLOCK_FLOATS = 256 * 256 + 256 * 32  # ... plus its 32 aux columns
 
 
 def feat_to_slot(n):
@@ -200,31 +201,43 @@ def feat_to_slot(n):
 
 
 class _Job:
-    """One weight-gradient GEMM  dW[row slot][col slot] = sum_points dpre[row] * act[col], tiled into 128x128 blocks."""
+    """Weight-gradient GEMMs of one layer group: dW[row slot][col slot] = sum_points dpre[row] * act[col].
 
-    def __init__(self, blocks, row_frag0, n_row, segs):
-        self.row_frag0, self.n_row, self.segs = row_frag0, n_row, segs
-        self.base = {}
-        for rb in range((n_row + WG_BLOCK - 1) // WG_BLOCK):
-            for si, (cf0, ncol, kind) in enumerate(segs):
-                for cb in range((ncol + WG_BLOCK - 1) // WG_BLOCK):
-                    self.base[(rb, si, cb)] = len(blocks)
-                    blocks.append([row_frag0 + rb * WG_BLOCK, min(WG_BLOCK, n_row - rb * WG_BLOCK), cf0 + cb * WG_BLOCK,
-                                   min(WG_BLOCK, ncol - cb * WG_BLOCK), kind, 0, 0, 0])
+    ``row_groups`` = [(first dpre fragment, n fragments <= 16)], ``col_segs`` = [(first activation fragment, n <= 16, kind)];
+    one block per (row group, column segment); every block also produces its rows x aux-slot columns.  A job without
+    column segments (fc_net.0: inputs are the aux slots only) gets one aux-only block per row group."""
+
+    def __init__(self, blocks, row_groups, col_segs):
+        self.row_groups, self.col_segs = row_groups, col_segs
+        self.block = {}
+        for gi, (rf0, nr) in enumerate(row_groups):
+            for si, (cf0, nc, kind) in enumerate(col_segs or [(0, 0, KIND_BF16)]):
+                self.block[(gi, si)] = len(blocks)
+                blocks.append([rf0, nr, cf0, nc, kind, 0, 0, 0])
+
+    def _group_of(self, row_slot):
+        row_slot = np.asarray(row_slot)
+        starts = np.cumsum([0] + [16 * nr for _, nr in self.row_groups])
+        gi = np.searchsorted(starts, row_slot, side="right") - 1
+        return gi, row_slot - starts[gi]
 
     def pos(self, row_slot, seg, col_slot):
-        row_slot, col_slot = np.asarray(row_slot), np.asarray(col_slot)
-        rb, cb = row_slot // 128, col_slot // 128
-        base = np.vectorize(lambda a, b: self.base[(int(a), seg, int(b))])(rb, cb) if row_slot.ndim or col_slot.ndim else \
-            self.base[(int(rb), seg, int(cb))]
-        return np.asarray(base) * (128 * 128) + (row_slot % 128) * 128 + (col_slot % 128)
+        """position of dW[row_slot][col_slot of segment seg] in the partial buffer (row_slot counts across the job's row groups)."""
+        gi, local = self._group_of(row_slot)
+        base = np.vectorize(lambda g: self.block[(int(g), seg)])(gi)
+        return base * WG_BLOCK_FLOATS + local * 256 + np.asarray(col_slot)
+
+    def pos_aux(self, row_slot, aux_slot):
+        gi, local = self._group_of(row_slot)
+        base = np.vectorize(lambda g: self.block[(int(g), 0)])(gi)
+        return base * WG_BLOCK_FLOATS + 256 * 256 + local * 32 + np.asarray(aux_slot)
 
 
 @functools.lru_cache(maxsize=8)
 def backward_maps(feat=256, tau=4):
     """Gather maps of the transposed (dX) stream, the weight-gradient job table and the gradient scatter map.
 
-    Returns dict(idx, scale: bwd stream;  blocks int32 [n_blocks, 8] = (row_frag0, n_row, col_frag0, n_col, col_kind, 0,0,0);
+    Returns dict(idx, scale: bwd stream;  blocks int32 [n_blocks, 8] = (row_frag0, n_row<=16, col_frag0, n_col<=16, col_kind, 0,0,0);
     gidx int32 [n_params] position of each parameter's gradient in the block-partial buffer (-1: not produced here),
     gscale fp32 [n_params]).
     """
@@ -274,16 +287,15 @@ def backward_maps(feat=256, tau=4):
     a_frag = lambda l: A + 16 * l  # noqa: E731
     ACT_FEATS, ACT_RGBH, ACT_S1, ACT_E1, ACT_S2, ACT_S3 = A + 128, A + 144, A + 152, A + 160, A + 168, A + 176
     DP_FEATS, DP_SIGMA, DP_RGBH, DP_S2, DP_S3, DP_HEAD = 128, 144, 145, 169, 177, 185
-    aux_seg = (0, auxs, KIND_BF16)
     blocks = []
-    jobs = {"L0": _Job(blocks, 0, 16, [aux_seg])}
+    jobs = {"L0": _Job(blocks, [(0, 16)], [])}
     for l in range(1, 8):
-        jobs[f"L{l}"] = _Job(blocks, 16 * l, 16, [(a_frag(l - 1), 16, KIND_PHASE), aux_seg])
-    jobs["G1"] = _Job(blocks, DP_FEATS, 17, [(a_frag(7), 16, KIND_PHASE), aux_seg])
-    jobs["G2"] = _Job(blocks, DP_RGBH, 24, [(ACT_FEATS, 16, KIND_BF16), aux_seg])
-    jobs["S2"] = _Job(blocks, DP_S2, 8, [(ACT_S1, 8, KIND_PHASE), aux_seg])
-    jobs["S3"] = _Job(blocks, DP_S3, 8, [(ACT_S2, 8, KIND_PHASE), aux_seg])
-    jobs["H"] = _Job(blocks, DP_HEAD, 1, [(ACT_RGBH, 8, KIND_PHASE), (ACT_S3, 8, KIND_PHASE), (ACT_E1, 8, KIND_PHASE), aux_seg])
+        jobs[f"L{l}"] = _Job(blocks, [(16 * l, 16)], [(a_frag(l - 1), 16, KIND_PHASE)])
+    jobs["G1"] = _Job(blocks, [(DP_FEATS, 16), (DP_SIGMA, 1)], [(a_frag(7), 16, KIND_PHASE)])
+    jobs["G2"] = _Job(blocks, [(DP_RGBH, 16), (DP_RGBH + 16, 8)], [(ACT_FEATS, 16, KIND_BF16)])
+    jobs["S2"] = _Job(blocks, [(DP_S2, 8)], [(ACT_S1, 8, KIND_PHASE)])
+    jobs["S3"] = _Job(blocks, [(DP_S3, 8)], [(ACT_S2, 8, KIND_PHASE)])
+    jobs["H"] = _Job(blocks, [(DP_HEAD, 1)], [(ACT_RGBH, 8, KIND_PHASE), (ACT_S3, 8, KIND_PHASE), (ACT_E1, 8, KIND_PHASE)])
 
     gidx = np.full(n_params, -1, np.int64)
     gscale = np.zeros(n_params, np.float32)
@@ -293,47 +305,48 @@ def backward_maps(feat=256, tau=4):
         """grad of W[name][r, cols[c]] (or bias[r] when 1-D) lives at job.pos(row_slots[r], seg, col_slots[c])."""
         off, shp = offsets[name]
         row_slots, col_slots = np.asarray(row_slots), np.asarray(col_slots)
+        where = (lambda r, c: job.pos_aux(r, c)) if seg == "aux" else (lambda r, c: job.pos(r, seg, c))
         if len(shp) == 1:
-            gidx[off + np.arange(shp[0])] = job.pos(row_slots, seg, np.full_like(row_slots, int(col_slots)))
+            gidx[off + np.arange(shp[0])] = where(row_slots, np.full_like(row_slots, int(col_slots)))
             gscale[off:off + shp[0]] = scale_
             return
         cols = np.arange(shp[1]) if cols is None else np.asarray(cols)
         r = np.arange(shp[0])[:, None]
         flat = off + r * shp[1] + cols[None, :]
-        gidx[flat] = job.pos(np.broadcast_to(row_slots[:, None], flat.shape), seg, np.broadcast_to(col_slots[None, :], flat.shape))
+        gidx[flat] = where(np.broadcast_to(row_slots[:, None], flat.shape), np.broadcast_to(col_slots[None, :], flat.shape))
         gscale[flat] = scale_
 
     AUXC = _Mat
-    put("fc_net.0.weight", jobs["L0"], inv256, 0, AUXC.AUX_XYZ + np.arange(3), W0_FIRST)
-    put("fc_net.0.bias", jobs["L0"], inv256, 0, AUXC.AUX_ONE, W0_FIRST)
+    put("fc_net.0.weight", jobs["L0"], inv256, "aux", AUXC.AUX_XYZ + np.arange(3), W0_FIRST)
+    put("fc_net.0.bias", jobs["L0"], inv256, "aux", AUXC.AUX_ONE, W0_FIRST)
     for l in range(1, 8):
         name, job = f"fc_net.{2 * l}", jobs[f"L{l}"]
         if l == 4:
-            put(name + ".weight", job, inv256, 1, AUXC.AUX_XYZ + np.arange(3), cols=[0, 1, 2])
+            put(name + ".weight", job, inv256, "aux", AUXC.AUX_XYZ + np.arange(3), cols=[0, 1, 2])
             put(name + ".weight", job, inv256, 0, inv256, cols=3 + np.arange(256))
         else:
             put(name + ".weight", job, inv256, 0, inv256)
-        put(name + ".bias", job, inv256, 1, AUXC.AUX_ONE)
+        put(name + ".bias", job, inv256, "aux", AUXC.AUX_ONE)
     put("feats_from_xyz.weight", jobs["G1"], inv256, 0, inv256)
-    put("feats_from_xyz.bias", jobs["G1"], inv256, 1, AUXC.AUX_ONE)
+    put("feats_from_xyz.bias", jobs["G1"], inv256, "aux", AUXC.AUX_ONE)
     put("sigma_from_xyz.0.weight", jobs["G1"], np.array([256 + inv16[0]]), 0, inv256)
-    put("sigma_from_xyz.0.bias", jobs["G1"], np.array([256 + inv16[0]]), 1, AUXC.AUX_ONE)
+    put("sigma_from_xyz.0.bias", jobs["G1"], np.array([256 + inv16[0]]), "aux", AUXC.AUX_ONE)
     for k, (name, aux0) in enumerate((("rgb_from_xyzdir.0", None), ("sun_v_net.0", AUXC.AUX_SUN), ("beta_from_xyz.0", AUXC.AUX_T))):
         rows = 128 * k + inv128
         put(name + ".weight", jobs["G2"], rows, 0, inv256, cols=np.arange(256))
-        put(name + ".bias", jobs["G2"], rows, 1, AUXC.AUX_ONE)
+        put(name + ".bias", jobs["G2"], rows, "aux", AUXC.AUX_ONE)
         if aux0 is not None:
             extra = offsets[name + ".weight"][1][1] - 256
-            put(name + ".weight", jobs["G2"], rows, 1, aux0 + np.arange(extra), cols=256 + np.arange(extra))
+            put(name + ".weight", jobs["G2"], rows, "aux", aux0 + np.arange(extra), cols=256 + np.arange(extra))
     put("sun_v_net.2.weight", jobs["S2"], inv128, 0, inv128)
-    put("sun_v_net.2.bias", jobs["S2"], inv128, 1, AUXC.AUX_ONE)
+    put("sun_v_net.2.bias", jobs["S2"], inv128, "aux", AUXC.AUX_ONE)
     put("sun_v_net.4.weight", jobs["S3"], inv128, 0, inv128)
-    put("sun_v_net.4.bias", jobs["S3"], inv128, 1, AUXC.AUX_ONE)
+    put("sun_v_net.4.bias", jobs["S3"], inv128, "aux", AUXC.AUX_ONE)
     put("rgb_from_xyzdir.2.weight", jobs["H"], inv16[[0, 1, 2]], 0, inv128)
-    put("rgb_from_xyzdir.2.bias", jobs["H"], inv16[[0, 1, 2]], 3, AUXC.AUX_ONE)
+    put("rgb_from_xyzdir.2.bias", jobs["H"], inv16[[0, 1, 2]], "aux", AUXC.AUX_ONE)
     put("sun_v_net.6.weight", jobs["H"], inv16[[3]], 1, inv128)
-    put("sun_v_net.6.bias", jobs["H"], inv16[[3]], 3, AUXC.AUX_ONE)
+    put("sun_v_net.6.bias", jobs["H"], inv16[[3]], "aux", AUXC.AUX_ONE)
     put("beta_from_xyz.2.weight", jobs["H"], inv16[[4]], 2, inv128)
-    put("beta_from_xyz.2.bias", jobs["H"], inv16[[4]], 3, AUXC.AUX_ONE)
+    put("beta_from_xyz.2.bias", jobs["H"], inv16[[4]], "aux", AUXC.AUX_ONE)
     return dict(idx=idx, scale=scale, blocks=np.asarray(blocks, np.int32), gidx=gidx.astype(np.int32), gscale=gscale,
                 n_params=n_params, auxs=auxs, offsets=offsets)

@@ -166,11 +166,14 @@ class Emulator:
         acts = list(sv["aux"]) + [f for l in range(8) for f in sv["a"][l]] + sv["feats"] + sv["rgbh"] + sv["s1"] + sv["e1"] + sv["s2"] + sv["s3"]
         dpre = [f for l in range(8) for f in d_pre[l]] + d_feats + [dsig] + d_rgbh + d_s1 + d_e1 + d_s2 + d_s3 + [dhead]
         slotmat = lambda fr: np.concatenate([f.reshape(2, 32, 8).transpose(0, 2, 1).reshape(16, 32) for f in fr], 0)  # noqa: E731
-        partial = np.zeros((bm["blocks"].shape[0], 128, 128))
+        partial = np.zeros((bm["blocks"].shape[0], packing.WG_BLOCK_FLOATS))
+        aux_m = slotmat(acts[0:self.auxs])
         for b, (rf0, nr, cf0, nc, kind, *_) in enumerate(bm["blocks"]):
             r = slotmat(dpre[rf0:rf0 + nr])
-            c = slotmat(acts[cf0:cf0 + nc])
-            partial[b, :16 * nr, :16 * nc] = r @ c.T
+            main, aux = partial[b, :256 * 256].reshape(256, 256), partial[b, 256 * 256:].reshape(256, 32)
+            if nc > 0:
+                main[:16 * nr, :16 * nc] = r @ slotmat(acts[cf0:cf0 + nc]).T
+            aux[:16 * nr, :16 * self.auxs] = r @ aux_m.T
         pf = partial.reshape(-1)
         grad = np.where(bm["gidx"] >= 0, pf[np.maximum(bm["gidx"], 0)] * bm["gscale"], 0.0)
         # rows of the d-t tile: lane (p,h) reg g holds row ROW_OF
