@@ -46,6 +46,10 @@ int64_t sr_dpre_elems_per_tile(int feat);        /* bf16 elements of pre-activat
  * (out_lo may be NULL).  idx < 0 selects the constant 0. */
 int sr_pack_stream(const float* src, const int32_t* idx, const float* scale, int64_t n,
                    uint16_t* out_hi, uint16_t* out_lo, void* stream);
+/* the same plus an fp32 gather (sr_gather_scale_f32) in ONE launch: the forward stream, the backward stream (concatenated
+ * maps) and the fc_net.0 table are refreshed together after every optimizer step */
+int sr_pack_all(const float* src, const int32_t* idx, const float* scale, int64_t n, uint16_t* out_hi, uint16_t* out_lo,
+                const int32_t* f32_idx, const float* f32_scale, int64_t n_f32, float* out_f32, void* stream);
 
 /* out[i] = src[idx[i]] * scale[i] in fp32 (idx < 0 -> 0): builds the fc_net.0 table `l0` of sr_satnerf_mlp_fwd */
 int sr_gather_scale_f32(const float* src, const int32_t* idx, const float* scale, int64_t n, float* out, void* stream);
@@ -112,15 +116,15 @@ int sr_sky_bwd(const float* sun, int sun_stride, int64_t n, int hidden, const fl
 int sr_embedding_bwd(const float* d_t, const int64_t* ts, int64_t n_rays, int n_samples, int tau, float* g_emb, void* stream);
 
 /* ---- training-step kernels --------------------------------------------------------------
- * sr_satnerf_loss: metrics.SatNerfLoss for the coarse model (metrics.py:21-25,56-73): loss_out[0] = value, and
- * grad_scale * dLoss/d{rgb (N,3), weights (N,S), beta (N,S)} in g_*.
- * sr_adam_step: torch.optim.Adam update (main.py:84) over a flat buffer; step_count is a 1-float DEVICE counter the call
- * increments (graph-replayable); grads are multiplied by grad_scale first and zeroed afterwards when zero_grad != 0. */
+ * sr_satnerf_loss: metrics.SatNerfLoss for the coarse model (metrics.py:21-25,56-73): value = sum of
+ * loss_parts[0 .. ceil(N/4)), and grad_scale * dLoss/d{rgb (N,3), weights (N,S), beta (N,S)} in g_*.
+ * sr_adam_step: torch.optim.Adam update (main.py:84) over a flat buffer; `step` is the 1-based step count; grads are
+ * multiplied by grad_scale first and zeroed afterwards when zero_grad != 0. */
 int sr_satnerf_loss(const float* rgb, const float* weights, const float* beta, const float* target, int64_t n_rays,
-                    int n_samples, float beta_min, float grad_scale, float* loss_out, float* g_rgb, float* g_weights,
+                    int n_samples, float beta_min, float grad_scale, float* loss_parts, float* g_rgb, float* g_weights,
                     float* g_beta, void* stream);
 int sr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                 float beta2, float eps, float grad_scale, float* step_count, int zero_grad, void* stream);
+                 float beta2, float eps, float grad_scale, int64_t step, int zero_grad, void* stream);
 
 /* ---- sigma -> alpha compositing: models/satnerf.py:52-70 ------------------------------------------
  * noise may be NULL (== noise_std 0).  sky is per ray (N,3).  Outputs: weights, transparency (N,S),

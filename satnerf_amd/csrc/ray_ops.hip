@@ -366,6 +366,29 @@ __global__ void __launch_bounds__(256) pack_stream_kernel(const float* __restric
   if (lo) reinterpret_cast<uint32_t*>(lo)[i >> 1] = l;
 }
 
+__global__ void __launch_bounds__(256) pack_all_kernel(const float* __restrict__ src, const int* __restrict__ idx, const float* __restrict__ scale,
+                                                      long n, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, const int* __restrict__ fidx,
+                                                      const float* __restrict__ fscale, long nf, float* __restrict__ fout) {
+#pragma clang fp contract(off)
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long i = t * 2;
+  if (i < n) {
+    const int i0 = idx[i], i1 = idx[i + 1];
+    const float v0 = i0 >= 0 ? src[i0] * scale[i] : 0.f;
+    const float v1 = i1 >= 0 ? src[i1] * scale[i + 1] : 0.f;
+    uint32_t h, l;
+    split_bf16x2(v0, v1, h, l);
+    reinterpret_cast<uint32_t*>(hi)[t] = h;
+    if (lo) reinterpret_cast<uint32_t*>(lo)[t] = l;
+  } else {
+    const long k = t - n / 2;
+    if (k < nf) {
+      const int j = fidx[k];
+      fout[k] = j >= 0 ? src[j] * fscale[k] : 0.f;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) gather_scale_kernel(const float* __restrict__ src, const int* __restrict__ idx,
                                                           const float* __restrict__ scale, long n, float* __restrict__ out) {
 #pragma clang fp contract(off)
@@ -376,41 +399,61 @@ __global__ void __launch_bounds__(256) gather_scale_kernel(const float* __restri
 }
 
 // ---- backward of the per-ray sky head (models/satnerf.py:138-143): parameter gradients only ----------------------------
-// Each block reduces kSkyRays rays in registers (thread = hidden unit) and issues one atomicAdd per parameter.
-constexpr int kSkyRays = 8;  // rays per block: 1024 rays -> 128 blocks
+// Block = 32 rays; thread (k = hidden unit, half) reduces 16 rays in registers, the two halves meet in LDS, then one atomicAdd
+// per parameter per block (1024 rays -> 32 blocks x 899 atomics).
+constexpr int kSkyRays = 32;
 __global__ void __launch_bounds__(256) sky_bwd_kernel(const float* __restrict__ sun, int sun_stride, long n, int hidden,
                                                      const float* __restrict__ w1, const float* __restrict__ b1,
                                                      const float* __restrict__ w2, const float* __restrict__ sky,
                                                      const float* __restrict__ d_sky, float* __restrict__ g_w1, float* __restrict__ g_b1,
                                                      float* __restrict__ g_w2, float* __restrict__ g_b2) {
+  __shared__ float ray[kSkyRays][8];   // sun xyz, dz0..2 per ray
+  __shared__ float comb[128][7];
   const long r0 = (long)blockIdx.x * kSkyRays;
-  const long r1 = r0 + kSkyRays < n ? r0 + kSkyRays : n;
-  for (int k = threadIdx.x; k < hidden; k += 256) {
-    const float wx = w1[k * 3], wy = w1[k * 3 + 1], wz = w1[k * 3 + 2], bb = b1[k];
-    const float v0 = w2[k], v1 = w2[hidden + k], v2 = w2[2 * hidden + k];
-    float a_wx = 0.f, a_wy = 0.f, a_wz = 0.f, a_b = 0.f, a_v0 = 0.f, a_v1 = 0.f, a_v2 = 0.f;
-    for (long r = r0; r < r1; ++r) {
-      const float sx = sun[r * sun_stride], sy = sun[r * sun_stride + 1], sz = sun[r * sun_stride + 2];
-      const float hk = __builtin_fmaf(wz, sz, __builtin_fmaf(wy, sy, __builtin_fmaf(wx, sx, bb)));
-      const float s0 = sky[r * 3], s1 = sky[r * 3 + 1], s2 = sky[r * 3 + 2];
-      const float z0 = d_sky[r * 3] * s0 * (1.f - s0), z1 = d_sky[r * 3 + 1] * s1 * (1.f - s1), z2 = d_sky[r * 3 + 2] * s2 * (1.f - s2);
-      if (hk > 0.f) {
-        a_v0 += z0 * hk, a_v1 += z1 * hk, a_v2 += z2 * hk;
-        const float dh = z0 * v0 + z1 * v1 + z2 * v2;
-        a_b += dh, a_wx += dh * sx, a_wy += dh * sy, a_wz += dh * sz;
+  const int nr = (int)((r0 + kSkyRays < n ? r0 + kSkyRays : n) - r0);
+  if (threadIdx.x < nr) {
+    const long r = r0 + threadIdx.x;
+    const float s0 = sky[r * 3], s1 = sky[r * 3 + 1], s2 = sky[r * 3 + 2];
+    ray[threadIdx.x][0] = sun[r * sun_stride], ray[threadIdx.x][1] = sun[r * sun_stride + 1], ray[threadIdx.x][2] = sun[r * sun_stride + 2];
+    ray[threadIdx.x][3] = d_sky[r * 3] * s0 * (1.f - s0);
+    ray[threadIdx.x][4] = d_sky[r * 3 + 1] * s1 * (1.f - s1);
+    ray[threadIdx.x][5] = d_sky[r * 3 + 2] * s2 * (1.f - s2);
+  }
+  __syncthreads();
+  const int half = threadIdx.x >> 7, kk = threadIdx.x & 127;
+  for (int k0 = 0; k0 < hidden; k0 += 128) {
+    const int k = k0 + kk;
+    float a[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (k < hidden) {
+      const float wx = w1[k * 3], wy = w1[k * 3 + 1], wz = w1[k * 3 + 2], bb = b1[k];
+      const float v0 = w2[k], v1 = w2[hidden + k], v2 = w2[2 * hidden + k];
+      for (int i = half * (kSkyRays / 2); i < (half + 1) * (kSkyRays / 2) && i < nr; ++i) {
+        const float sx = ray[i][0], sy = ray[i][1], sz = ray[i][2], z0 = ray[i][3], z1 = ray[i][4], z2 = ray[i][5];
+        const float hk = __builtin_fmaf(wz, sz, __builtin_fmaf(wy, sy, __builtin_fmaf(wx, sx, bb)));
+        if (hk > 0.f) {
+          a[4] += z0 * hk, a[5] += z1 * hk, a[6] += z2 * hk;
+          const float dh = z0 * v0 + z1 * v1 + z2 * v2;
+          a[3] += dh, a[0] += dh * sx, a[1] += dh * sy, a[2] += dh * sz;
+        }
       }
     }
-    atomicAdd(&g_w1[k * 3], a_wx), atomicAdd(&g_w1[k * 3 + 1], a_wy), atomicAdd(&g_w1[k * 3 + 2], a_wz), atomicAdd(&g_b1[k], a_b);
-    atomicAdd(&g_w2[k], a_v0), atomicAdd(&g_w2[hidden + k], a_v1), atomicAdd(&g_w2[2 * hidden + k], a_v2);
+    if (half == 1) {
+#pragma unroll
+      for (int c = 0; c < 7; ++c) comb[kk][c] = a[c];
+    }
+    __syncthreads();
+    if (half == 0 && k < hidden) {
+#pragma unroll
+      for (int c = 0; c < 7; ++c) a[c] += comb[kk][c];
+      atomicAdd(&g_w1[k * 3], a[0]), atomicAdd(&g_w1[k * 3 + 1], a[1]), atomicAdd(&g_w1[k * 3 + 2], a[2]), atomicAdd(&g_b1[k], a[3]);
+      atomicAdd(&g_w2[k], a[4]), atomicAdd(&g_w2[hidden + k], a[5]), atomicAdd(&g_w2[2 * hidden + k], a[6]);
+    }
+    __syncthreads();
   }
   if (threadIdx.x < 3) {
-    const int c = threadIdx.x;
-    float a = 0.f;
-    for (long r = r0; r < r1; ++r) {
-      const float sc = sky[r * 3 + c];
-      a += d_sky[r * 3 + c] * sc * (1.f - sc);
-    }
-    atomicAdd(&g_b2[c], a);
+    float acc = 0.f;
+    for (int i = 0; i < nr; ++i) acc += ray[i][3 + threadIdx.x];
+    atomicAdd(&g_b2[threadIdx.x], acc);
   }
 }
 
@@ -515,6 +558,17 @@ extern "C" int sr_pack_stream(const float* src, const int32_t* idx, const float*
   hipLaunchKernelGGL(pack_stream_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, idx, scale,
                      (long)n, out_hi, out_lo);
   return check_launch("pack_stream_kernel");
+}
+
+extern "C" int sr_pack_all(const float* src, const int32_t* idx, const float* scale, int64_t n, uint16_t* out_hi, uint16_t* out_lo,
+                           const int32_t* f32_idx, const float* f32_scale, int64_t n_f32, float* out_f32, void* stream) {
+  SR_REQUIRE(src && idx && scale && out_hi && f32_idx && f32_scale && out_f32, "sr_pack_all: null pointer");
+  SR_REQUIRE(n % 2 == 0, "sr_pack_all: n must be even");
+  const long threads = n / 2 + n_f32;
+  if (threads <= 0) return 0;
+  hipLaunchKernelGGL(pack_all_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, idx, scale, (long)n, out_hi,
+                     out_lo, f32_idx, f32_scale, (long)n_f32, out_f32);
+  return check_launch("pack_all_kernel");
 }
 
 extern "C" int sr_gather_scale_f32(const float* src, const int32_t* idx, const float* scale, int64_t n, float* out, void* stream) {

@@ -153,29 +153,34 @@ class SatNeRF(_FlatParamModule):
         return hi, lo, l0
 
     def repack(self, mode, backward=False):
-        """Re-run the pack kernels unconditionally INTO THE SAME device buffers (hipGraph-capturable: fixed addresses,
-        no version checks on the captured path) and refresh the caches that ``packed`` / ``packed_backward`` consult."""
+        """Re-run the pack kernel unconditionally INTO THE SAME device buffers (hipGraph-capturable: fixed addresses, no
+        version checks on the captured path) and refresh the caches ``packed`` / ``packed_backward`` consult.  With
+        ``backward`` the forward stream, the transposed stream and the fc_net.0 table are produced by ONE launch."""
         flat = self.flat_params()
         key = (mode == "bf16x3")
         maps = self._device_maps()
-        bufs = self._pack_cache.get(("buf", key))
-        if bufs is None or bufs[0].device != flat.device:
-            n = maps["idx"].numel()
-            bufs = (torch.empty(n, dtype=torch.int16, device=flat.device), torch.empty(n, dtype=torch.int16, device=flat.device) if key else None,
-                    torch.empty(maps["l0_idx"].numel(), dtype=torch.float32, device=flat.device))
-            self._pack_cache[("buf", key)] = bufs
-        ops.pack_stream_into(flat, maps["idx"], maps["scale"], bufs[0], bufs[1])
-        ops.gather_scale_into(flat, maps["l0_idx"], maps["l0_scale"], bufs[2])
+        if backward and "bmaps" not in self._pack_cache:
+            self.packed_backward()
+        n_f = maps["idx"].numel()
+        n_b = self._pack_cache["bmaps"]["idx"].numel() if backward else 0
+        ck = ("buf", key, backward)
+        bufs = self._pack_cache.get(ck)
+        if bufs is None or bufs["hi"].device != flat.device:
+            dev = flat.device
+            bufs = {"hi": torch.empty(n_f + n_b, dtype=torch.int16, device=dev),
+                    "lo": torch.empty(n_f + n_b, dtype=torch.int16, device=dev) if key else None,
+                    "l0": torch.empty(maps["l0_idx"].numel(), dtype=torch.float32, device=dev)}
+            if backward:
+                bm = self._pack_cache["bmaps"]
+                bufs["idx"], bufs["scale"] = torch.cat([maps["idx"], bm["idx"]]), torch.cat([maps["scale"], bm["scale"]])
+            else:
+                bufs["idx"], bufs["scale"] = maps["idx"], maps["scale"]
+            self._pack_cache[ck] = bufs
+        ops.pack_all(flat, bufs["idx"], bufs["scale"], bufs["hi"], bufs["lo"], maps["l0_idx"], maps["l0_scale"], bufs["l0"])
         version = self.weights_version()
-        self._pack_cache[key] = (version, flat.data_ptr(), bufs)
+        self._pack_cache[key] = (version, flat.data_ptr(), (bufs["hi"][:n_f], bufs["lo"][:n_f] if key else None, bufs["l0"]))
         if backward:
-            _, ent = self.packed_backward() if "bmaps" not in self._pack_cache else (None, self._pack_cache["bmaps"])
-            bbuf = self._pack_cache.get("bbuf")
-            if bbuf is None or bbuf.device != flat.device:
-                bbuf = torch.empty(ent["idx"].numel(), dtype=torch.int16, device=flat.device)
-                self._pack_cache["bbuf"] = bbuf
-            ops.pack_stream_into(flat, ent["idx"], ent["scale"], bbuf, None)
-            self._pack_cache["bstream"] = (version, flat.data_ptr(), bbuf)
+            self._pack_cache["bstream"] = (version, flat.data_ptr(), bufs["hi"][n_f:])
 
     def _device_maps(self):
         dev = self._flat.device

@@ -226,10 +226,11 @@ def embedding_bwd(d_t, ts, n_rays, n_samples, tau, g_emb):
 
 
 def satnerf_loss(rgb, weights, beta, target, beta_min=0.05, grad_scale=1.0):
-    """Fused SatNerfLoss forward + gradient: returns (loss (1,), g_rgb (N,3), g_weights (N,S), g_beta (N,S))."""
+    """Fused SatNerfLoss forward + gradient: returns (loss partial sums (ceil(N/4),) -- the loss is their sum --, g_rgb (N,3),
+    g_weights (N,S), g_beta (N,S))."""
     n, s = weights.shape
     dev = rgb.device
-    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    loss = torch.empty((n + 3) // 4, dtype=torch.float32, device=dev)
     g_rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
     g_w = torch.empty(n, s, dtype=torch.float32, device=dev)
     g_b = torch.empty(n, s, dtype=torch.float32, device=dev)
@@ -238,7 +239,12 @@ def satnerf_loss(rgb, weights, beta, target, beta_min=0.05, grad_scale=1.0):
     return loss, g_rgb, g_w, g_b
 
 
-def adam_step(params, grads, exp_avg, exp_avg_sq, step_count, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, zero_grad=True):
+def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, zero_grad=True):
+    """``step`` is the 1-based step count (bias corrections are computed on the host in fp64)."""
     _lib.call("sr_adam_step", _p(_chk(params, "params")), _p(_chk(grads, "grads")), _p(_chk(exp_avg, "exp_avg")), _p(_chk(exp_avg_sq, "exp_avg_sq")),
-              params.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), float(grad_scale), _p(_chk(step_count, "step_count")),
-              int(zero_grad), _stream())
+              params.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), float(grad_scale), int(step), int(zero_grad), _stream())
+
+
+def pack_all(flat, idx, scale, hi, lo, f32_idx, f32_scale, f32_out):
+    _lib.call("sr_pack_all", _p(_chk(flat, "flat")), _p(_chk(idx, "idx", torch.int32)), _p(_chk(scale, "scale")), idx.numel(), _p(hi), _p(lo),
+              _p(_chk(f32_idx, "f32_idx", torch.int32)), _p(_chk(f32_scale, "f32_scale")), f32_idx.numel(), _p(f32_out), _stream())

@@ -76,6 +76,22 @@ def shard_rays(n_total, rank, world_size):
     return start, start + base + (1 if rank < rem else 0)
 
 
+class _LazyLoss:
+    """The fused loss kernel leaves per-block partial sums; the scalar is only reduced when somebody looks at it."""
+
+    def __init__(self, parts):
+        self.parts = parts
+
+    def item(self):
+        return float(self.parts.sum().item())
+
+    def detach(self):
+        return self.parts.sum()
+
+    def __float__(self):
+        return self.item()
+
+
 class Trainer:
     """One training step = main.py:119-154 for the sat-nerf colour batch.
 
@@ -91,7 +107,7 @@ class Trainer:
         self.state = FlatState(mods)
         p = self.state.params
         self.exp_avg, self.exp_avg_sq = torch.zeros_like(p), torch.zeros_like(p)
-        self.step_count = torch.zeros(1, dtype=torch.float32, device=p.device)
+        self.n_steps = 0
         self.loss_fn = loss_fn
         self.direct = (loss_fn is None and p.is_cuda and getattr(args, "sc_lambda", 0.0) == 0 and args.n_importance == 0
                        and args.model == "sat-nerf")
@@ -163,8 +179,10 @@ class Trainer:
                 loss = self._forward_backward(rays.contiguous(), ts.contiguous(), rgbs.contiguous())
             if self.world > 1:
                 dist.all_reduce(self.state.grads, op=dist.ReduceOp.SUM)
-            ops.adam_step(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.step_count, lr=self.lr,
+            self.n_steps += 1
+            ops.adam_step(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.n_steps, lr=self.lr,
                           grad_scale=1.0 / self.world, zero_grad=True)
+            loss = _LazyLoss(loss)
         else:
             from .rendering import render_rays
 
@@ -175,7 +193,8 @@ class Trainer:
             if self.world > 1:
                 dist.all_reduce(self.state.grads, op=dist.ReduceOp.SUM)
             if self.state.params.is_cuda:
-                ops.adam_step(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.step_count, lr=self.lr,
+                self.n_steps += 1
+                ops.adam_step(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.n_steps, lr=self.lr,
                               grad_scale=1.0 / self.world, zero_grad=True)
             else:
                 raise RuntimeError("training needs a GPU: satnerf_amd has no CPU path")
@@ -183,5 +202,5 @@ class Trainer:
             if hasattr(m, "mark_weights_changed"):
                 m.mark_weights_changed()
         self.args.noise_std *= 0.9  # main.py:132
-        self.last_loss = loss.detach()
+        self.last_loss = loss if isinstance(loss, _LazyLoss) else loss.detach()
         return self.last_loss
