@@ -73,11 +73,11 @@ __device__ __forceinline__ void bstage(const uint4 (&in)[KIN], uint4 (&out)[NOUT
     static_for<TPC>([&](auto tc) {
       constexpr int tt = decltype(tc)::value, t = c * TPC + tt, o = O0 + 2 * t;
       uint4 p0 = {}, p1 = {};
-      if constexpr (COS) p0 = phase[(2 * t) * 64], p1 = phase[(2 * t + 1) * 64];
+      if constexpr (COS) p0 = ws_load(phase + (2 * t) * 64), p1 = ws_load(phase + (2 * t + 1) * 64);
       const f32x16 acc = btile<KIN>(slot, tt * KIN, in, lane);
       bpack<COS>(acc, p0, p1, out[o], out[o + 1]);
-      dst[(2 * t) * 64] = out[o];
-      dst[(2 * t + 1) * 64] = out[o + 1];
+      ws_store(dst + (2 * t) * 64, out[o]);
+      ws_store(dst + (2 * t + 1) * 64, out[o + 1]);
     });
   });
 }
@@ -141,15 +141,15 @@ __global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
       constexpr int T = decltype(tc)::value, part = T / kMTH, t = T % kMTH;
       constexpr int act0 = part == 0 ? kActRgbh : (part == 1 ? kActS3 : kActE1);
       constexpr int dp0 = part == 0 ? kDpRgbh : (part == 1 ? kDpS3 : kDpE1);
-      const uint4 p0 = acts[(A + act0 + 2 * t) * 64], p1 = acts[(A + act0 + 2 * t + 1) * 64];
+      const uint4 p0 = ws_load(acts + (A + act0 + 2 * t) * 64), p1 = ws_load(acts + (A + act0 + 2 * t + 1) * 64);
       const f32x16 acc = btile<1>(slot, T, dhead, lane);
       uint4 o0, o1;
       bpack<true>(acc, p0, p1, o0, o1);
       if constexpr (part == 0) d_rgbh[2 * t] = o0, d_rgbh[2 * t + 1] = o1;
       else if constexpr (part == 1) d_s3[2 * t] = o0, d_s3[2 * t + 1] = o1;
       else d_e1[2 * t] = o0, d_e1[2 * t + 1] = o1;
-      dpre[(dp0 + 2 * t) * 64] = o0;
-      dpre[(dp0 + 2 * t + 1) * 64] = o1;
+      ws_store(dpre + (dp0 + 2 * t) * 64, o0);
+      ws_store(dpre + (dp0 + 2 * t + 1) * 64, o1);
     });
   }
   // ---- sun chain: bS3 (d s3 -> d s2), bS2 (d s2 -> d s1) -------------------------------------------------------------
@@ -194,11 +194,11 @@ __global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
       constexpr int t = decltype(tc)::value;
       wait_then_barrier<(kD - 1) * min_loads<1>(kKS)>();
       issue_chunk<1, kKS>(stream, nullptr, (offL + (cbase + t + kD) * kKS) * 1024L, ring + ((BS::G_L + t + kD) % kNSLOT) * kBSlot, wave, lane);
-      const uint4 p0 = ph[(2 * t) * 64], p1 = ph[(2 * t + 1) * 64];
+      const uint4 p0 = ws_load(ph + (2 * t) * 64), p1 = ws_load(ph + (2 * t + 1) * 64);
       const f32x16 acc = btile<kKS>(ring + ((BS::G_L + t) % kNSLOT) * kBSlot, 0, cur, lane);
       bpack<true>(acc, p0, p1, nxt[2 * t], nxt[2 * t + 1]);
-      dst[(2 * t) * 64] = nxt[2 * t];
-      dst[(2 * t + 1) * 64] = nxt[2 * t + 1];
+      ws_store(dst + (2 * t) * 64, nxt[2 * t]);
+      ws_store(dst + (2 * t + 1) * 64, nxt[2 * t + 1]);
     });
 #pragma unroll
     for (int i = 0; i < kKS; ++i) cur[i] = nxt[i];

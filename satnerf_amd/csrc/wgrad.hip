@@ -68,9 +68,9 @@ __global__ void __launch_bounds__(1024) wgrad_kernel(const WgradParams prm) {
   auto fetch = [&](long tile) {
     const uint4* dp = prm.dpre + tile * kDpFrags * 64 + lane;
     const uint4* ac = prm.acts + tile * prm.ak * 64 + lane;
-    st0 = dp[fr * 64];
-    st1 = ac[fc * 64];
-    if (wave < 2) st2 = ac[fa * 64];
+    st0 = ws_load_cached(dp + fr * 64);
+    st1 = ws_load_cached(ac + fc * 64);
+    if (wave < 2) st2 = ws_load_cached(ac + fa * 64);
   };
   auto stash = [&](int buf) {
     char* base = lds + buf * kBufBytes + unit_off;
