@@ -147,6 +147,9 @@ int sr_composite_bwd(const float* z_vals, const float* sigma, const float* noise
  * z_coarse (N,S) sorted, weights_coarse (N,S), u (N,I) -> z_fine (N,S+I) = sort(cat(z_coarse, z_new)). */
 int sr_sample_pdf_merge(const float* z_coarse, const float* weights_coarse, const float* u, int64_t n_rays,
                         int n_samples, int n_importance, float eps, float* z_fine, void* stream);
+/* stand-alone rendering.sample_pdf (rendering.py:10-49): bins (N,nb), weights (N,nb-1), u (N,I) -> samples (N,I) */
+int sr_sample_pdf(const float* bins, const float* weights, const float* u, int64_t n_rays, int n_bins, int n_importance,
+                  float eps, float* samples, void* stream);
 
 #ifdef __cplusplus
 }

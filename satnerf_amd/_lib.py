@@ -47,6 +47,7 @@ SIGNATURES = {
     "sr_composite_bwd": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp, _vp]),
     "sr_sample_pdf_merge": (_i, [_vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp]),
+    "sr_sample_pdf": (_i, [_vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp]),
 }
 
 _lib = None

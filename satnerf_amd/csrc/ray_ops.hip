@@ -276,6 +276,41 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(
 // ---- importance resampling + merge: rendering.py:10-49,121-125 ----------------------------------------------
 constexpr int kMaxMerge = 1024;  // S + I rounded up to a power of two must fit
 
+// cdf[0] = 0, cdf[k] = sum_{j<k} (w_j + eps) / total for nw weights (rendering.py:22-27); one wave, cdf in LDS
+__device__ __forceinline__ void build_cdf(const float* w, int nw, float eps, float* cdf, int lane) {
+  float tot = 0.f;
+  for (int j = lane; j < nw; j += 64) tot += w[j] + eps;
+  tot = wave_sum(tot);
+  float carry = 0.f;
+  for (int j0 = 0; j0 < nw; j0 += 64) {
+    const int j = j0 + lane;
+    const float p = j < nw ? (w[j] + eps) / tot : 0.f;
+    const float incl = wave_scan_add(p, lane);
+    if (j < nw) cdf[j + 1] = carry + incl;
+    carry += __shfl(incl, 63, 64);
+  }
+  if (lane == 0) cdf[0] = 0.f;
+}
+
+// inverse-cdf sample (rendering.py:36-48): searchsorted(right=True), clamped neighbours, denom < eps -> 1
+__device__ __forceinline__ float invert_cdf(const float* cdf, const float* bins, int nw, float ui, float eps) {
+#pragma clang fp contract(off)
+  int lo = 0, hi = nw + 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (cdf[mid] <= ui) lo = mid + 1;
+    else hi = mid;
+  }
+  const int below = lo - 1 > 0 ? lo - 1 : 0;
+  const int above = lo < nw ? lo : nw;
+  const float cb = cdf[below], ca = cdf[above], bb = bins[below], ba = bins[above];
+  float denom = ca - cb;
+  if (denom < eps) denom = 1.f;
+  const float t = (ui - cb) / denom;
+  const float step = t * (ba - bb);
+  return bb + step;
+}
+
 __global__ void __launch_bounds__(256) sample_pdf_merge_kernel(const float* __restrict__ zc, const float* __restrict__ wc,
                                                               const float* __restrict__ u, long n_rays, int S, int I, float eps,
                                                               int npow2, float* __restrict__ z_fine) {
@@ -283,54 +318,19 @@ __global__ void __launch_bounds__(256) sample_pdf_merge_kernel(const float* __re
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long r = (long)blockIdx.x * kRaysPerBlock + wv;
   if (r >= n_rays) return;
-  const int nb = S - 1;  // bins = cdf entries
+  const int nb = S - 1, nw = S - 2;  // bins = interval mid points, weights = w[1:-1]
   float* cdf = reinterpret_cast<float*>(smem) + (size_t)wv * (2 * (size_t)S + npow2);
   float* bins = cdf + S;
   float* buf = bins + S;
   const float* zr = zc + r * S;
-  const float* wr = wc + r * S;
-  // bins = interval mid points; pdf weights = w[1:-1] + eps
   for (int j = lane; j < nb; j += 64) bins[j] = 0.5f * (zr[j] + zr[j + 1]);
-  const int nw = S - 2;
-  float tot = 0.f;
-  for (int j = lane; j < nw; j += 64) tot += wr[j + 1] + eps;
-  tot = wave_sum(tot);
-  // cdf[0] = 0, cdf[k] = sum_{j<k} pdf_j : segmented wave scan
-  float carry = 0.f;
-  for (int j0 = 0; j0 < nw; j0 += 64) {
-    const int j = j0 + lane;
-    const float p = j < nw ? (wr[j + 1] + eps) / tot : 0.f;
-    const float incl = wave_scan_add(p, lane);
-    if (j < nw) cdf[j + 1] = carry + incl;
-    carry += __shfl(incl, 63, 64);
-  }
-  if (lane == 0) cdf[0] = 0.f;
+  build_cdf(wc + r * S + 1, nw, eps, cdf, lane);
   // merge buffer: coarse depths, then the new samples, padded with +inf
   for (int j = lane; j < S; j += 64) buf[j] = zr[j];
   for (int j = S + I + lane; j < npow2; j += 64) buf[j] = __builtin_inff();
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  for (int i = lane; i < I; i += 64) {
-    const float ui = u[r * I + i];
-    // searchsorted(cdf, u, right=True): number of entries <= u
-    int lo = 0, hi = nb;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (cdf[mid] <= ui) lo = mid + 1;
-      else hi = mid;
-    }
-    const int below = lo - 1 > 0 ? lo - 1 : 0;
-    const int above = lo < nw ? lo : nw;
-    const float cb = cdf[below], ca = cdf[above], bb = bins[below], ba = bins[above];
-    float denom = ca - cb;
-    if (denom < eps) denom = 1.f;
-    {
-#pragma clang fp contract(off)
-      const float t = (ui - cb) / denom;
-      const float step = t * (ba - bb);
-      buf[S + i] = bb + step;
-    }
-  }
+  for (int i = lane; i < I; i += 64) buf[S + i] = invert_cdf(cdf, bins, nw, u[r * I + i], eps);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   // bitonic sort of npow2 values by one wave
@@ -348,6 +348,23 @@ __global__ void __launch_bounds__(256) sample_pdf_merge_kernel(const float* __re
     }
   }
   for (int j = lane; j < S + I; j += 64) z_fine[r * (S + I) + j] = buf[j];
+}
+
+// stand-alone rendering.sample_pdf(bins (N,nb), weights (N,nb-1), u (N,I)) -> samples (N,I), no merge
+__global__ void __launch_bounds__(256) sample_pdf_kernel(const float* __restrict__ bins_g, const float* __restrict__ w, const float* __restrict__ u,
+                                                        long n_rays, int nb, int I, float eps, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long r = (long)blockIdx.x * kRaysPerBlock + wv;
+  if (r >= n_rays) return;
+  const int nw = nb - 1;
+  float* cdf = reinterpret_cast<float*>(smem) + (size_t)wv * 2 * nb;
+  float* bins = cdf + nb;
+  for (int j = lane; j < nb; j += 64) bins[j] = bins_g[r * nb + j];
+  build_cdf(w + r * nw, nw, eps, cdf, lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < I; i += 64) out[r * I + i] = invert_cdf(cdf, bins, nw, u[r * I + i], eps);
 }
 
 // ---- weight stream pack / gradient unpack ---------------------------------------------------------------------
@@ -548,6 +565,18 @@ extern "C" int sr_sample_pdf_merge(const float* z_coarse, const float* weights_c
   hipLaunchKernelGGL(sample_pdf_merge_kernel, dim3((unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(256), lds,
                      (hipStream_t)stream, z_coarse, weights_coarse, u, (long)n_rays, n_samples, n_importance, eps, npow2, z_fine);
   return check_launch("sample_pdf_merge_kernel");
+}
+
+extern "C" int sr_sample_pdf(const float* bins, const float* weights, const float* u, int64_t n_rays, int n_bins, int n_importance, float eps,
+                             float* samples, void* stream) {
+  SR_REQUIRE(bins && weights && u && samples, "sr_sample_pdf: null pointer");
+  SR_REQUIRE(n_bins >= 2 && n_importance >= 1, "sr_sample_pdf: need n_bins>=2, n_importance>=1");
+  if (n_rays <= 0) return 0;
+  const size_t lds = (size_t)kRaysPerBlock * 2 * n_bins * sizeof(float);
+  SR_REQUIRE(lds <= 64 * 1024, "sr_sample_pdf: n_bins=%d too large", n_bins);
+  hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(256), lds, (hipStream_t)stream, bins,
+                     weights, u, (long)n_rays, n_bins, n_importance, eps, samples);
+  return check_launch("sample_pdf_kernel");
 }
 
 extern "C" int sr_pack_stream(const float* src, const int32_t* idx, const float* scale, int64_t n, uint16_t* out_hi, uint16_t* out_lo,

@@ -7,7 +7,7 @@
 // is done by the LDS: fragments are staged point-major and read back with ds_read_b64_tr_b16 (a 16-lane group reads a
 // 4-point x 16-slot block and each lane receives one slot's 4 points), two reads per 32x32x16 MFMA operand.
 //
-// Grid = (job blocks, split-K slices).  A workgroup (16 waves) owns one job block of up to 256 x 256 (16 row fragments of
+// Grid = (job blocks, split-K slices).  A workgroup (8 waves) owns one job block of up to 256 x 256 (16 row fragments of
 // dpre x 16 column fragments of the saved activations, packing.backward_maps lists them) PLUS the block's aux columns
 // (biases, skip / sun / embedding columns) over a contiguous slice of 32-point tiles, so every operand fragment is read
 // from HBM once per job.  Phase-coded activation fragments are decoded to bf16 sin() on the way into LDS.  fp32 partial
@@ -46,10 +46,15 @@ __device__ __forceinline__ uint32_t phase_pair_to_bf16(uint32_t w) {
   return pack_bf16x2(a, b);
 }
 
-// Workgroup = 16 waves in a 4 x 4 grid; wave (wr, wc) owns rows 64*wr.. and columns 64*wc.. of the 256 x 256 block
-// (2 x 2 MFMA tiles) plus ONE aux MFMA per point tile: row tile (wc >> 1) of its rows against the aux fragment for k-step
-// (wc & 1); the two k-step halves are added through LDS once at the end.
-__global__ void __launch_bounds__(1024) wgrad_kernel(const WgradParams prm) {
+// Workgroup = 8 waves in a 4 x 2 grid; wave (wr, wc) owns rows 64*wr.. and columns 128*wc.. of the 256 x 256 block
+// (2 x 4 MFMA tiles, 128 accumulator registers) plus the aux columns of row tile 2*wr + wc.  Ablation on MI355X
+// (profiles/r01_ab_variants.txt): the kernel is bound by LDS traffic and the per-tile rendezvous, not by MFMA or HBM, hence few
+// fat waves (1.4 transposed reads per MFMA instead of 2.2) and global loads issued two point tiles ahead.
+struct Stage {
+  uint4 r0, r1, c0, c1, ax;
+};
+
+__global__ void __launch_bounds__(512) wgrad_kernel(const WgradParams prm) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -59,32 +64,37 @@ __global__ void __launch_bounds__(1024) wgrad_kernel(const WgradParams prm) {
   long t_end = t_begin + prm.tiles_per_split;
   if (t_end > prm.n_tiles) t_end = prm.n_tiles;
 
-  // staging: wave w moves row fragment w and column fragment w; waves 0,1 also move the aux fragments
-  const int fr = rf0 + (wave < nr ? wave : nr - 1);
-  const int fc = nc > 0 ? cf0 + (wave < nc ? wave : nc - 1) : 0;
+  // staging: wave w moves row fragments w, w+8 and column fragments w, w+8; waves 0,1 also move the aux fragments
+  const int fr0 = rf0 + (wave < nr ? wave : nr - 1), fr1 = rf0 + (wave + 8 < nr ? wave + 8 : nr - 1);
+  const int fc0 = nc > 0 ? cf0 + (wave < nc ? wave : nc - 1) : 0, fc1 = nc > 0 ? cf0 + (wave + 8 < nc ? wave + 8 : nc - 1) : 0;
   const int fa = wave < prm.auxs ? wave : prm.auxs - 1;  // aux fragments are the first fragments of the activation tile
   const int unit_off = (lane >> 5) * kHslotStride + (lane & 31) * 16;
-  uint4 st0, st1, st2;
-  auto fetch = [&](long tile) {
+  auto fetch = [&](long tile, Stage& st) {
     const uint4* dp = prm.dpre + tile * kDpFrags * 64 + lane;
     const uint4* ac = prm.acts + tile * prm.ak * 64 + lane;
-    st0 = ws_load_cached(dp + fr * 64);
-    st1 = ws_load_cached(ac + fc * 64);
-    if (wave < 2) st2 = ws_load_cached(ac + fa * 64);
+    st.r0 = ws_load_cached(dp + fr0 * 64), st.r1 = ws_load_cached(dp + fr1 * 64);
+    st.c0 = ws_load_cached(ac + fc0 * 64), st.c1 = ws_load_cached(ac + fc1 * 64);
+    if (wave < 2) st.ax = ws_load_cached(ac + fa * 64);
   };
-  auto stash = [&](int buf) {
+  auto decode = [](const uint4& v) {
+    return make_uint4(phase_pair_to_bf16(v.x), phase_pair_to_bf16(v.y), phase_pair_to_bf16(v.z), phase_pair_to_bf16(v.w));
+  };
+  auto stash = [&](int buf, Stage& st) {
     char* base = lds + buf * kBufBytes + unit_off;
-    if (kind == 1)  // phase-coded sin stage -> bf16 activation values
-      st1 = make_uint4(phase_pair_to_bf16(st1.x), phase_pair_to_bf16(st1.y), phase_pair_to_bf16(st1.z), phase_pair_to_bf16(st1.w));
-    *reinterpret_cast<uint4*>(base + wave * kFragStride) = st0;
-    *reinterpret_cast<uint4*>(base + (16 + wave) * kFragStride) = st1;
-    if (wave < 2) *reinterpret_cast<uint4*>(base + (32 + wave) * kFragStride) = st2;
+#ifndef SR_ABL_NODECODE
+    if (kind == 1) st.c0 = decode(st.c0), st.c1 = decode(st.c1);  // phase-coded sin stage -> bf16 activation values
+#endif
+    *reinterpret_cast<uint4*>(base + wave * kFragStride) = st.r0;
+    *reinterpret_cast<uint4*>(base + (8 + wave) * kFragStride) = st.r1;
+    *reinterpret_cast<uint4*>(base + (16 + wave) * kFragStride) = st.c0;
+    *reinterpret_cast<uint4*>(base + (24 + wave) * kFragStride) = st.c1;
+    if (wave < 2) *reinterpret_cast<uint4*>(base + (32 + wave) * kFragStride) = st.ax;
   };
 
   // transposed operand reads: lane = (hh, rh, m, q): MFMA row/col = 16*rh + 4*q + e, k = 8*hh + 4*rd + m
   const int hh = lane >> 5, rh = (lane >> 4) & 1, m = (lane >> 2) & 3, q = lane & 3;
   const int rd_off = rh * kFragStride + (q >> 1) * kHslotStride + (8 * hh + m) * 16 + (q & 1) * 8;
-  const int wr = wave >> 2, wc = wave & 3;
+  const int wr = wave >> 1, wc = wave & 1;
   auto operand = [&](const char* buf, int frag_pair, int ks) {
     const char* p = buf + frag_pair * 2 * kFragStride + ks * 256 + rd_off;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
@@ -96,33 +106,46 @@ __global__ void __launch_bounds__(1024) wgrad_kernel(const WgradParams prm) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   };
   const bool main_on = nc > 0;
-  const int aux_rt = wc >> 1, aux_ks = wc & 1;
 
-  f32x16 acc[2][2] = {}, acc_aux = {};
-  if (t_begin < t_end) fetch(t_begin);
-  int buf = 0;
-  for (long tile = t_begin; tile < t_end; ++tile) {
-    stash(buf);
-    __syncthreads();
-    if (tile + 1 < t_end) fetch(tile + 1);  // next tile's global loads fly during this tile's MFMAs
-    const char* b = lds + buf * kBufBytes;
+  f32x16 acc[2][4] = {}, acc_aux = {};
+  auto compute = [&](const char* b) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const uint4 a0 = operand(b, 2 * wr, ks), a1 = operand(b, 2 * wr + 1, ks);
+#ifndef SR_ABL_NOMFMA
       if (main_on) {
-        const uint4 b0 = operand(b, 8 + 2 * wc, ks), b1 = operand(b, 8 + 2 * wc + 1, ks);
-        acc[0][0] = mma(a0, b0, acc[0][0]);
-        acc[0][1] = mma(a0, b1, acc[0][1]);
-        acc[1][0] = mma(a1, b0, acc[1][0]);
-        acc[1][1] = mma(a1, b1, acc[1][1]);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const uint4 bc = operand(b, 8 + 4 * wc + ct, ks);
+          acc[0][ct] = mma(a0, bc, acc[0][ct]);
+          acc[1][ct] = mma(a1, bc, acc[1][ct]);
+        }
       }
-      if (aux_ks == ks) {  // wave-uniform: this wave's one aux MFMA of the tile
-        const uint4 bx = operand(b, 16, ks);  // aux fragments 32, 33 = fragment pair 16
-        if (aux_rt) acc_aux = mma(a1, bx, acc_aux);
-        else acc_aux = mma(a0, bx, acc_aux);
-      }
+#endif
+      const uint4 bx = operand(b, 16, ks);  // aux fragments 32, 33 = fragment pair 16
+      if (wc) acc_aux = mma(a1, bx, acc_aux);  // wave-uniform
+      else acc_aux = mma(a0, bx, acc_aux);
     }
-    buf ^= 1;
+  };
+
+  Stage sa, sb;  // tiles t and t+1 in flight: the loop is unrolled by two so the sets keep static names
+  if (t_begin < t_end) fetch(t_begin, sa);
+  if (t_begin + 1 < t_end) fetch(t_begin + 1, sb);
+  for (long tile = t_begin; tile < t_end; tile += 2) {
+    stash(0, sa);
+    __syncthreads();
+#ifndef SR_ABL_NOLOAD
+    if (tile + 2 < t_end) fetch(tile + 2, sa);
+#endif
+    compute(lds);
+    if (tile + 1 < t_end) {
+      stash(1, sb);
+      __syncthreads();
+#ifndef SR_ABL_NOLOAD
+      if (tile + 3 < t_end) fetch(tile + 3, sb);
+#endif
+      compute(lds + kBufBytes);
+    }
   }
 
   float* out = prm.partial + (long)blockIdx.y * prm.split_stride + (long)blockIdx.x * kBlockFloats;
@@ -131,29 +154,19 @@ __global__ void __launch_bounds__(1024) wgrad_kernel(const WgradParams prm) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
           const int row = 64 * wr + 32 * rt + (g & 3) + 8 * (g >> 2) + 4 * hh;
-          const int col = 64 * wc + 32 * ct + (lane & 31);
+          const int col = 128 * wc + 32 * ct + (lane & 31);
           if (row < n_rows && col < n_cols) out[row * 256 + col] = acc[rt][ct][g];
         }
   }
-  // aux columns: add the k-step-1 half to the k-step-0 half through LDS, then store rows [64 wr + 32 aux_rt ..) x 32 columns
-  __syncthreads();
-  float* scratch = reinterpret_cast<float*>(lds) + ((wr * 2 + aux_rt) * 64 + lane) * 16;
-  if (aux_ks == 1) {
+  float* oa = out + 256 * 256;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) scratch[g] = acc_aux[g];
-  }
-  __syncthreads();
-  if (aux_ks == 0) {
-    float* oa = out + 256 * 256;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const int row = 64 * wr + 32 * aux_rt + (g & 3) + 8 * (g >> 2) + 4 * hh;
-      if (row < n_rows) oa[row * 32 + (lane & 31)] = acc_aux[g] + scratch[g];
-    }
+  for (int g = 0; g < 16; ++g) {
+    const int row = 64 * wr + 32 * wc + (g & 3) + 8 * (g >> 2) + 4 * hh;
+    if (row < n_rows) oa[row * 32 + (lane & 31)] = acc_aux[g];
   }
 }
 
@@ -196,7 +209,7 @@ extern "C" int sr_satnerf_wgrad(int feat, int tau, int64_t n_points, const uint1
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgrad_kernel, dim3(n_blocks, n_split), dim3(1024), lds, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(n_blocks, n_split), dim3(512), lds, (hipStream_t)stream, p);
   return check_launch("wgrad_kernel");
 }
 

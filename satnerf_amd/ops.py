@@ -164,6 +164,16 @@ def composite_bwd(z, sigma, noise, noise_std, albedo, sun_v, sky_rgb, weights, t
     return d_sigma, d_albedo, d_sun, d_sky
 
 
+def sample_pdf(bins, weights, u, eps=1e-5):
+    n, nb = bins.shape
+    _chk(bins, "bins"), _chk(weights, "weights"), _chk(u, "u")
+    if tuple(weights.shape) != (n, nb - 1) or u.shape[0] != n:
+        raise ValueError(f"sample_pdf: weights must be ({n},{nb - 1}) and u ({n},I)")
+    out = torch.empty(n, u.shape[1], dtype=torch.float32, device=bins.device)
+    _lib.call("sr_sample_pdf", _p(bins), _p(weights), _p(u), n, nb, u.shape[1], float(eps), _p(out), _stream())
+    return out
+
+
 def sample_pdf_merge(z_coarse, weights_coarse, u, eps=1e-5):
     n, s = z_coarse.shape
     i = u.shape[1]

@@ -139,10 +139,17 @@ def render_rays(models, args, rays, ts):
 
 
 def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
-    """``rendering.sample_pdf``: samples only (no merge).  Implemented on the merge kernel by passing the bins'
-    generating depths is not possible in general, so this entry point accepts what the reference accepts and
-    runs the resampling kernel on a synthetic coarse grid whose mid points are ``bins``."""
-    raise NotImplementedError("use render_rays(n_importance>0): the HIP path fuses sample_pdf with the sort/merge (sr_sample_pdf_merge)")
+    """``rendering.sample_pdf`` (rendering.py:10-49): draw ``N_importance`` depths per ray from the piecewise-constant pdf
+    ``weights`` (N, nb-1) over ``bins`` (N, nb).  ``det`` uses u = linspace(0,1,N_importance) instead of a uniform draw.
+    (``render_rays`` itself uses the fused resample+merge kernel.)"""
+    if not bins.is_cuda:
+        raise RuntimeError("bins must be on the GPU: satnerf_amd has no CPU path")
+    n = bins.shape[0]
+    if det:
+        u = torch.linspace(0, 1, N_importance, device=bins.device).expand(n, N_importance).contiguous()
+    else:
+        u = _rng.rand(n, N_importance, bins.device)
+    return ops.sample_pdf(bins.contiguous().float(), weights.contiguous().float(), u, eps)
 
 
 @torch.no_grad()

@@ -114,6 +114,21 @@ def test_sample_pdf_merge_matches_oracle(s, i):
     assert err_hip <= 4 * err_ref + 1e-6, (err_hip, err_ref)
 
 
+def test_sample_pdf_standalone_golden():
+    _, rendering, _ = _lazy()
+    g = load_golden("sample_pdf")
+    with rendering.replay_rng([g["u"].to(DEV)]):
+        z = rendering.sample_pdf(g["bins"].to(DEV), g["weights"].to(DEV), 48, det=False).cpu()
+    zd = rendering.sample_pdf(g["bins"].to(DEV), g["weights"].to(DEV), 48, det=True).cpu()
+    assert z.shape == g["z_rand"].shape
+    # det=True (unreachable in the reference: perturb is hard-wired to 1, rendering.py:59) ends at u == 1.0 exactly, where the
+    # result flips between the last two bins depending on whether the fp32 cdf tail rounds to 1.0000001 or 0.99999994 -- a
+    # 1-ulp discontinuity of the algorithm itself (summation order), so that single endpoint is excluded
+    for got, want in ((z, g["z_rand"]), (zd[:, :-1], g["z_det"][:, :-1])):
+        assert (got - want).abs().max() < 1e-4
+        assert ((got - want).abs() > 2e-6).float().mean() < 5e-3
+
+
 @pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-4), ("bf16", 2e-2)])
 def test_mlp_forward_points_golden(mode, tol):
     _, _, load_model = _lazy()
