@@ -115,6 +115,18 @@ int sr_sky_bwd(const float* sun, int sun_stride, int64_t n, int hidden, const fl
                const float* sky, const float* d_sky, float* g_w1, float* g_b1, float* g_w2, float* g_b2, void* stream);
 int sr_embedding_bwd(const float* d_t, const int64_t* ts, int64_t n_rays, int n_samples, int tau, float* g_emb, void* stream);
 
+/* ---- fused fast-path launches of the training step (same arithmetic as the separate entry points) -------------------
+ * sr_ray_setup = sr_ray_sample_fwd + sr_sky_fwd (rays need >= 11 columns);
+ * sr_render_loss = sr_composite_fwd -> sr_satnerf_loss -> sr_composite_bwd for n_samples <= 64, one wave per ray:
+ *   outputs the MLP-backward inputs d_sigma (N,S), d_albedo (N,S,3), d_sun_v (N,S), g_beta (N,S), the per-ray d_sky (N,3),
+ *   the loss partial sums (ceil(N/4)) and optionally the rendered rgb (N,3). */
+int sr_ray_setup(const float* rays, int ray_stride, const float* u, int64_t n_rays, int n_samples, int hidden, const float* w1,
+                 const float* b1, const float* w2, const float* b2, float* z_vals, float* sky, void* stream);
+int sr_render_loss(const float* z_vals, const float* sigma, const float* noise, float noise_std, const float* albedo,
+                   const float* sun_v, const float* beta, const float* sky, const float* target, int64_t n_rays, int n_samples,
+                   float beta_min, float* loss_parts, float* rgb, float* d_sigma, float* d_albedo, float* d_sun_v, float* g_beta,
+                   float* d_sky, void* stream);
+
 /* ---- training-step kernels --------------------------------------------------------------
  * sr_satnerf_loss: metrics.SatNerfLoss for the coarse model (metrics.py:21-25,56-73): value = sum of
  * loss_parts[0 .. ceil(N/4)), and grad_scale * dLoss/d{rgb (N,3), weights (N,S), beta (N,S)} in g_*.

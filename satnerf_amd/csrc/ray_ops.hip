@@ -114,6 +114,46 @@ __global__ void __launch_bounds__(256) sky_kernel(const float* __restrict__ sun,
   }
 }
 
+// ---- sampling + sky head in one launch (training fast path), one wave per ray ---------------------------------------------------
+__global__ void __launch_bounds__(256) ray_setup_kernel(const float* __restrict__ rays, int ray_stride, const float* __restrict__ u, long n_rays,
+                                                       int S, int hidden, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ z_out,
+                                                       float* __restrict__ sky) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
+  if (r >= n_rays) return;
+  const float* ray = rays + r * ray_stride;
+  {
+#pragma clang fp contract(off)
+    const float near = ray[6], far = ray[7];
+    const float step = 1.0f / (float)(S - 1);
+    for (int j = lane; j < S; j += 64) {
+      const float zj = lerp_near_far(near, far, linspace01(j, S, step));
+      float lower = zj, upper = zj;
+      if (j > 0) lower = 0.5f * (lerp_near_far(near, far, linspace01(j - 1, S, step)) + zj);
+      if (j < S - 1) upper = 0.5f * (zj + lerp_near_far(near, far, linspace01(j + 1, S, step)));
+      const float span = upper - lower;
+      const float jit = span * u[r * S + j];
+      z_out[r * S + j] = lower + jit;
+    }
+  }
+  const float sx = ray[8], sy = ray[9], sz = ray[10];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int k = lane; k < hidden; k += 64) {
+    float hk = __builtin_fmaf(w1[k * 3 + 2], sz, __builtin_fmaf(w1[k * 3 + 1], sy, __builtin_fmaf(w1[k * 3], sx, b1[k])));
+    hk = hk > 0.f ? hk : 0.f;
+    a0 = __builtin_fmaf(w2[k], hk, a0);
+    a1 = __builtin_fmaf(w2[hidden + k], hk, a1);
+    a2 = __builtin_fmaf(w2[2 * hidden + k], hk, a2);
+  }
+  a0 = wave_sum(a0), a1 = wave_sum(a1), a2 = wave_sum(a2);
+  if (lane == 0) {
+    sky[r * 3 + 0] = sigmoid_f(a0 + b2[0]);
+    sky[r * 3 + 1] = sigmoid_f(a1 + b2[1]);
+    sky[r * 3 + 2] = sigmoid_f(a2 + b2[2]);
+  }
+}
+
 // ---- compositing: models/satnerf.py:52-70 --------------------------------------------------------------------
 // One wave per ray; samples are processed in segments of 64 (lane = sample) with a running transmittance carry.
 __device__ __forceinline__ void alpha_of(const float* z, const float* sigma, const float* noise, float noise_std, long base,
@@ -513,6 +553,16 @@ extern "C" int sr_ray_sample_fwd(const float* rays, int ray_stride, const float*
   hipLaunchKernelGGL(ray_sample_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rays, ray_stride, u,
                      (long)n_rays, n_samples, z_vals);
   return check_launch("ray_sample_kernel");
+}
+
+extern "C" int sr_ray_setup(const float* rays, int ray_stride, const float* u, int64_t n_rays, int n_samples, int hidden, const float* w1,
+                            const float* b1, const float* w2, const float* b2, float* z_vals, float* sky, void* stream) {
+  SR_REQUIRE(rays && u && w1 && b1 && w2 && b2 && z_vals && sky, "sr_ray_setup: null pointer");
+  SR_REQUIRE(ray_stride >= 11 && n_samples >= 2, "sr_ray_setup: ray_stride>=11 and n_samples>=2 required");
+  if (n_rays <= 0) return 0;
+  hipLaunchKernelGGL(ray_setup_kernel, dim3((unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(256), 0, (hipStream_t)stream, rays,
+                     ray_stride, u, (long)n_rays, n_samples, hidden, w1, b1, w2, b2, z_vals, sky);
+  return check_launch("ray_setup_kernel");
 }
 
 extern "C" int sr_sky_fwd(const float* sun, int sun_stride, int64_t n, int hidden, const float* w1, const float* b1, const float* w2,

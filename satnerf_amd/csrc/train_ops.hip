@@ -53,6 +53,108 @@ __global__ void __launch_bounds__(256) satnerf_loss_kernel(const float* __restri
   }
 }
 
+// ---- fused per-ray training kernel: compositing forward -> SatNerf loss -> compositing backward ---------------------------
+// One wave per ray (lane = sample, S <= 64).  Replaces models/satnerf.py:52-70 + metrics.py:21-25,56-73 + their autograd in ONE
+// launch: the wave already holds alpha, T, w for the whole ray, so the loss gradient (which needs the ray sums beta_r, rgb_r) and
+// the closed-form compositing backward run back to back in registers.  Writes what the MLP backward consumes
+// (d_sigma, d_albedo, d_sun_v, g_beta per sample; d_sky per ray), the loss partial sums and the rendered colour (for logging).
+__device__ __forceinline__ float wave_scan_mul_f(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_up(v, d, 64);
+    if (lane >= d) v *= o;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_rscan_add_f(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_down(v, d, 64);
+    if (lane + d < 64) v += o;
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(256) render_loss_kernel(const float* __restrict__ z, const float* __restrict__ sigma,
+                                                         const float* __restrict__ noise, float noise_std, const float* __restrict__ albedo,
+                                                         const float* __restrict__ sun_v, const float* __restrict__ beta,
+                                                         const float* __restrict__ sky, const float* __restrict__ target, long n_rays, int S,
+                                                         float beta_min, float* __restrict__ loss_parts, float* __restrict__ rgb_out,
+                                                         float* __restrict__ d_sigma, float* __restrict__ d_albedo, float* __restrict__ d_sun,
+                                                         float* __restrict__ g_beta, float* __restrict__ d_sky) {
+  __shared__ float part[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long r = (long)blockIdx.x * 4 + wv;
+  if (lane == 0) part[wv] = 0.f;
+  const bool ray_on = r < n_rays;
+  const bool on = ray_on && lane < S;
+  const long i = ray_on ? r * S + (lane < S ? lane : S - 1) : 0;
+  // forward: alpha, transmittance, weights (models/satnerf.py:52-63)
+  float delta = 0.f, dens = 0.f, alpha = 0.f, zj = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, sv = 0.f, bj = 0.f;
+  float k0 = 0.f, k1 = 0.f, k2 = 0.f;
+  if (ray_on) k0 = sky[r * 3], k1 = sky[r * 3 + 1], k2 = sky[r * 3 + 2];
+  if (on) {
+#pragma clang fp contract(off)
+    zj = z[i];
+    delta = lane < S - 1 ? z[i + 1] - zj : 1e10f;
+    float s = sigma[i];
+    if (noise) s = s + noise[i] * noise_std;
+    dens = s;
+    alpha = 1.0f - expf(-delta * (s > 0.f ? s : 0.f));
+    a0 = albedo[i * 3], a1 = albedo[i * 3 + 1], a2 = albedo[i * 3 + 2];
+    sv = sun_v[i], bj = beta[i];
+  }
+  float f;
+  {
+#pragma clang fp contract(off)
+    f = on ? (1.0f - alpha) + 1e-10f : 1.f;
+  }
+  const float incl = wave_scan_mul_f(f, lane);
+  float T = __shfl_up(incl, 1, 64);
+  if (lane == 0) T = 1.f;
+  const float w = on ? alpha * T : 0.f;
+  const float i0 = sv + (1.f - sv) * k0, i1 = sv + (1.f - sv) * k1, i2 = sv + (1.f - sv) * k2;  // irradiance, :68
+  const float c0 = wave_sum_f(w * a0 * i0), c1 = wave_sum_f(w * a1 * i1), c2 = wave_sum_f(w * a2 * i2);
+  const float b = wave_sum_f(w * bj) + beta_min;
+  const float r0 = fminf(fmaxf(c0, 0.f), 1.f), r1 = fminf(fmaxf(c1, 0.f), 1.f), r2 = fminf(fmaxf(c2, 0.f), 1.f);
+  // loss (metrics.py:21-25) and its gradient w.r.t. rgb and beta_r
+  const float inv_n = 1.0f / (float)n_rays;
+  float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+  if (ray_on) e0 = r0 - target[r * 3], e1 = r1 - target[r * 3 + 1], e2 = r2 - target[r * 3 + 2];
+  const float sq = e0 * e0 + e1 * e1 + e2 * e2;
+  const float ib2 = 1.0f / (b * b);
+  if (lane == 0 && ray_on) {
+    float contrib = sq * ib2 * (0.5f / 3.0f) * inv_n + 0.5f * logf(b) * inv_n;
+    if (r == 0) contrib += 1.5f;
+    part[wv] = contrib;
+    if (rgb_out) rgb_out[r * 3] = r0, rgb_out[r * 3 + 1] = r1, rgb_out[r * 3 + 2] = r2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) loss_parts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+  if (!ray_on) return;
+  const float kk = ib2 * (1.0f / 3.0f) * inv_n;
+  const float gr0 = (c0 >= 0.f && c0 <= 1.f) ? e0 * kk : 0.f;  // torch.clamp passes the gradient where min <= x <= max
+  const float gr1 = (c1 >= 0.f && c1 <= 1.f) ? e1 * kk : 0.f;
+  const float gr2 = (c2 >= 0.f && c2 <= 1.f) ? e2 * kk : 0.f;
+  const float db = (-sq * ib2 / b * (1.0f / 3.0f) + 0.5f / b) * inv_n;  // d loss / d beta_r
+  // backward through compositing: G_j = dL/dw_j
+  const float G = db * bj + gr0 * a0 * i0 + gr1 * a1 * i1 + gr2 * a2 * i2;
+  const float tail = on ? G * w : 0.f;
+  const float suf = wave_rscan_add_f(tail, lane);
+  const float after = suf - tail;
+  const float q0 = w * gr0, q1 = w * gr1, q2 = w * gr2;
+  const float di0 = q0 * a0, di1 = q1 * a1, di2 = q2 * a2;
+  const float s0 = wave_sum_f(di0 * (1.f - sv)), s1 = wave_sum_f(di1 * (1.f - sv)), s2 = wave_sum_f(di2 * (1.f - sv));
+  if (lane == 0) d_sky[r * 3] = s0, d_sky[r * 3 + 1] = s1, d_sky[r * 3 + 2] = s2;
+  if (on) {
+    const float dalpha = G * T - after / f;
+    d_sigma[i] = dens > 0.f ? dalpha * delta * expf(-delta * dens) : 0.f;
+    d_albedo[i * 3] = q0 * i0, d_albedo[i * 3 + 1] = q1 * i1, d_albedo[i * 3 + 2] = q2 * i2;
+    d_sun[i] = di0 * (1.f - k0) + di1 * (1.f - k1) + di2 * (1.f - k2);
+    g_beta[i] = db * w;
+  }
+}
+
 // torch.optim.Adam (main.py:84: lr 5e-4, betas (0.9, 0.999), eps 1e-8, no weight decay), one launch over the flat buffer.
 // The 1-based step count arrives by value (the update is launched eagerly after the gradient all-reduce, outside the
 // captured forward/backward graph); grad is optionally zeroed for the next step.
@@ -82,6 +184,20 @@ extern "C" int sr_satnerf_loss(const float* rgb, const float* weights, const flo
   hipLaunchKernelGGL(satnerf_loss_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rgb, weights, beta, target,
                      (long)n_rays, n_samples, beta_min, grad_scale, loss_parts, g_rgb, g_weights, g_beta);
   return check_launch("satnerf_loss_kernel");
+}
+
+extern "C" int sr_render_loss(const float* z_vals, const float* sigma, const float* noise, float noise_std, const float* albedo,
+                              const float* sun_v, const float* beta, const float* sky, const float* target, int64_t n_rays, int n_samples,
+                              float beta_min, float* loss_parts, float* rgb, float* d_sigma, float* d_albedo, float* d_sun_v, float* g_beta,
+                              float* d_sky, void* stream) {
+  SR_REQUIRE(z_vals && sigma && albedo && sun_v && beta && sky && target && loss_parts && d_sigma && d_albedo && d_sun_v && g_beta && d_sky,
+             "sr_render_loss: null pointer");
+  SR_REQUIRE(n_samples >= 1 && n_samples <= 64, "sr_render_loss: n_samples=%d unsupported (1..64); use the separate kernels", n_samples);
+  if (n_rays <= 0) return 0;
+  hipLaunchKernelGGL(render_loss_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z_vals, sigma, noise, noise_std,
+                     albedo, sun_v, beta, sky, target, (long)n_rays, n_samples, beta_min, loss_parts, rgb, d_sigma, d_albedo, d_sun_v, g_beta,
+                     d_sky);
+  return check_launch("render_loss_kernel");
 }
 
 extern "C" int sr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,

@@ -258,3 +258,27 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=5e-4, betas=(0.9, 0.9
 def pack_all(flat, idx, scale, hi, lo, f32_idx, f32_scale, f32_out):
     _lib.call("sr_pack_all", _p(_chk(flat, "flat")), _p(_chk(idx, "idx", torch.int32)), _p(_chk(scale, "scale")), idx.numel(), _p(hi), _p(lo),
               _p(_chk(f32_idx, "f32_idx", torch.int32)), _p(_chk(f32_scale, "f32_scale")), f32_idx.numel(), _p(f32_out), _stream())
+
+
+def ray_setup(rays, u, n_samples, w1, b1, w2, b2):
+    """Fused sr_ray_sample_fwd + sr_sky_fwd: returns (z (N,S), sky (N,3))."""
+    rays, stride = _rows(rays, "rays", 11)
+    n = rays.shape[0]
+    z = torch.empty(n, n_samples, dtype=torch.float32, device=rays.device)
+    sky_rgb = torch.empty(n, 3, dtype=torch.float32, device=rays.device)
+    _lib.call("sr_ray_setup", _p(rays), stride, _p(_chk(u, "u")), n, n_samples, w1.shape[0], _p(_chk(w1, "w1")), _p(_chk(b1, "b1")), _p(_chk(w2, "w2")),
+              _p(_chk(b2, "b2")), _p(z), _p(sky_rgb), _stream())
+    return z, sky_rgb
+
+
+def render_loss(z, sigma, noise, noise_std, albedo, sun_v, beta, sky_rgb, target, beta_min=0.05):
+    """Fused compositing forward + SatNerf loss + compositing backward (S <= 64).
+    Returns (loss partial sums, rgb (N,3), d_sigma (N,S), d_albedo (N,S,3), d_sun (N,S), g_beta (N,S), d_sky (N,3))."""
+    n, s = z.shape
+    dev = z.device
+    e = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+    loss, rgb, d_sigma, d_albedo, d_sun, g_beta, d_sky = e((n + 3) // 4), e(n, 3), e(n, s), e(n, s, 3), e(n, s), e(n, s), e(n, 3)
+    _lib.call("sr_render_loss", _p(_chk(z, "z")), _p(_chk(sigma, "sigma")), _p(_chk(noise, "noise", allow_none=True)), float(noise_std),
+              _p(_chk(albedo, "albedo")), _p(_chk(sun_v, "sun_v")), _p(_chk(beta, "beta")), _p(_chk(sky_rgb, "sky")), _p(_chk(target, "target")), n, s,
+              float(beta_min), _p(loss), _p(rgb), _p(d_sigma), _p(d_albedo), _p(d_sun), _p(g_beta), _p(d_sky), _stream())
+    return loss, rgb, d_sigma, d_albedo, d_sun, g_beta, d_sky

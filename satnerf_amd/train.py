@@ -113,6 +113,7 @@ class Trainer:
                        and args.model == "sat-nerf")
         self.use_graph = use_graph and self.direct
         self._graph, self._static = None, None
+        self.last_rgb = None
         self.last_loss = None
 
     # ---- forward + loss + backward on the current stream, gradients accumulate into the flat buffer -------------------
@@ -128,19 +129,24 @@ class Trainer:
         model.repack(mode, backward=True)
         hi, lo, l0 = model.packed(mode)
         bstream, maps = model.packed_backward()
-        z = ops.ray_sample(rays, torch.rand(n, s, device=rays.device), s)  # rendering.py:77
-        noise = torch.randn(n, s, device=rays.device)                      # models/satnerf.py:58 (drawn even when unused)
+        sk = model.sky_color
+        u = torch.rand(n, s, device=rays.device)  # rendering.py:77
         noise_std = float(args.noise_std)
+        # models/satnerf.py:58 draws randn even when noise_std == 0; the draw is skipped then (results are identical)
+        nz = torch.randn(n, s, device=rays.device) if noise_std != 0 else None
+        z, sky = ops.ray_setup(rays, u, s, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data)
         acts = ops.acts_workspace(n * s, feat, rays.device)
         albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, 3:6], rays[:, 8:11], z, emb.weight.data, ts, n * s, s, feat, tau, mode,
                                                      hi, lo, l0, acts=acts)
-        sk = model.sky_color
-        sky = ops.sky(rays[:, 8:11], sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data)
-        nz = noise if noise_std != 0 else None
-        weights, transp, depth, rgb = ops.composite(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky)
-        loss, g_rgb, g_w, g_beta = ops.satnerf_loss(rgb, weights, beta.view(n, s), rgbs)
-        d_sigma, d_albedo, d_sun, d_sky = ops.composite_bwd(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky, weights,
-                                                           transp, g_rgb, None, g_w, None)
+        if s <= 64:  # one launch: compositing forward -> loss -> compositing backward
+            loss, self.last_rgb, d_sigma, d_albedo, d_sun, g_beta, d_sky = ops.render_loss(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3),
+                                                                                           sun_v.view(n, s), beta.view(n, s), sky, rgbs)
+        else:
+            weights, transp, depth, rgb = ops.composite(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky)
+            loss, g_rgb, g_w, g_beta = ops.satnerf_loss(rgb, weights, beta.view(n, s), rgbs)
+            d_sigma, d_albedo, d_sun, d_sky = ops.composite_bwd(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky,
+                                                               weights, transp, g_rgb, None, g_w, None)
+            self.last_rgb = rgb
         dpre, d_t = ops.satnerf_mlp_bwd(feat, tau, n * s, bstream, acts, albedo, sigma, sun_v, beta, d_albedo, d_sigma, d_sun, g_beta.view(-1))
         from .autograd import _N_SPLIT
 
