@@ -174,3 +174,49 @@ def test_direct_step_matches_autograd_path_and_graph_replay():
     # different jitter draws per trainer (graph-safe generator offsets) -> statistically equal, not bitwise
     assert all(abs(a - b) < 0.05 * abs(b) + 0.02 for a, b in zip(lg, le)), (lg, le)
     assert maxnorm_rel(trg.state.params.cpu(), tre.state.params.cpu()) < 5e-2
+
+
+@pytest.mark.parametrize("tau,n_samples", [(16, 64), (4, 128), (4, 50)])
+def test_gradients_vs_oracle_autograd_variants(tau, n_samples):
+    """Two aux k-steps (tau=16) and sample counts that are not one 64-lane wave, against autograd through the oracle."""
+    from satnerf_amd import rendering
+    from satnerf_amd.models import load_model
+
+    args = O.default_args(t_embbeding_tau=tau, n_samples=n_samples, mlp_mode="bf16x3")
+    params = O.procedural_satnerf_params(256, tau, seed=21)
+    embw = O.procedural_uniform((30, tau), 1.0, 22)
+    m = load_model(args)
+    m.load_state_dict(params)
+    emb = torch.nn.Embedding(30, tau)
+    emb.load_state_dict({"weight": embw})
+    models = {"coarse": m.to(DEV), "t": emb.to(DEV)}
+    rays, ts = O.synthetic_rays(48, seed=23)
+    g = torch.Generator().manual_seed(24)
+    u, nz = torch.rand(48, n_samples, generator=g), torch.randn(48, n_samples, generator=g)
+    target = torch.rand(48, 3, generator=g)
+    loss_of = lambda r, t: ((r["rgb_coarse"] - t) ** 2).sum() + r["depth_coarse"].sum() + (r["weights_coarse"].unsqueeze(-1) * r["beta_coarse"]).sum()  # noqa: E731
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    eo = embw.clone().requires_grad_(True)
+    loss_of(O.render_rays({"coarse": po, "t": eo}, O.default_args(t_embbeding_tau=tau, n_samples=n_samples), rays, ts, O.ReplayRng([u, nz])), target).backward()
+    with rendering.replay_rng([u.to(DEV), nz.to(DEV)]):
+        res = rendering.render_rays(models, args, rays.to(DEV), ts.to(DEV))
+    loss_of(res, target.to(DEV)).backward()
+    sd = dict(models["coarse"].named_parameters())
+    errs = {k: maxnorm_rel(sd[k].grad.cpu(), po[k].grad) for k in po}
+    errs["embedding"] = maxnorm_rel(models["t"].weight.grad.cpu(), eo.grad)
+    worst = max(errs, key=errs.get)
+    print(tau, n_samples, "worst", worst, f"{errs[worst]:.1e}")
+    assert errs[worst] < GRAD_TOL, errs
+
+
+def test_trainer_direct_step_with_128_samples_uses_separate_kernels():
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    torch.manual_seed(0)
+    args = O.default_args(n_samples=128, mlp_mode="bf16")
+    tr = Trainer({"coarse": load_model(args).to(DEV), "t": torch.nn.Embedding(30, 4).to(DEV)}, args)
+    rays, ts = O.synthetic_rays(256, seed=3)
+    target = torch.rand(256, 3, generator=torch.Generator().manual_seed(4)) * 0.2 + 0.4
+    losses = [tr.step(rays.to(DEV), ts.to(DEV), target.to(DEV)).item() for _ in range(20)]
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]

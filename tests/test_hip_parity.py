@@ -228,3 +228,99 @@ def test_unsupported_width_raises():
     m = load_model(O.default_args(fc_units=512)).to(DEV)
     with pytest.raises(Exception):
         m(torch.zeros(4, 3, device=DEV), input_sun_dir=torch.zeros(4, 3, device=DEV), input_t=torch.zeros(4, 4, device=DEV))
+
+
+def _oracle_vs_hip(args, n_rays, seed, tol, sample=None, check=("rgb", "depth", "weights", "beta")):
+    """Fresh random weights (not the golden ones), same draws on both sides; `sample` rays are compared against the oracle."""
+    _, rendering, load_model = _lazy()
+    tau = args.t_embbeding_tau
+    models = {}
+    params = {}
+    for typ, sd in (("coarse", 11),) + ((("fine", 12),) if args.n_importance > 0 else ()):
+        params[typ] = O.procedural_satnerf_params(args.fc_units, tau, seed=sd)
+        m = load_model(args)
+        m.load_state_dict(params[typ])
+        models[typ] = m.to(DEV).eval()
+    embw = O.procedural_uniform((args.t_embbeding_vocab, tau), 1.0, 13)
+    emb = torch.nn.Embedding(args.t_embbeding_vocab, tau)
+    emb.load_state_dict({"weight": embw})
+    models["t"] = emb.to(DEV)
+    rays, ts = O.synthetic_rays(n_rays, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    s, i = args.n_samples, args.n_importance
+    draws = [torch.rand(n_rays, s, generator=g), torch.randn(n_rays, s, generator=g)]
+    if i > 0:
+        draws += [torch.rand(n_rays, i, generator=g), torch.randn(n_rays, s + i, generator=g)]
+    with torch.no_grad(), rendering.replay_rng([d.to(DEV) for d in draws]):
+        res = rendering.render_rays(models, args, rays.to(DEV), ts.to(DEV))
+    torch.cuda.synchronize()
+    idx = torch.arange(n_rays) if sample is None else torch.linspace(0, n_rays - 1, sample).long()
+    oargs = O.default_args(**{k: v for k, v in vars(args).items() if k != "mlp_mode"})
+    with torch.no_grad():
+        want = O.render_rays({**params, "t": embw}, oargs, rays[idx], ts[idx], O.ReplayRng([d[idx] for d in draws]))
+    errs = {}
+    for typ in ("coarse",) + (("fine",) if i > 0 else ()):
+        for k in check:
+            errs[f"{k}_{typ}"] = maxnorm_rel(res[f"{k}_{typ}"].cpu()[idx], want[f"{k}_{typ}"])
+    print({k: f"{e:.1e}" for k, e in errs.items()})
+    assert max(errs.values()) < tol, errs
+    return res
+
+
+def test_tau16_two_aux_ksteps():
+    """class-default t_embedding_dims=16 (models/satnerf.py:82) needs two aux k-steps in the weight stream."""
+    _oracle_vs_hip(O.default_args(t_embbeding_tau=16, mlp_mode="bf16x3"), 77, 31, 1e-4)
+    _oracle_vs_hip(O.default_args(t_embbeding_tau=16, mlp_mode="bf16"), 77, 31, 2e-2)
+
+
+def test_config3_4096_rays_with_importance_sampling():
+    """BASELINE configs[2]: 4096 rays x 64 samples + N_importance=64 (two models); 48 sampled rays against the oracle."""
+    res = _oracle_vs_hip(O.default_args(n_importance=64, mlp_mode="bf16x3"), 4096, 32, 1e-4, sample=48, check=("rgb", "depth", "weights"))
+    assert res["weights_fine"].shape == (4096, 128) and torch.isfinite(res["rgb_fine"]).all()
+    t = res["transparency_fine"]
+    assert (t[:, 1:] <= t[:, :-1] + 1e-6).all()
+
+
+def test_config5_8192_rays_128_samples_chunked():
+    """BASELINE configs[4] shape through batched_inference (chunk 5120 -> ragged second chunk); 32 sampled rays vs the oracle."""
+    _, rendering, load_model = _lazy()
+    args = O.default_args(n_samples=128, mlp_mode="bf16x3")
+    params = O.procedural_satnerf_params(256, 4, seed=11)
+    m = load_model(args)
+    m.load_state_dict(params)
+    embw = O.procedural_uniform((30, 4), 1.0, 13)
+    emb = torch.nn.Embedding(30, 4)
+    emb.load_state_dict({"weight": embw})
+    models = {"coarse": m.to(DEV).eval(), "t": emb.to(DEV)}
+    rays, ts = O.synthetic_rays(8192, seed=33)
+    g = torch.Generator().manual_seed(33)
+    u, nz = torch.rand(8192, 128, generator=g), torch.randn(8192, 128, generator=g)
+    draws = [u[:5120], nz[:5120], u[5120:], nz[5120:]]  # per-chunk draw order (SURVEY.md A.5)
+    with rendering.replay_rng([d.to(DEV) for d in draws]):
+        res = rendering.batched_inference(models, rays.to(DEV), ts.to(DEV), args)
+    assert res["rgb_coarse"].shape == (8192, 3) and res["weights_coarse"].shape == (8192, 128)
+    idx = torch.linspace(0, 8191, 32).long()
+    with torch.no_grad():
+        want = O.render_rays({"coarse": params, "t": embw}, O.default_args(n_samples=128), rays[idx], ts[idx], O.ReplayRng([u[idx], nz[idx]]))
+    for k in ("rgb_coarse", "depth_coarse", "weights_coarse"):
+        assert maxnorm_rel(res[k].cpu()[idx], want[k]) < 1e-4, k
+
+
+def test_odd_inputs_non_contiguous_rays_int32_ts_and_tiny_batches():
+    _, rendering, load_model = _lazy()
+    args = O.default_args(mlp_mode="bf16x3")
+    models = build_models(args)
+    rays, ts = O.synthetic_rays(5, seed=40)
+    wide = torch.zeros(5, 16)
+    wide[:, 2:13] = rays
+    u, nz = torch.rand(5, 64), torch.randn(5, 64)
+    with torch.no_grad():
+        want = O.render_rays({"coarse": O.procedural_satnerf_params(256, 4, seed=1), "t": O.procedural_uniform((30, 4), 1.0, 7)}, O.default_args(),
+                             rays, ts, O.ReplayRng([u, nz]))
+        with rendering.replay_rng([u.to(DEV), nz.to(DEV)]):
+            got = rendering.render_rays(models, args, wide.to(DEV)[:, 2:13], ts.to(DEV).int())  # strided view, int32 indices
+        with rendering.replay_rng([u[:1].to(DEV), nz[:1].to(DEV)]):
+            one = rendering.render_rays(models, args, rays[:1].to(DEV), ts[:1].to(DEV))  # a single ray: 64 points < one workgroup
+    assert maxnorm_rel(got["rgb_coarse"].cpu(), want["rgb_coarse"]) < 1e-4
+    assert maxnorm_rel(got["weights_coarse"].cpu(), want["weights_coarse"]) < 1e-4
+    assert maxnorm_rel(one["weights_coarse"].cpu(), want["weights_coarse"][:1]) < 1e-4
