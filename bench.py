@@ -96,13 +96,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    # SATNERF_BENCH_BACKEND=gloo is a TEST hook: it lets two ranks share one GPU so the N>1 code path can be exercised on a
+    # single-GPU box (gloo stages the all-reduce through the host; never use it for measurements)
+    backend = os.environ.get("SATNERF_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from satnerf_amd import ops, rendering
     from satnerf_amd.models import load_model
