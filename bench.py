@@ -129,23 +129,25 @@ def main():
     model = load_model(args).to(dev)
     emb = torch.nn.Embedding(args.t_embbeding_vocab, args.t_embbeding_tau).to(dev)
     models = {"coarse": model, "t": emb}
-    # GPU-resident synthetic ray bank, different rays per rank and per step
-    bank_rays, bank_ts = O.synthetic_rays(a.rays * 8, seed=20240628 + rank)
-    bank_rays, bank_ts = bank_rays.to(dev), bank_ts.to(dev)
-    bank_rgb = torch.rand(a.rays * 8, 3, generator=torch.Generator().manual_seed(rank)).to(dev)
+    # GPU-resident synthetic ray bank (SURVEY.md 8d recipe) + on-device shuffled batch sampler; ranks draw disjoint shares
+    from satnerf_amd.data import RayBank
+
+    n_bank = max(1 << 20, a.rays * 16 * world)  # 1 M rays (47 MB): an epoch is ~1000 steps, as with a real scene
+    bank_rays, bank_ts = O.synthetic_rays(n_bank, seed=20240628)
+    bank_rgb = torch.rand(n_bank, 3, generator=torch.Generator().manual_seed(7))
+    bank = RayBank(bank_rays.to(dev), bank_rgb.to(dev), bank_ts.to(dev), a.rays, seed=11, rank=rank, world_size=world)
     torch.manual_seed(1234 + rank)  # per-rank sampling jitter
 
     if phase == "train":
         stepper = train_mod.Trainer(models, args, world_size=world)
 
         def step(i):
-            s = (i % 8) * a.rays
-            stepper.step(bank_rays[s:s + a.rays], bank_ts[s:s + a.rays], bank_rgb[s:s + a.rays])
+            stepper.step_from_bank(bank)
     else:
         def step(i):
-            s = (i % 8) * a.rays
+            rays_b, ts_b, _ = bank.next_batch()
             with torch.no_grad():
-                rendering.render_rays(models, args, bank_rays[s:s + a.rays], bank_ts[s:s + a.rays])
+                rendering.render_rays(models, args, rays_b, ts_b)
 
     def fence():
         if world > 1:

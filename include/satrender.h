@@ -135,6 +135,10 @@ int sr_render_loss(const float* z_vals, const float* sigma, const float* noise, 
 int sr_satnerf_loss(const float* rgb, const float* weights, const float* beta, const float* target, int64_t n_rays,
                     int n_samples, float beta_min, float grad_scale, float* loss_parts, float* g_rgb, float* g_weights,
                     float* g_beta, void* stream);
+/* batch gather from a GPU-resident ray bank: rows idx[0..n) of rays (.,11), rgbs (.,3), ts (.) -> contiguous batch tensors
+ * (replaces DataLoader collate + host-to-device copy, main.py:96-110) */
+int sr_gather_batch(const float* rays, const float* rgbs, const int64_t* ts, const int64_t* idx, int64_t n, float* out_rays,
+                    float* out_rgbs, int64_t* out_ts, void* stream);
 int sr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                  float beta2, float eps, float grad_scale, int64_t step, int zero_grad, void* stream);
 

@@ -155,6 +155,22 @@ __global__ void __launch_bounds__(256) render_loss_kernel(const float* __restric
   }
 }
 
+// ---- batch gather from the GPU-resident ray bank (replaces DataLoader collate + H2D copy, main.py:96-110) -----------------
+// out_rays[b] = rays[idx[b]] (11 floats), out_rgbs[b] = rgbs[idx[b]] (3), out_ts[b] = ts[idx[b]]; one thread per (ray, column)
+__global__ void __launch_bounds__(256) gather_batch_kernel(const float* __restrict__ rays, const float* __restrict__ rgbs,
+                                                          const long long* __restrict__ ts, const long long* __restrict__ idx, long n,
+                                                          float* __restrict__ out_rays, float* __restrict__ out_rgbs,
+                                                          long long* __restrict__ out_ts) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long b = t >> 4;
+  const int c = (int)(t & 15);
+  if (b >= n) return;
+  const long src = idx[b];
+  if (c < 11) out_rays[b * 11 + c] = rays[src * 11 + c];
+  else if (c < 14) out_rgbs[b * 3 + (c - 11)] = rgbs[src * 3 + (c - 11)];
+  else if (c == 14) out_ts[b] = ts[src];
+}
+
 // torch.optim.Adam (main.py:84: lr 5e-4, betas (0.9, 0.999), eps 1e-8, no weight decay), one launch over the flat buffer.
 // The 1-based step count arrives by value (the update is launched eagerly after the gradient all-reduce, outside the
 // captured forward/backward graph); grad is optionally zeroed for the next step.
@@ -198,6 +214,15 @@ extern "C" int sr_render_loss(const float* z_vals, const float* sigma, const flo
                      albedo, sun_v, beta, sky, target, (long)n_rays, n_samples, beta_min, loss_parts, rgb, d_sigma, d_albedo, d_sun_v, g_beta,
                      d_sky);
   return check_launch("render_loss_kernel");
+}
+
+extern "C" int sr_gather_batch(const float* rays, const float* rgbs, const int64_t* ts, const int64_t* idx, int64_t n, float* out_rays,
+                               float* out_rgbs, int64_t* out_ts, void* stream) {
+  SR_REQUIRE(rays && rgbs && ts && idx && out_rays && out_rgbs && out_ts, "sr_gather_batch: null pointer");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(gather_batch_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rays, rgbs,
+                     (const long long*)ts, (const long long*)idx, (long)n, out_rays, out_rgbs, (long long*)out_ts);
+  return check_launch("gather_batch_kernel");
 }
 
 extern "C" int sr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,

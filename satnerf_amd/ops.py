@@ -282,3 +282,16 @@ def render_loss(z, sigma, noise, noise_std, albedo, sun_v, beta, sky_rgb, target
               _p(_chk(albedo, "albedo")), _p(_chk(sun_v, "sun_v")), _p(_chk(beta, "beta")), _p(_chk(sky_rgb, "sky")), _p(_chk(target, "target")), n, s,
               float(beta_min), _p(loss), _p(rgb), _p(d_sigma), _p(d_albedo), _p(d_sun), _p(g_beta), _p(d_sky), _stream())
     return loss, rgb, d_sigma, d_albedo, d_sun, g_beta, d_sky
+
+
+def gather_batch(rays, rgbs, ts, idx, out=None):
+    """Rows ``idx`` of the ray bank -> (rays (B,11), ts (B,), rgbs (B,3)), one launch."""
+    n = idx.numel()
+    if rays.shape[1] != 11 or rgbs.shape[1] != 3:
+        raise ValueError("gather_batch expects (N,11) rays and (N,3) rgbs")
+    if out is None:
+        out = (torch.empty(n, 11, dtype=torch.float32, device=rays.device), torch.empty(n, dtype=torch.int64, device=rays.device),
+               torch.empty(n, 3, dtype=torch.float32, device=rays.device))
+    _lib.call("sr_gather_batch", _p(_chk(rays, "rays")), _p(_chk(rgbs, "rgbs")), _p(_chk(ts, "ts", torch.int64)), _p(_chk(idx, "idx", torch.int64)), n,
+              _p(_chk(out[0], "out_rays")), _p(_chk(out[2], "out_rgbs")), _p(_chk(out[1], "out_ts", torch.int64)), _stream())
+    return out

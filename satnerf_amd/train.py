@@ -171,14 +171,22 @@ class Trainer:
             self._static_loss = self._forward_backward(*self._static)
         self.state.zero_grad()  # capture does not execute
 
-    def step(self, rays, ts, rgbs):
+    def step_from_bank(self, bank):
+        """One step on the bank's next batch; with a captured graph the batch is gathered straight into its static inputs."""
+        if self.direct and self._graph is not None and self._static[0].shape[0] == bank.batch_size:
+            bank.next_batch(out=self._static)
+            return self.step(*self._static, _inputs_in_place=True)
+        return self.step(*bank.next_batch())
+
+    def step(self, rays, ts, rgbs, _inputs_in_place=False):
         from . import ops
 
         if self.direct:
             if self.use_graph and float(self.args.noise_std) == 0.0:
                 if self._graph is None or self._static[0].shape != rays.shape:
                     self._capture(rays, ts, rgbs)
-                self._static[0].copy_(rays), self._static[1].copy_(ts), self._static[2].copy_(rgbs)
+                if not _inputs_in_place:
+                    self._static[0].copy_(rays), self._static[1].copy_(ts), self._static[2].copy_(rgbs)
                 self._graph.replay()
                 loss = self._static_loss
             else:
