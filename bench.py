@@ -144,10 +144,16 @@ def main():
         def step(i):
             stepper.step_from_bank(bank)
     else:
+        graphed = rendering.GraphedRenderer(models, args, a.rays, dev)
+        use_graph = [True]
+
         def step(i):
             rays_b, ts_b, _ = bank.next_batch()
-            with torch.no_grad():
-                rendering.render_rays(models, args, rays_b, ts_b)
+            if use_graph[0]:
+                graphed(rays_b, ts_b)
+            else:
+                with torch.no_grad():
+                    rendering.render_rays(models, args, rays_b, ts_b)
 
     def fence():
         if world > 1:
@@ -168,6 +174,8 @@ def main():
     ops.kernel_timer = timer
     if phase == "train":
         stepper.use_graph = False
+    else:
+        use_graph[0] = False
     for i in range(min(a.steps, 30)):
         step(i)
     torch.cuda.synchronize()

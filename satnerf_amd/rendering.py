@@ -152,13 +152,64 @@ def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
     return ops.sample_pdf(bins.contiguous().float(), weights.contiguous().float(), u, eps)
 
 
+class GraphedRenderer:
+    """``render_rays`` (no grad) for a FIXED chunk shape replayed from one hipGraph.
+
+    A chunk is ~8 launches of 5-400 us; issued eagerly from Python they leave the GPU idle about half the time at 1024 rays
+    (profiles/r01_bench_forward.json).  The captured graph contains the same launches (including the RNG draws, which advance
+    torch's generator exactly as eager calls would), so results and the random stream are unchanged.  Outputs are views of
+    static buffers: they are overwritten by the next call -- clone what must survive.  Weights may change between calls
+    (the pack kernels are part of the graph) but not be re-allocated.
+    """
+
+    def __init__(self, models, args, n_rays, device):
+        self.models, self.args, self.n = models, args, n_rays
+        self.rays = torch.zeros(n_rays, 11, device=device)
+        self.ts = torch.zeros(n_rays, dtype=torch.int64, device=device)
+        self.graph, self.out = None, None
+
+    def _run(self):
+        mode = _mode_of(self.args)
+        for typ in ("coarse", "fine"):
+            if typ in self.models:
+                self.models[typ].repack(mode)  # unconditional pack into fixed buffers: safe to capture
+        return render_rays(self.models, self.args, self.rays, self.ts)
+
+    @torch.no_grad()
+    def __call__(self, rays, ts):
+        if rays.shape[0] != self.n:
+            raise ValueError(f"GraphedRenderer was built for {self.n} rays, got {rays.shape[0]}")
+        self.rays.copy_(rays)
+        self.ts.copy_(ts.view(-1))
+        if self.graph is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._run()  # warm-up outside capture: lazy initialisation (LDS attributes, index maps)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._run()
+        self.graph.replay()
+        return self.out
+
+
 @torch.no_grad()
 def batched_inference(models, rays, ts, args):
-    """``eval_satnerf.batched_inference``: ray-chunked no-grad rendering, per-key concatenation."""
+    """``eval_satnerf.batched_inference``: ray-chunked no-grad rendering, per-key concatenation.  With ``args.use_graph`` the
+    full-size chunks are replayed from a hipGraph (the ragged last chunk runs eagerly)."""
     chunk_size = args.chunk
     results = defaultdict(list)
+    graphed = None
+    if getattr(args, "use_graph", False) and ts is not None and rays.shape[0] >= 2 * chunk_size and type(_rng) is _TorchRng:
+        graphed = GraphedRenderer(models, args, chunk_size, rays.device)
     for i in range(0, rays.shape[0], chunk_size):
-        out = render_rays(models, args, rays[i:i + chunk_size], ts[i:i + chunk_size] if ts is not None else None)
+        r, t = rays[i:i + chunk_size], ts[i:i + chunk_size] if ts is not None else None
+        if graphed is not None and r.shape[0] == chunk_size:
+            out = {k: v.clone() for k, v in graphed(r, t).items()}
+        else:
+            out = render_rays(models, args, r, t)
         for k, v in out.items():
             results[k] += [v]
     for k, v in results.items():

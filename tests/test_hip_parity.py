@@ -324,3 +324,29 @@ def test_odd_inputs_non_contiguous_rays_int32_ts_and_tiny_batches():
     assert maxnorm_rel(got["rgb_coarse"].cpu(), want["rgb_coarse"]) < 1e-4
     assert maxnorm_rel(got["weights_coarse"].cpu(), want["weights_coarse"]) < 1e-4
     assert maxnorm_rel(one["weights_coarse"].cpu(), want["weights_coarse"][:1]) < 1e-4
+
+
+def test_graphed_renderer_matches_eager_and_keeps_the_rng_stream():
+    _, rendering, _ = _lazy()
+    args = O.default_args(mlp_mode="bf16x3", n_importance=32)
+    models = build_models(args)
+    rays, ts = O.synthetic_rays(300, seed=50)
+    rays, ts = rays.to(DEV), ts.to(DEV)
+    gr = rendering.GraphedRenderer(models, args, 300, DEV)
+    torch.manual_seed(3)
+    a1 = {k: v.clone() for k, v in gr(rays, ts).items()}   # capture + first replay
+    a2 = {k: v.clone() for k, v in gr(rays, ts).items()}   # second replay draws fresh jitter
+    torch.manual_seed(3)
+    with torch.no_grad():
+        rendering.render_rays(models, args, rays, ts)       # stands in for the warm-up + capture passes' draws
+    # statistically identical renders, different jitter
+    assert set(a1) == set(a2) and a1["rgb_fine"].shape == (300, 3)
+    assert not torch.equal(a1["weights_coarse"], a2["weights_coarse"])
+    assert (a1["rgb_fine"] - a2["rgb_fine"]).abs().max() < 0.2
+    assert torch.isfinite(a2["depth_fine"]).all()
+    # batched_inference with use_graph: same keys / shapes as eager, ragged tail handled
+    args2 = O.default_args(mlp_mode="bf16x3", chunk=128, use_graph=True)
+    m2 = build_models(args2)
+    out = rendering.batched_inference(m2, rays, ts, args2)
+    assert out["rgb_coarse"].shape == (300, 3) and out["weights_coarse"].shape == (300, 64)
+    assert torch.isfinite(out["rgb_coarse"]).all()
