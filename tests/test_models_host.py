@@ -56,3 +56,30 @@ def test_cpu_inputs_fail_loudly_no_fallback():
         load_model(O.default_args(model="s-nerf"))
     with pytest.raises(ValueError):
         load_model(O.default_args(model="bogus"))
+
+
+def test_lightning_style_checkpoint_loads_by_reference_key_layout(tmp_path):
+    """A checkpoint written the way NeRF_pl does (main.py:51-58 attribute prefixes) loads through the eval_satnerf.py:23-93 twins."""
+    import json
+
+    from satnerf_amd import checkpoint
+
+    args = O.default_args(n_importance=64)
+    coarse, fine = O.procedural_satnerf_params(256, 4, seed=1), O.procedural_satnerf_params(256, 4, seed=2)
+    emb = O.procedural_uniform((30, 4), 1.0, 7)
+    sd = {f"nerf_coarse.{k}": v for k, v in coarse.items()}
+    sd.update({f"nerf_fine.{k}": v for k, v in fine.items()})
+    sd["embedding_t.weight"] = emb
+    run = "run0"
+    (tmp_path / "logs" / run).mkdir(parents=True)
+    (tmp_path / "ckpts" / run).mkdir(parents=True)
+    torch.save({"state_dict": sd, "epoch": 3}, tmp_path / "ckpts" / run / "epoch=3.ckpt")
+    json.dump(vars(args), open(tmp_path / "logs" / run / "opts.json", "w"))
+    models, loaded_args = checkpoint.load_nerf(run, str(tmp_path / "logs"), str(tmp_path / "ckpts"), 3, device="cpu")
+    assert loaded_args.n_importance == 64 and set(models) == {"coarse", "fine", "t"}
+    assert all(torch.equal(models["coarse"].state_dict()[k], v) for k, v in coarse.items())
+    assert all(torch.equal(models["fine"].state_dict()[k], v) for k, v in fine.items())  # NOT the coarse weights / random init
+    assert torch.equal(models["t"].weight.data, emb)
+    assert models["coarse"].flat_params().numel() == 662537  # still one flat buffer after load
+    with pytest.raises(FileNotFoundError):
+        checkpoint.load_nerf(run, str(tmp_path / "logs"), str(tmp_path / "ckpts"), 9, device="cpu")
