@@ -47,9 +47,10 @@ int64_t sr_dpre_elems_per_tile(int feat);        /* bf16 elements of pre-activat
 int sr_pack_stream(const float* src, const int32_t* idx, const float* scale, int64_t n,
                    uint16_t* out_hi, uint16_t* out_lo, void* stream);
 /* the same plus an fp32 gather (sr_gather_scale_f32) in ONE launch: the forward stream, the backward stream (concatenated
- * maps) and the fc_net.0 table are refreshed together after every optimizer step */
+ * maps) and the fc_net.0 table are refreshed together after every optimizer step; `tick` (may be NULL) is a 1-float device
+ * counter the launch increments: the step count sr_adam_step_graph reads later in the same captured graph */
 int sr_pack_all(const float* src, const int32_t* idx, const float* scale, int64_t n, uint16_t* out_hi, uint16_t* out_lo,
-                const int32_t* f32_idx, const float* f32_scale, int64_t n_f32, float* out_f32, void* stream);
+                const int32_t* f32_idx, const float* f32_scale, int64_t n_f32, float* out_f32, float* tick, void* stream);
 
 /* out[i] = src[idx[i]] * scale[i] in fp32 (idx < 0 -> 0): builds the fc_net.0 table `l0` of sr_satnerf_mlp_fwd */
 int sr_gather_scale_f32(const float* src, const int32_t* idx, const float* scale, int64_t n, float* out, void* stream);
@@ -126,6 +127,16 @@ int sr_render_loss(const float* z_vals, const float* sigma, const float* noise, 
                    const float* sun_v, const float* beta, const float* sky, const float* target, int64_t n_rays, int n_samples,
                    float beta_min, float* loss_parts, float* rgb, float* d_sigma, float* d_albedo, float* d_sun_v, float* g_beta,
                    float* d_sky, void* stream);
+
+/* sr_grad_tail = sr_unpack_grads + sr_sky_bwd + sr_embedding_bwd as three block ranges of one launch (training fast path);
+ * sr_adam_step_graph = sr_adam_step with the 1-based step count read from the device (state[0], advanced by sr_pack_all's
+ * `tick` earlier in the same step) so the launch can be replayed from a hipGraph. */
+int sr_grad_tail(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, int n_split,
+                 int64_t split_stride, float* grad, int accumulate, const float* sun, int sun_stride, int64_t n_rays, int hidden,
+                 const float* w1, const float* b1, const float* w2, const float* sky, const float* d_sky, float* g_w1, float* g_b1,
+                 float* g_w2, float* g_b2, const float* d_t, const int64_t* ts, int n_samples, int tau, float* g_emb, void* stream);
+int sr_adam_step_graph(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                       float beta2, float eps, float grad_scale, float* state, int zero_grad, void* stream);
 
 /* ---- training-step kernels --------------------------------------------------------------
  * sr_satnerf_loss: metrics.SatNerfLoss for the coarse model (metrics.py:21-25,56-73): value = sum of

@@ -41,7 +41,10 @@ SIGNATURES = {
     "sr_satnerf_loss": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "sr_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i64, _i, _vp]),
     "sr_gather_batch": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
-    "sr_pack_all": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "sr_grad_tail": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
+                          _vp, _vp]),
+    "sr_adam_step_graph": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp, _i, _vp]),
+    "sr_pack_all": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "sr_gather_scale_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "sr_ray_sample_fwd": (_i, [_vp, _i, _vp, _i64, _i, _vp, _vp]),
     "sr_sky_fwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

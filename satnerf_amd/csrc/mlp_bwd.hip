@@ -98,7 +98,11 @@ __global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
     if (g == 2) issue_chunk<1, BS::np(2)>(stream, nullptr, BS::offset_pieces(2) * 1024L, ring + 2 * kBSlot, wave, lane);
   }
 
+#ifdef SR_BWD_REVERSE
+  const long tile = (long)(gridDim.x - 1 - blockIdx.x) * 8 + wave;  // newest activations first: whatever the Infinity Cache kept
+#else
   const long tile = (long)blockIdx.x * 8 + wave;
+#endif
   const long pt = tile * 32 + pl;
   const bool valid = pt < prm.n_points;
   const uint4* acts = prm.acts + tile * AK * 64 + lane;   // + fragment * 64

@@ -425,9 +425,10 @@ __global__ void __launch_bounds__(256) pack_stream_kernel(const float* __restric
 
 __global__ void __launch_bounds__(256) pack_all_kernel(const float* __restrict__ src, const int* __restrict__ idx, const float* __restrict__ scale,
                                                       long n, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, const int* __restrict__ fidx,
-                                                      const float* __restrict__ fscale, long nf, float* __restrict__ fout) {
+                                                      const float* __restrict__ fscale, long nf, float* __restrict__ fout, float* tick) {
 #pragma clang fp contract(off)
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (tick != nullptr && t == 0) tick[0] += 1.0f;  // optimizer step counter of the captured training step
   const long i = t * 2;
   if (i < n) {
     const int i0 = idx[i], i1 = idx[i + 1];
@@ -459,14 +460,13 @@ __global__ void __launch_bounds__(256) gather_scale_kernel(const float* __restri
 // Block = 32 rays; thread (k = hidden unit, half) reduces 16 rays in registers, the two halves meet in LDS, then one atomicAdd
 // per parameter per block (1024 rays -> 32 blocks x 899 atomics).
 constexpr int kSkyRays = 32;
-__global__ void __launch_bounds__(256) sky_bwd_kernel(const float* __restrict__ sun, int sun_stride, long n, int hidden,
-                                                     const float* __restrict__ w1, const float* __restrict__ b1,
-                                                     const float* __restrict__ w2, const float* __restrict__ sky,
-                                                     const float* __restrict__ d_sky, float* __restrict__ g_w1, float* __restrict__ g_b1,
-                                                     float* __restrict__ g_w2, float* __restrict__ g_b2) {
+__device__ __forceinline__ void sky_bwd_body(int block, const float* __restrict__ sun, int sun_stride, long n, int hidden,
+                                             const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                             const float* __restrict__ sky, const float* __restrict__ d_sky, float* __restrict__ g_w1,
+                                             float* __restrict__ g_b1, float* __restrict__ g_w2, float* __restrict__ g_b2) {
   __shared__ float ray[kSkyRays][8];   // sun xyz, dz0..2 per ray
   __shared__ float comb[128][7];
-  const long r0 = (long)blockIdx.x * kSkyRays;
+  const long r0 = (long)block * kSkyRays;
   const int nr = (int)((r0 + kSkyRays < n ? r0 + kSkyRays : n) - r0);
   if (threadIdx.x < nr) {
     const long r = r0 + threadIdx.x;
@@ -514,11 +514,19 @@ __global__ void __launch_bounds__(256) sky_bwd_kernel(const float* __restrict__ 
   }
 }
 
+__global__ void __launch_bounds__(256) sky_bwd_kernel(const float* __restrict__ sun, int sun_stride, long n, int hidden,
+                                                     const float* __restrict__ w1, const float* __restrict__ b1,
+                                                     const float* __restrict__ w2, const float* __restrict__ sky,
+                                                     const float* __restrict__ d_sky, float* __restrict__ g_w1, float* __restrict__ g_b1,
+                                                     float* __restrict__ g_w2, float* __restrict__ g_b2) {
+  sky_bwd_body(blockIdx.x, sun, sun_stride, n, hidden, w1, b1, w2, sky, d_sky, g_w1, g_b1, g_w2, g_b2);
+}
+
 // ---- embedding gradient (nn.Embedding backward, rendering.py:100): d_emb[ts[r]] += sum_j d_t[r, j, :] ----------------------
-__global__ void __launch_bounds__(256) embedding_bwd_kernel(const float* __restrict__ d_t, const long long* __restrict__ ts, long n_rays,
-                                                           int S, int tau, float* __restrict__ g_emb) {
+__device__ __forceinline__ void embedding_bwd_body(int block, const float* __restrict__ d_t, const long long* __restrict__ ts, long n_rays,
+                                                   int S, int tau, float* __restrict__ g_emb) {
   const int lane = threadIdx.x & 63;
-  const long r = (long)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
+  const long r = (long)block * kRaysPerBlock + (threadIdx.x >> 6);
   if (r >= n_rays) return;
   const long row = ts[r];
   const float* src = d_t + r * (long)S * tau;  // the ray's S x tau block is contiguous
@@ -535,6 +543,41 @@ __global__ void __launch_bounds__(256) embedding_bwd_kernel(const float* __restr
       if (lane == 0) atomicAdd(&g_emb[row * tau + i], a);
     }
   }
+}
+
+__global__ void __launch_bounds__(256) embedding_bwd_kernel(const float* __restrict__ d_t, const long long* __restrict__ ts, long n_rays,
+                                                           int S, int tau, float* __restrict__ g_emb) {
+  embedding_bwd_body(blockIdx.x, d_t, ts, n_rays, S, tau, g_emb);
+}
+
+// gradient tail of the training fast path: [split-K reduction + scatter of the MLP weight gradients | sky-head gradients |
+// embedding gradients] as three block ranges of ONE launch (each sub-kernel is 8-15 us at a ~5 us launch floor)
+struct GradTailParams {
+  const float* partial; const int* gidx; const float* gscale; long n_params; int n_split; long split_stride; float* grad; int accumulate;
+  const float* sun; int sun_stride; long n_rays; int hidden; const float* w1; const float* b1; const float* w2; const float* sky;
+  const float* d_sky; float* g_w1; float* g_b1; float* g_w2; float* g_b2;
+  const float* d_t; const long long* ts; int S; int tau; float* g_emb;
+  int blocks_unpack, blocks_sky;
+};
+__global__ void __launch_bounds__(256) grad_tail_kernel(const GradTailParams q) {
+  int b = blockIdx.x;
+  if (b < q.blocks_unpack) {
+    const long i = (long)b * 256 + threadIdx.x;
+    if (i >= q.n_params) return;
+    const int k = q.gidx[i];
+    if (k < 0) return;
+    float s = 0.f;
+    for (int sp = 0; sp < q.n_split; ++sp) s += q.partial[sp * q.split_stride + k];
+    s *= q.gscale[i];
+    q.grad[i] = q.accumulate ? q.grad[i] + s : s;
+    return;
+  }
+  b -= q.blocks_unpack;
+  if (b < q.blocks_sky) {
+    sky_bwd_body(b, q.sun, q.sun_stride, q.n_rays, q.hidden, q.w1, q.b1, q.w2, q.sky, q.d_sky, q.g_w1, q.g_b1, q.g_w2, q.g_b2);
+    return;
+  }
+  embedding_bwd_body(b - q.blocks_sky, q.d_t, q.ts, q.n_rays, q.S, q.tau, q.g_emb);
 }
 
 }  // namespace sr
@@ -640,13 +683,13 @@ extern "C" int sr_pack_stream(const float* src, const int32_t* idx, const float*
 }
 
 extern "C" int sr_pack_all(const float* src, const int32_t* idx, const float* scale, int64_t n, uint16_t* out_hi, uint16_t* out_lo,
-                           const int32_t* f32_idx, const float* f32_scale, int64_t n_f32, float* out_f32, void* stream) {
+                           const int32_t* f32_idx, const float* f32_scale, int64_t n_f32, float* out_f32, float* tick, void* stream) {
   SR_REQUIRE(src && idx && scale && out_hi && f32_idx && f32_scale && out_f32, "sr_pack_all: null pointer");
   SR_REQUIRE(n % 2 == 0, "sr_pack_all: n must be even");
   const long threads = n / 2 + n_f32;
   if (threads <= 0) return 0;
   hipLaunchKernelGGL(pack_all_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, idx, scale, (long)n, out_hi,
-                     out_lo, f32_idx, f32_scale, (long)n_f32, out_f32);
+                     out_lo, f32_idx, f32_scale, (long)n_f32, out_f32, tick);
   return check_launch("pack_all_kernel");
 }
 
@@ -664,6 +707,25 @@ extern "C" int sr_sky_bwd(const float* sun, int sun_stride, int64_t n, int hidde
   hipLaunchKernelGGL(sky_bwd_kernel, dim3((unsigned)((n + kSkyRays - 1) / kSkyRays)), dim3(256), 0, (hipStream_t)stream, sun, sun_stride, (long)n, hidden, w1,
                      b1, w2, sky, d_sky, g_w1, g_b1, g_w2, g_b2);
   return check_launch("sky_bwd_kernel");
+}
+
+extern "C" int sr_grad_tail(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, int n_split, int64_t split_stride,
+                            float* grad, int accumulate, const float* sun, int sun_stride, int64_t n_rays, int hidden, const float* w1,
+                            const float* b1, const float* w2, const float* sky, const float* d_sky, float* g_w1, float* g_b1, float* g_w2,
+                            float* g_b2, const float* d_t, const int64_t* ts, int n_samples, int tau, float* g_emb, void* stream) {
+  SR_REQUIRE(partial && gidx && gscale && grad && sun && w1 && b1 && w2 && sky && d_sky && g_w1 && g_b1 && g_w2 && g_b2 && d_t && ts && g_emb,
+             "sr_grad_tail: null pointer");
+  if (n_rays <= 0) return 0;
+  GradTailParams q;
+  q.partial = partial, q.gidx = gidx, q.gscale = gscale, q.n_params = n_params, q.n_split = n_split, q.split_stride = split_stride, q.grad = grad;
+  q.accumulate = accumulate, q.sun = sun, q.sun_stride = sun_stride, q.n_rays = n_rays, q.hidden = hidden, q.w1 = w1, q.b1 = b1, q.w2 = w2;
+  q.sky = sky, q.d_sky = d_sky, q.g_w1 = g_w1, q.g_b1 = g_b1, q.g_w2 = g_w2, q.g_b2 = g_b2, q.d_t = d_t, q.ts = (const long long*)ts;
+  q.S = n_samples, q.tau = tau, q.g_emb = g_emb;
+  q.blocks_unpack = (int)((n_params + 255) / 256);
+  q.blocks_sky = (int)((n_rays + kSkyRays - 1) / kSkyRays);
+  const int blocks_emb = (int)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
+  hipLaunchKernelGGL(grad_tail_kernel, dim3(q.blocks_unpack + q.blocks_sky + blocks_emb), dim3(256), 0, (hipStream_t)stream, q);
+  return check_launch("grad_tail_kernel");
 }
 
 extern "C" int sr_embedding_bwd(const float* d_t, const int64_t* ts, int64_t n_rays, int n_samples, int tau, float* g_emb, void* stream) {

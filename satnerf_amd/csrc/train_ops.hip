@@ -188,6 +188,27 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float*
   if (zero_grad) g[i] = 0.f;
 }
 
+// Graph-capturable Adam: the 1-based step count is read from state[0]; it is advanced earlier in the same graph by the step's
+// first kernel (sr_pack_all's `tick`), so no kernel both reads and writes it.  Bias corrections once per block.
+__global__ void __launch_bounds__(256) adam_graph_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                        float grad_scale, const float* __restrict__ state, int zero_grad) {
+  __shared__ float bc[2];
+  if (threadIdx.x == 0) {
+    const float t = state[0];
+    bc[0] = 1.0f - powf(b1, t), bc[1] = 1.0f - powf(b2, t);
+  }
+  __syncthreads();
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * grad_scale;
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi, v[i] = vi;
+  p[i] -= (lr / bc[0]) * (mi / (sqrtf(vi) / sqrtf(bc[1]) + eps));
+  if (zero_grad) g[i] = 0.f;
+}
+
 }  // namespace sr
 
 using namespace sr;
@@ -234,4 +255,13 @@ extern "C" int sr_adam_step(float* params, float* grads, float* exp_avg, float* 
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
                      (long)n, lr, beta1, beta2, eps, grad_scale, bc1, bc2, zero_grad);
   return check_launch("adam_kernel");
+}
+
+extern "C" int sr_adam_step_graph(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                                  float eps, float grad_scale, float* state, int zero_grad, void* stream) {
+  SR_REQUIRE(params && grads && exp_avg && exp_avg_sq && state, "sr_adam_step_graph: null pointer");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(adam_graph_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
+                     (long)n, lr, beta1, beta2, eps, grad_scale, state, zero_grad);
+  return check_launch("adam_graph_kernel");
 }

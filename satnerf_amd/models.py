@@ -152,7 +152,7 @@ class SatNeRF(_FlatParamModule):
         self._pack_cache[key] = (version, flat.data_ptr(), (hi, lo, l0))
         return hi, lo, l0
 
-    def repack(self, mode, backward=False):
+    def repack(self, mode, backward=False, tick=None):
         """Re-run the pack kernel unconditionally INTO THE SAME device buffers (hipGraph-capturable: fixed addresses, no
         version checks on the captured path) and refresh the caches ``packed`` / ``packed_backward`` consult.  With
         ``backward`` the forward stream, the transposed stream and the fc_net.0 table are produced by ONE launch."""
@@ -176,7 +176,7 @@ class SatNeRF(_FlatParamModule):
             else:
                 bufs["idx"], bufs["scale"] = maps["idx"], maps["scale"]
             self._pack_cache[ck] = bufs
-        ops.pack_all(flat, bufs["idx"], bufs["scale"], bufs["hi"], bufs["lo"], maps["l0_idx"], maps["l0_scale"], bufs["l0"])
+        ops.pack_all(flat, bufs["idx"], bufs["scale"], bufs["hi"], bufs["lo"], maps["l0_idx"], maps["l0_scale"], bufs["l0"], tick)
         version = self.weights_version()
         self._pack_cache[key] = (version, flat.data_ptr(), (bufs["hi"][:n_f], bufs["lo"][:n_f] if key else None, bufs["l0"]))
         if backward:

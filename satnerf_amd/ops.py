@@ -255,9 +255,9 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=5e-4, betas=(0.9, 0.9
               params.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), float(grad_scale), int(step), int(zero_grad), _stream())
 
 
-def pack_all(flat, idx, scale, hi, lo, f32_idx, f32_scale, f32_out):
+def pack_all(flat, idx, scale, hi, lo, f32_idx, f32_scale, f32_out, tick=None):
     _lib.call("sr_pack_all", _p(_chk(flat, "flat")), _p(_chk(idx, "idx", torch.int32)), _p(_chk(scale, "scale")), idx.numel(), _p(hi), _p(lo),
-              _p(_chk(f32_idx, "f32_idx", torch.int32)), _p(_chk(f32_scale, "f32_scale")), f32_idx.numel(), _p(f32_out), _stream())
+              _p(_chk(f32_idx, "f32_idx", torch.int32)), _p(_chk(f32_scale, "f32_scale")), f32_idx.numel(), _p(f32_out), _p(tick), _stream())
 
 
 def ray_setup(rays, u, n_samples, w1, b1, w2, b2):
@@ -295,3 +295,33 @@ def gather_batch(rays, rgbs, ts, idx, out=None):
     _lib.call("sr_gather_batch", _p(_chk(rays, "rays")), _p(_chk(rgbs, "rgbs")), _p(_chk(ts, "ts", torch.int64)), _p(_chk(idx, "idx", torch.int64)), n,
               _p(_chk(out[0], "out_rays")), _p(_chk(out[2], "out_rgbs")), _p(_chk(out[1], "out_ts", torch.int64)), _stream())
     return out
+
+
+def wgrad_partials(feat, tau, n_points, dpre, acts, blocks, n_split):
+    """Weight-gradient GEMMs only: returns the (n_split, n_blocks, block) fp32 partial buffer (reduce with grad_tail / unpack)."""
+    n_blocks = blocks.shape[0]
+    block_floats = 256 * 256 + 256 * 32
+    partial = torch.empty(n_split * n_blocks * block_floats, dtype=torch.float32, device=dpre.device)
+    ev = kernel_timer.span("wgrad") if kernel_timer is not None else None
+    if ev:
+        ev[0].record()
+    _lib.call("sr_satnerf_wgrad", feat, tau, n_points, _p(dpre), _p(acts), _p(_chk(blocks, "blocks", torch.int32)), n_blocks, n_split, _p(partial),
+              _stream())
+    if ev:
+        ev[1].record()
+    return partial, n_blocks * block_floats
+
+
+def grad_tail(partial, split_stride, n_split, gidx, gscale, grad_flat, sun, w1, b1, w2, sky_rgb, d_sky, g_w1, g_b1, g_w2, g_b2, d_t, ts, n_rays,
+              n_samples, tau, g_emb):
+    sun, stride = _rows(sun, "sun", 3)
+    _lib.call("sr_grad_tail", _p(partial), _p(_chk(gidx, "gidx", torch.int32)), _p(_chk(gscale, "gscale")), gidx.numel(), n_split, split_stride,
+              _p(_chk(grad_flat, "grad_flat")), 1, _p(sun), stride, n_rays, w1.shape[0], _p(w1), _p(b1), _p(w2), _p(_chk(sky_rgb, "sky")),
+              _p(_chk(d_sky, "d_sky")), _p(g_w1), _p(g_b1), _p(g_w2), _p(g_b2), _p(_chk(d_t, "d_t")), _p(_chk(ts, "ts", torch.int64)), n_samples, tau,
+              _p(_chk(g_emb, "g_emb")), _stream())
+
+
+def adam_step_graph(params, grads, exp_avg, exp_avg_sq, state, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, zero_grad=True):
+    _lib.call("sr_adam_step_graph", _p(_chk(params, "params")), _p(_chk(grads, "grads")), _p(_chk(exp_avg, "exp_avg")), _p(_chk(exp_avg_sq, "exp_avg_sq")),
+              params.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), float(grad_scale), _p(_chk(state, "state")), int(zero_grad),
+              _stream())

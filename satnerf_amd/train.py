@@ -108,6 +108,8 @@ class Trainer:
         p = self.state.params
         self.exp_avg, self.exp_avg_sq = torch.zeros_like(p), torch.zeros_like(p)
         self.n_steps = 0
+        self.adam_state = torch.zeros(1, dtype=torch.float32, device=p.device)  # optimizer step count for the in-graph Adam
+        self._adam_in_graph = False
         self.loss_fn = loss_fn
         self.direct = (loss_fn is None and p.is_cuda and getattr(args, "sc_lambda", 0.0) == 0 and args.n_importance == 0
                        and args.model == "sat-nerf")
@@ -126,7 +128,7 @@ class Trainer:
         n, s = rays.shape[0], args.n_samples
         mode = _mode_of(args)
         feat, tau = model.feat, model.t_embedding_dims
-        model.repack(mode, backward=True)
+        model.repack(mode, backward=True, tick=self.adam_state if (self.world == 1 and self._adam_in_graph) else None)
         hi, lo, l0 = model.packed(mode)
         bstream, maps = model.packed_backward()
         sk = model.sky_color
@@ -150,14 +152,18 @@ class Trainer:
         dpre, d_t = ops.satnerf_mlp_bwd(feat, tau, n * s, bstream, acts, albedo, sigma, sun_v, beta, d_albedo, d_sigma, d_sun, g_beta.view(-1))
         from .autograd import _N_SPLIT
 
-        ops.satnerf_wgrad(feat, tau, n * s, dpre, acts, maps["blocks"], _N_SPLIT, maps["gidx"], maps["gscale"], model.flat_grads(), accumulate=True)
-        ops.sky_bwd(rays[:, 8:11], sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sky, d_sky, sk[0].weight.grad, sk[0].bias.grad,
-                    sk[2].weight.grad, sk[2].bias.grad)
-        ops.embedding_bwd(d_t, ts, n, s, tau, emb.weight.grad)
+        partial, stride = ops.wgrad_partials(feat, tau, n * s, dpre, acts, maps["blocks"], _N_SPLIT)
+        ops.grad_tail(partial, stride, _N_SPLIT, maps["gidx"], maps["gscale"], model.flat_grads(), rays[:, 8:11], sk[0].weight.data, sk[0].bias.data,
+                      sk[2].weight.data, sky, d_sky, sk[0].weight.grad, sk[0].bias.grad, sk[2].weight.grad, sk[2].bias.grad, d_t, ts, n, s, tau,
+                      emb.weight.grad)
+        if self.world == 1 and self._adam_in_graph:  # no all-reduce to wait for: the update rides in the same graph
+            ops.adam_step_graph(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.adam_state, lr=self.lr, zero_grad=True)
         return loss
 
     def _capture(self, rays, ts, rgbs):
         self._static = (rays.clone(), ts.clone(), rgbs.clone())
+        self._adam_in_graph = self.world == 1
+        snapshot = (self.state.params.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.adam_state.clone())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up on a side stream: lazy inits (LDS attributes, maps) happen outside capture
@@ -166,6 +172,8 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.state.zero_grad()
+        if self._adam_in_graph:  # the warm-up passes stepped the optimizer: roll them back
+            self.state.params.copy_(snapshot[0]), self.exp_avg.copy_(snapshot[1]), self.exp_avg_sq.copy_(snapshot[2]), self.adam_state.copy_(snapshot[3])
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._static_loss = self._forward_backward(*self._static)
@@ -194,8 +202,13 @@ class Trainer:
             if self.world > 1:
                 dist.all_reduce(self.state.grads, op=dist.ReduceOp.SUM)
             self.n_steps += 1
-            ops.adam_step(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.n_steps, lr=self.lr,
-                          grad_scale=1.0 / self.world, zero_grad=True)
+            in_graph = self._adam_in_graph and self._graph is not None and self.use_graph and float(self.args.noise_std) == 0.0
+            if not in_graph:
+                if self._adam_in_graph:  # eager direct step after a capture: _forward_backward already stepped Adam
+                    pass
+                else:
+                    ops.adam_step(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.n_steps, lr=self.lr,
+                                  grad_scale=1.0 / self.world, zero_grad=True)
             loss = _LazyLoss(loss)
         else:
             from .rendering import render_rays
