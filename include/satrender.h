@@ -55,10 +55,11 @@ int sr_pack_all(const float* src, const int32_t* idx, const float* scale, int64_
 /* out[i] = src[idx[i]] * scale[i] in fp32 (idx < 0 -> 0): builds the fc_net.0 table `l0` of sr_satnerf_mlp_fwd */
 int sr_gather_scale_f32(const float* src, const int32_t* idx, const float* scale, int64_t n, float* out, void* stream);
 
-/* grad[e] (+)= gscale[e] * sum_s partial[s*split_stride + gidx[e]]  (gidx < 0: left untouched) -- reduces the split-K
- * slices of sr_satnerf_wgrad and scatters into the flat parameter-gradient buffer (inverse of sr_pack_stream's gather) */
-int sr_unpack_grads(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, int n_split,
-                    int64_t split_stride, float* grad, int accumulate, void* stream);
+/* grad[e] (+)= gscale[e] * (sum over the split-K slices of partial element gidx[e])  (gidx < 0: left untouched) -- reduces
+ * the slices of sr_satnerf_wgrad (`blocks` = its planned job table, device) and scatters into the flat parameter-gradient
+ * buffer (inverse of sr_pack_stream's gather) */
+int sr_unpack_grads(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, const int32_t* blocks,
+                    float* grad, int accumulate, void* stream);
 
 /* ---- stratified sampling: rendering.py:62-78 -----------------------------------------------------
  * rays (N, ray_stride>=8) with near at column 6, far at column 7; u (N,S) in [0,1) -> z_vals (N,S). */
@@ -102,13 +103,18 @@ int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, int mode, con
  * those outputs (g_* may be NULL = 0); bwd_stream = packed transposed weights (sr_pack_stream with
  * packing.backward_maps).  Outputs: dpre (sr_dpre_elems_per_tile(feat) * ceil(P/32) bf16) and d_t (P,tau) fp32, the
  * gradient w.r.t. each point's embedding vector (NULL to skip).
- * sr_satnerf_wgrad: weight-gradient GEMMs dpre x acts over all points, 128x128 blocks listed in `blocks`
- * (n_blocks x 8 int32) x n_split point slices -> partial (n_split, n_blocks, 128, 128) fp32; reduce with sr_unpack_grads. */
+ * sr_satnerf_wgrad: weight-gradient GEMMs dpre x acts over all points.  `blocks` (n_blocks x 8 int32, device) lists the job
+ * blocks (row_frag0, n_row, col_frag0, n_col, col_kind, n_slices, first_slice, -; packing.backward_maps); every block is
+ * cut into n_slices contiguous ranges of 32-point tiles (split-K), one workgroup each, writing slice s to
+ * partial + s * (256*256 + 256*32) floats; reduce with sr_unpack_grads.
+ * sr_wgrad_plan (host, no GPU work): fills n_slices / first_slice of a HOST copy of the table for n_points points and at
+ * most n_wg workgroups (n_wg <= 0: the current device's CU count); *n_slices = total slices. */
 int sr_satnerf_mlp_bwd(int feat, int tau, int64_t n_points, const uint16_t* bwd_stream, const uint16_t* acts,
                        const float* albedo, const float* sigma, const float* sun_v, const float* beta, const float* g_albedo,
                        const float* g_sigma, const float* g_sun_v, const float* g_beta, uint16_t* dpre, float* d_t, void* stream);
+int sr_wgrad_plan(int32_t* blocks, int n_blocks, int64_t n_points, int n_wg, int* n_slices);
 int sr_satnerf_wgrad(int feat, int tau, int64_t n_points, const uint16_t* dpre, const uint16_t* acts, const int32_t* blocks,
-                     int n_blocks, int n_split, float* partial, void* stream);
+                     int n_blocks, int n_slices, float* partial, void* stream);
 
 /* parameter gradients of the sky head (atomicAdd into g_*; zero them first) and of the embedding table
  * g_emb[ts[r]] += sum_j d_t[r*S + j] (nn.Embedding backward, rendering.py:100) */
@@ -131,8 +137,8 @@ int sr_render_loss(const float* z_vals, const float* sigma, const float* noise, 
 /* sr_grad_tail = sr_unpack_grads + sr_sky_bwd + sr_embedding_bwd as three block ranges of one launch (training fast path);
  * sr_adam_step_graph = sr_adam_step with the 1-based step count read from the device (state[0], advanced by sr_pack_all's
  * `tick` earlier in the same step) so the launch can be replayed from a hipGraph. */
-int sr_grad_tail(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, int n_split,
-                 int64_t split_stride, float* grad, int accumulate, const float* sun, int sun_stride, int64_t n_rays, int hidden,
+int sr_grad_tail(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, const int32_t* blocks,
+                 float* grad, int accumulate, const float* sun, int sun_stride, int64_t n_rays, int hidden,
                  const float* w1, const float* b1, const float* w2, const float* sky, const float* d_sky, float* g_w1, float* g_b1,
                  float* g_w2, float* g_b2, const float* d_t, const int64_t* ts, int n_samples, int tau, float* g_emb, void* stream);
 int sr_adam_step_graph(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

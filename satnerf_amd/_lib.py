@@ -31,7 +31,8 @@ SIGNATURES = {
     "sr_act_elems_per_tile": (_i64, [_i]),
     "sr_pack_stream": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "sr_dpre_elems_per_tile": (_i64, [_i]),
-    "sr_unpack_grads": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _vp, _i, _vp]),
+    "sr_unpack_grads": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _vp]),
+    "sr_wgrad_plan": (_i, [_vp, _i, _i64, _i, _vp]),
     "sr_satnerf_mlp_bwd": (_i, [_i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sr_satnerf_wgrad": (_i, [_i, _i, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "sr_sky_bwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -41,7 +42,7 @@ SIGNATURES = {
     "sr_satnerf_loss": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "sr_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i64, _i, _vp]),
     "sr_gather_batch": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
-    "sr_grad_tail": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
+    "sr_grad_tail": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
                           _vp, _vp]),
     "sr_adam_step_graph": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp, _i, _vp]),
     "sr_pack_all": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),

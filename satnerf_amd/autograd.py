@@ -16,7 +16,6 @@ import torch
 
 from . import ops
 
-_N_SPLIT = 15  # split-K slices of the weight-gradient GEMMs (17 blocks x 15 = 255 sixteen-wave workgroups on 256 CUs)
 
 
 class _InferenceFn(torch.autograd.Function):
@@ -61,7 +60,7 @@ class _InferenceFn(torch.autograd.Function):
         dpre, d_t = ops.satnerf_mlp_bwd(feat, tau, n * s, bstream, acts, albedo, sigma, sun_v, beta, d_albedo.contiguous(), d_sigma, d_sun.contiguous(),
                                         g_beta_pt)
         grad_flat = model.flat_grads()
-        ops.satnerf_wgrad(feat, tau, n * s, dpre, acts, maps["blocks"], _N_SPLIT, maps["gidx"], maps["gscale"], grad_flat, accumulate=True)
+        ops.satnerf_wgrad(feat, tau, n * s, dpre, acts, maps["blocks"], maps["gidx"], maps["gscale"], grad_flat, accumulate=True)
         sk = model.sky_color
         ops.sky_bwd(rays[:, 8:11], sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sky, d_sky.contiguous(), sk[0].weight.grad, sk[0].bias.grad,
                     sk[2].weight.grad, sk[2].bias.grad)

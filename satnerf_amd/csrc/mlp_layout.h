@@ -125,4 +125,22 @@ struct BwdStream {
   static constexpr long total_pieces() { return offset_pieces(NCH); }
 };
 
+// ---- weight-gradient partial blocks (wgrad.hip) -------------------------------------------------------------------
+// One split-K slice of one job block: 256 x 256 main block + 256 x 32 aux columns, fp32.  Job table row (8 int32):
+// row_frag0, n_row, col_frag0, n_col, col_kind, n_slices, first_slice, - ; slices of all blocks are numbered consecutively
+// (sr_wgrad_plan) and slice s lives at partial + s * kWgBlockFloats.
+constexpr int kWgBlockFloats = 256 * 256 + 256 * 32;
+
+#ifdef __HIPCC__
+// sum over the slices of element k = block * kWgBlockFloats + offset
+__device__ __forceinline__ float wg_sum_slices(const float* __restrict__ partial, const int* __restrict__ blocks, int k) {
+  const int b = k / kWgBlockFloats, w = k - b * kWgBlockFloats;
+  const int ns = blocks[8 * b + 5];
+  const float* p = partial + (long)blocks[8 * b + 6] * kWgBlockFloats + w;
+  float s = 0.f;
+  for (int sp = 0; sp < ns; ++sp) s += p[(long)sp * kWgBlockFloats];
+  return s;
+}
+#endif
+
 }  // namespace sr

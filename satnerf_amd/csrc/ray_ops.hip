@@ -6,6 +6,7 @@
 #include <stdarg.h>
 
 #include "common.h"
+#include "mlp_layout.h"
 
 namespace sr {
 
@@ -553,7 +554,7 @@ __global__ void __launch_bounds__(256) embedding_bwd_kernel(const float* __restr
 // gradient tail of the training fast path: [split-K reduction + scatter of the MLP weight gradients | sky-head gradients |
 // embedding gradients] as three block ranges of ONE launch (each sub-kernel is 8-15 us at a ~5 us launch floor)
 struct GradTailParams {
-  const float* partial; const int* gidx; const float* gscale; long n_params; int n_split; long split_stride; float* grad; int accumulate;
+  const float* partial; const int* gidx; const float* gscale; long n_params; const int* blocks; float* grad; int accumulate;
   const float* sun; int sun_stride; long n_rays; int hidden; const float* w1; const float* b1; const float* w2; const float* sky;
   const float* d_sky; float* g_w1; float* g_b1; float* g_w2; float* g_b2;
   const float* d_t; const long long* ts; int S; int tau; float* g_emb;
@@ -566,9 +567,7 @@ __global__ void __launch_bounds__(256) grad_tail_kernel(const GradTailParams q) 
     if (i >= q.n_params) return;
     const int k = q.gidx[i];
     if (k < 0) return;
-    float s = 0.f;
-    for (int sp = 0; sp < q.n_split; ++sp) s += q.partial[sp * q.split_stride + k];
-    s *= q.gscale[i];
+    const float s = wg_sum_slices(q.partial, q.blocks, k) * q.gscale[i];
     q.grad[i] = q.accumulate ? q.grad[i] + s : s;
     return;
   }
@@ -709,15 +708,15 @@ extern "C" int sr_sky_bwd(const float* sun, int sun_stride, int64_t n, int hidde
   return check_launch("sky_bwd_kernel");
 }
 
-extern "C" int sr_grad_tail(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, int n_split, int64_t split_stride,
+extern "C" int sr_grad_tail(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, const int32_t* blocks,
                             float* grad, int accumulate, const float* sun, int sun_stride, int64_t n_rays, int hidden, const float* w1,
                             const float* b1, const float* w2, const float* sky, const float* d_sky, float* g_w1, float* g_b1, float* g_w2,
                             float* g_b2, const float* d_t, const int64_t* ts, int n_samples, int tau, float* g_emb, void* stream) {
-  SR_REQUIRE(partial && gidx && gscale && grad && sun && w1 && b1 && w2 && sky && d_sky && g_w1 && g_b1 && g_w2 && g_b2 && d_t && ts && g_emb,
+  SR_REQUIRE(partial && gidx && gscale && blocks && grad && sun && w1 && b1 && w2 && sky && d_sky && g_w1 && g_b1 && g_w2 && g_b2 && d_t && ts && g_emb,
              "sr_grad_tail: null pointer");
   if (n_rays <= 0) return 0;
   GradTailParams q;
-  q.partial = partial, q.gidx = gidx, q.gscale = gscale, q.n_params = n_params, q.n_split = n_split, q.split_stride = split_stride, q.grad = grad;
+  q.partial = partial, q.gidx = gidx, q.gscale = gscale, q.n_params = n_params, q.blocks = blocks, q.grad = grad;
   q.accumulate = accumulate, q.sun = sun, q.sun_stride = sun_stride, q.n_rays = n_rays, q.hidden = hidden, q.w1 = w1, q.b1 = b1, q.w2 = w2;
   q.sky = sky, q.d_sky = d_sky, q.g_w1 = g_w1, q.g_b1 = g_b1, q.g_w2 = g_w2, q.g_b2 = g_b2, q.d_t = d_t, q.ts = (const long long*)ts;
   q.S = n_samples, q.tau = tau, q.g_emb = g_emb;

@@ -209,20 +209,46 @@ def satnerf_mlp_bwd(feat, tau, n_points, bwd_stream, acts, albedo, sigma, sun_v,
     return dpre, d_t
 
 
-def satnerf_wgrad(feat, tau, n_points, dpre, acts, blocks, n_split, gidx, gscale, grad_flat, accumulate=True):
-    """Weight-gradient GEMMs + split-K reduction + scatter into the flat gradient buffer."""
-    n_blocks = blocks.shape[0]
-    block_floats = 256 * 256 + 256 * 32  # csrc/wgrad.hip kBlockFloats
-    partial = torch.empty(n_split * n_blocks * block_floats, dtype=torch.float32, device=dpre.device)
+_plan_cache = {}
+
+
+def wgrad_plan(blocks, n_points, n_wg=0):
+    """Split-K plan of the weight-gradient job table for ``n_points`` points (sr_wgrad_plan): returns (planned device table,
+    total slices).  Cached per (table, n_points): the copy to the device must not happen inside a graph capture."""
+    key = (blocks.data_ptr(), int(n_points), int(n_wg), str(blocks.device))
+    ent = _plan_cache.get(key)
+    if ent is None:
+        import ctypes
+
+        host = _chk(blocks, "blocks", torch.int32).cpu().contiguous().clone()
+        n_slices = ctypes.c_int(0)
+        with torch.cuda.device(blocks.device):
+            _lib.call("sr_wgrad_plan", host.data_ptr(), host.shape[0], n_points, n_wg, ctypes.addressof(n_slices))
+        if len(_plan_cache) > 64:
+            _plan_cache.clear()
+        ent = _plan_cache[key] = (host.to(blocks.device), int(n_slices.value), blocks)  # keeps `blocks` alive: data_ptr stays unique
+    return ent[0], ent[1]
+
+
+def wgrad_partials(feat, tau, n_points, dpre, acts, blocks):
+    """Weight-gradient GEMMs only: returns (fp32 split-K slices, planned job table); reduce with grad_tail / unpack_grads."""
+    plan, n_slices = wgrad_plan(blocks, n_points)
+    block_floats = 256 * 256 + 256 * 32  # csrc/mlp_layout.h kWgBlockFloats
+    partial = torch.empty(n_slices * block_floats, dtype=torch.float32, device=dpre.device)
     ev = kernel_timer.span("wgrad") if kernel_timer is not None else None
     if ev:
         ev[0].record()
-    _lib.call("sr_satnerf_wgrad", feat, tau, n_points, _p(dpre), _p(acts), _p(_chk(blocks, "blocks", torch.int32)), n_blocks, n_split, _p(partial),
-              _stream())
+    _lib.call("sr_satnerf_wgrad", feat, tau, n_points, _p(dpre), _p(acts), _p(plan), plan.shape[0], n_slices, _p(partial), _stream())
     if ev:
         ev[1].record()
-    _lib.call("sr_unpack_grads", _p(partial), _p(_chk(gidx, "gidx", torch.int32)), _p(_chk(gscale, "gscale")), gidx.numel(), n_split,
-              n_blocks * block_floats, _p(_chk(grad_flat, "grad_flat")), int(accumulate), _stream())
+    return partial, plan
+
+
+def satnerf_wgrad(feat, tau, n_points, dpre, acts, blocks, gidx, gscale, grad_flat, accumulate=True):
+    """Weight-gradient GEMMs + split-K reduction + scatter into the flat gradient buffer."""
+    partial, plan = wgrad_partials(feat, tau, n_points, dpre, acts, blocks)
+    _lib.call("sr_unpack_grads", _p(partial), _p(_chk(gidx, "gidx", torch.int32)), _p(_chk(gscale, "gscale")), gidx.numel(), _p(plan),
+              _p(_chk(grad_flat, "grad_flat")), int(accumulate), _stream())
 
 
 def sky_bwd(sun, w1, b1, w2, sky_rgb, d_sky, g_w1, g_b1, g_w2, g_b2):
@@ -297,25 +323,10 @@ def gather_batch(rays, rgbs, ts, idx, out=None):
     return out
 
 
-def wgrad_partials(feat, tau, n_points, dpre, acts, blocks, n_split):
-    """Weight-gradient GEMMs only: returns the (n_split, n_blocks, block) fp32 partial buffer (reduce with grad_tail / unpack)."""
-    n_blocks = blocks.shape[0]
-    block_floats = 256 * 256 + 256 * 32
-    partial = torch.empty(n_split * n_blocks * block_floats, dtype=torch.float32, device=dpre.device)
-    ev = kernel_timer.span("wgrad") if kernel_timer is not None else None
-    if ev:
-        ev[0].record()
-    _lib.call("sr_satnerf_wgrad", feat, tau, n_points, _p(dpre), _p(acts), _p(_chk(blocks, "blocks", torch.int32)), n_blocks, n_split, _p(partial),
-              _stream())
-    if ev:
-        ev[1].record()
-    return partial, n_blocks * block_floats
-
-
-def grad_tail(partial, split_stride, n_split, gidx, gscale, grad_flat, sun, w1, b1, w2, sky_rgb, d_sky, g_w1, g_b1, g_w2, g_b2, d_t, ts, n_rays,
+def grad_tail(partial, plan, gidx, gscale, grad_flat, sun, w1, b1, w2, sky_rgb, d_sky, g_w1, g_b1, g_w2, g_b2, d_t, ts, n_rays,
               n_samples, tau, g_emb):
     sun, stride = _rows(sun, "sun", 3)
-    _lib.call("sr_grad_tail", _p(partial), _p(_chk(gidx, "gidx", torch.int32)), _p(_chk(gscale, "gscale")), gidx.numel(), n_split, split_stride,
+    _lib.call("sr_grad_tail", _p(partial), _p(_chk(gidx, "gidx", torch.int32)), _p(_chk(gscale, "gscale")), gidx.numel(), _p(plan),
               _p(_chk(grad_flat, "grad_flat")), 1, _p(sun), stride, n_rays, w1.shape[0], _p(w1), _p(b1), _p(w2), _p(_chk(sky_rgb, "sky")),
               _p(_chk(d_sky, "d_sky")), _p(g_w1), _p(g_b1), _p(g_w2), _p(g_b2), _p(_chk(d_t, "d_t")), _p(_chk(ts, "ts", torch.int64)), n_samples, tau,
               _p(_chk(g_emb, "g_emb")), _stream())

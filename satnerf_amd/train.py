@@ -150,10 +150,8 @@ class Trainer:
                                                                weights, transp, g_rgb, None, g_w, None)
             self.last_rgb = rgb
         dpre, d_t = ops.satnerf_mlp_bwd(feat, tau, n * s, bstream, acts, albedo, sigma, sun_v, beta, d_albedo, d_sigma, d_sun, g_beta.view(-1))
-        from .autograd import _N_SPLIT
-
-        partial, stride = ops.wgrad_partials(feat, tau, n * s, dpre, acts, maps["blocks"], _N_SPLIT)
-        ops.grad_tail(partial, stride, _N_SPLIT, maps["gidx"], maps["gscale"], model.flat_grads(), rays[:, 8:11], sk[0].weight.data, sk[0].bias.data,
+        partial, plan = ops.wgrad_partials(feat, tau, n * s, dpre, acts, maps["blocks"])
+        ops.grad_tail(partial, plan, maps["gidx"], maps["gscale"], model.flat_grads(), rays[:, 8:11], sk[0].weight.data, sk[0].bias.data,
                       sk[2].weight.data, sky, d_sky, sk[0].weight.grad, sk[0].bias.grad, sk[2].weight.grad, sk[2].bias.grad, d_t, ts, n, s, tau,
                       emb.weight.grad)
         if self.world == 1 and self._adam_in_graph:  # no all-reduce to wait for: the update rides in the same graph

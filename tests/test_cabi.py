@@ -52,3 +52,30 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.SatRenderError):
         _lib.lib()
+
+
+def test_wgrad_plan_host_only(handle):
+    """sr_wgrad_plan is host logic: slices >= 1 per block, <= tiles, consecutive numbering, at most n_wg in total."""
+    import ctypes
+
+    import numpy as np
+
+    from satnerf_amd import packing
+
+    blocks0 = packing.backward_maps(256, 4)["blocks"]
+    for n_points, n_wg in ((65536, 256), (96 * 64, 256), (32, 256), (65536, 64), (1 << 20, 256), (65536, 3)):
+        blocks = np.ascontiguousarray(blocks0.copy())
+        n = ctypes.c_int(0)
+        rc = handle.sr_wgrad_plan(blocks.ctypes.data_as(ctypes.c_void_p), blocks.shape[0], n_points, n_wg, ctypes.byref(n))
+        assert rc == 0
+        ns, first = blocks[:, 5], blocks[:, 6]
+        tiles = (n_points + 31) // 32
+        assert (ns >= 1).all() and (ns <= tiles).all()
+        assert (first == np.concatenate([[0], np.cumsum(ns)[:-1]])).all() and n.value == ns.sum()
+        assert n.value <= max(n_wg, blocks.shape[0])
+        if tiles >= 1024 and n_wg >= 2 * blocks.shape[0]:
+            assert n.value > n_wg - blocks.shape[0]  # the launch fills the chip
+        assert (blocks[:, :5] == blocks0[:, :5]).all()
+    bad = np.ascontiguousarray(blocks0.copy())
+    bad[0, 1] = 17
+    assert handle.sr_wgrad_plan(bad.ctypes.data_as(ctypes.c_void_p), bad.shape[0], 65536, 256, ctypes.byref(n)) != 0
