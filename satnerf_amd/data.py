@@ -50,3 +50,15 @@ class RayBank:
         if out is not None and out[0].shape[0] != idx.numel():
             out = None
         return ops.gather_batch(self.rays, self.rgbs, self.ts, idx, out)
+
+
+class DepthBank(RayBank):
+    """Ray bank of the depth-supervision dataset (``SatelliteDataset_depth``, datasets/satellite_depth.py: items
+    ``{"rays": (11,), "depths": (2,) = [target depth, weight], "ts": (1,)}``; main.py:103-109 gives it its own shuffled
+    DataLoader).  Batches come out as (rays (B,11), ts (B,), depths (B,3)) with a zero third column -- the gather kernel
+    moves 3-float targets -- which is what ``Trainer.step(..., depth=...)`` takes."""
+
+    def __init__(self, rays, depths, ts, batch_size, **kw):
+        if depths.dim() != 2 or depths.shape[1] != 2:
+            raise ValueError("depths must be (N, 2) = [target depth, weight]")
+        super().__init__(rays, torch.cat([depths.float(), torch.zeros_like(depths[:, :1], dtype=torch.float32)], 1), ts, batch_size, **kw)

@@ -28,6 +28,15 @@ def satnerf_loss(res, target, lambda_sc=0.0, beta_min=0.05):
     return loss
 
 
+def depth_loss(res, targets, weights=1.0, lambda_ds=1.0):
+    """``metrics.DepthLoss`` (metrics.py:75-92): lambda_ds/3 * mean(weights * (depth - target)^2), coarse [+ fine]."""
+    lam = lambda_ds / 3.0
+    loss = lam * torch.mean(weights * (res["depth_coarse"] - targets) ** 2)
+    if "depth_fine" in res:
+        loss = loss + lam * torch.mean(weights * (res["depth_fine"] - targets) ** 2)
+    return loss
+
+
 class FlatState:
     """One flat parameter buffer and one flat gradient buffer shared by a list of modules (models + embedding)."""
 
@@ -93,7 +102,9 @@ class _LazyLoss:
 
 
 class Trainer:
-    """One training step = main.py:119-154 for the sat-nerf colour batch.
+    """One training step = main.py:119-154: the sat-nerf colour batch and, when ``args.ds_lambda > 0`` and a depth batch is
+    passed, the depth-supervision batch (main.py:134-141, metrics.DepthLoss) -- both backward passes accumulate into the same
+    flat gradient buffer before the single all-reduce + Adam update.
 
     Fast path (default loss, no solar correction, no fine model): the step calls the HIP kernels directly -- no autograd
     graph, fused loss+gradient kernel, fused Adam over the flat buffer -- and, when ``noise_std == 0``, replays the whole
@@ -119,7 +130,8 @@ class Trainer:
         self.last_loss = None
 
     # ---- forward + loss + backward on the current stream, gradients accumulate into the flat buffer -------------------
-    def _forward_backward(self, rays, ts, rgbs):
+    def _forward_backward(self, rays, ts, rgbs, depth=None):
+        """Colour pass [+ depth-supervision pass] [+ in-graph Adam]; returns the per-block loss partial sums."""
         from . import ops
         from .rendering import _mode_of
 
@@ -144,7 +156,7 @@ class Trainer:
             loss, self.last_rgb, d_sigma, d_albedo, d_sun, g_beta, d_sky = ops.render_loss(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3),
                                                                                            sun_v.view(n, s), beta.view(n, s), sky, rgbs)
         else:
-            weights, transp, depth, rgb = ops.composite(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky)
+            weights, transp, _, rgb = ops.composite(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky)
             loss, g_rgb, g_w, g_beta = ops.satnerf_loss(rgb, weights, beta.view(n, s), rgbs)
             d_sigma, d_albedo, d_sun, d_sky = ops.composite_bwd(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky,
                                                                weights, transp, g_rgb, None, g_w, None)
@@ -154,19 +166,53 @@ class Trainer:
         ops.grad_tail(partial, plan, maps["gidx"], maps["gscale"], model.flat_grads(), rays[:, 8:11], sk[0].weight.data, sk[0].bias.data,
                       sk[2].weight.data, sky, d_sky, sk[0].weight.grad, sk[0].bias.grad, sk[2].weight.grad, sk[2].bias.grad, d_t, ts, n, s, tau,
                       emb.weight.grad)
+        if depth is not None:
+            loss = torch.cat([loss.view(-1), self._depth_pass(*depth, noise_std * 0.9).view(-1)])  # main.py:132 decays the noise first
         if self.world == 1 and self._adam_in_graph:  # no all-reduce to wait for: the update rides in the same graph
             ops.adam_step_graph(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.adam_state, lr=self.lr, zero_grad=True)
         return loss
 
-    def _capture(self, rays, ts, rgbs):
-        self._static = (rays.clone(), ts.clone(), rgbs.clone())
+    def _depth_pass(self, rays, ts, depths, noise_std):
+        """Depth supervision (main.py:134-141): render the depth batch, loss = ds_lambda/3 * mean(w * (depth - target)^2)
+        (metrics.py:75-92); only sigma receives a gradient, so the MLP backward runs with the other head gradients absent."""
+        from . import ops
+        from .rendering import _mode_of
+
+        model, emb, args = self.models["coarse"], self.models["t"], self.args
+        n, s = rays.shape[0], args.n_samples
+        mode = _mode_of(args)
+        feat, tau = model.feat, model.t_embedding_dims
+        hi, lo, l0 = model.packed(mode)
+        bstream, maps = model.packed_backward()
+        sk = model.sky_color
+        u = torch.rand(n, s, device=rays.device)
+        nz = torch.randn(n, s, device=rays.device) if noise_std != 0 else None
+        z, sky = ops.ray_setup(rays, u, s, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data)
+        acts = ops.acts_workspace(n * s, feat, rays.device)
+        albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, 3:6], rays[:, 8:11], z, emb.weight.data, ts, n * s, s, feat, tau, mode,
+                                                     hi, lo, l0, acts=acts)
+        weights, transp, depth, _ = ops.composite(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky)
+        lam = float(args.ds_lambda) / 3.0
+        diff = depth - depths[:, 0]
+        w_diff = diff if getattr(args, "ds_noweights", False) else depths[:, 1] * diff
+        loss = lam * torch.mean(w_diff * diff)
+        g_depth = (2.0 * lam / n) * w_diff
+        d_sigma, _, _, _ = ops.composite_bwd(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky, weights, transp,
+                                             None, g_depth.contiguous(), None, None)
+        dpre, _ = ops.satnerf_mlp_bwd(feat, tau, n * s, bstream, acts, albedo, sigma, sun_v, beta, None, d_sigma, None, None, want_dt=False)
+        ops.satnerf_wgrad(feat, tau, n * s, dpre, acts, maps["blocks"], maps["gidx"], maps["gscale"], model.flat_grads(), accumulate=True)
+        return loss
+
+    def _capture(self, inputs):
+        self._static = tuple(t.clone() for t in inputs)
         self._adam_in_graph = self.world == 1
         snapshot = (self.state.params.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.adam_state.clone())
+        run = lambda: self._forward_backward(*self._static[:3], depth=self._static[3:] or None)  # noqa: E731
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up on a side stream: lazy inits (LDS attributes, maps) happen outside capture
             for _ in range(2):
-                self._forward_backward(*self._static)
+                run()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.state.zero_grad()
@@ -174,39 +220,46 @@ class Trainer:
             self.state.params.copy_(snapshot[0]), self.exp_avg.copy_(snapshot[1]), self.exp_avg_sq.copy_(snapshot[2]), self.adam_state.copy_(snapshot[3])
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            self._static_loss = self._forward_backward(*self._static)
+            self._static_loss = run()
         self.state.zero_grad()  # capture does not execute
 
-    def step_from_bank(self, bank):
-        """One step on the bank's next batch; with a captured graph the batch is gathered straight into its static inputs."""
-        if self.direct and self._graph is not None and self._static[0].shape[0] == bank.batch_size:
-            bank.next_batch(out=self._static)
-            return self.step(*self._static, _inputs_in_place=True)
-        return self.step(*bank.next_batch())
+    def step_from_bank(self, bank, depth_bank=None):
+        """One step on the banks' next batches; with a captured graph the batches are gathered straight into its static inputs."""
+        shapes = (bank.batch_size,) + ((depth_bank.batch_size,) if depth_bank is not None else ())
+        if self.direct and self._graph is not None and tuple(t.shape[0] for t in self._static[::3]) == shapes:
+            bank.next_batch(out=self._static[:3])
+            if depth_bank is not None:
+                depth_bank.next_batch(out=self._static[3:])
+            return self.step(*self._static[:3], depth=self._static[3:] or None, _inputs_in_place=True)
+        return self.step(*bank.next_batch(), depth=None if depth_bank is None else depth_bank.next_batch())
 
-    def step(self, rays, ts, rgbs, _inputs_in_place=False):
+    def step(self, rays, ts, rgbs, depth=None, _inputs_in_place=False):
+        """``depth`` = (rays (M,11), ts (M,), depths (M,2) = [target depth, weight]) of the depth-supervision batch or None
+        (pass None once past ``ds_drop``: main.py:138 stops adding the term)."""
         from . import ops
 
+        if depth is not None and not float(getattr(self.args, "ds_lambda", 0.0)) > 0:
+            raise ValueError("a depth batch was passed but args.ds_lambda is not > 0 (main.py:51)")
         if self.direct:
+            inputs = (rays, ts, rgbs) + (tuple(depth) if depth is not None else ())
             if self.use_graph and float(self.args.noise_std) == 0.0:
-                if self._graph is None or self._static[0].shape != rays.shape:
-                    self._capture(rays, ts, rgbs)
+                if self._graph is None or [t.shape for t in self._static] != [t.shape for t in inputs]:
+                    self._capture(inputs)
                 if not _inputs_in_place:
-                    self._static[0].copy_(rays), self._static[1].copy_(ts), self._static[2].copy_(rgbs)
+                    for dst, src in zip(self._static, inputs):
+                        dst.copy_(src)
                 self._graph.replay()
                 loss = self._static_loss
             else:
-                loss = self._forward_backward(rays.contiguous(), ts.contiguous(), rgbs.contiguous())
+                inputs = tuple(t.contiguous() for t in inputs)
+                loss = self._forward_backward(*inputs[:3], depth=inputs[3:] or None)
             if self.world > 1:
                 dist.all_reduce(self.state.grads, op=dist.ReduceOp.SUM)
             self.n_steps += 1
             in_graph = self._adam_in_graph and self._graph is not None and self.use_graph and float(self.args.noise_std) == 0.0
-            if not in_graph:
-                if self._adam_in_graph:  # eager direct step after a capture: _forward_backward already stepped Adam
-                    pass
-                else:
-                    ops.adam_step(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.n_steps, lr=self.lr,
-                                  grad_scale=1.0 / self.world, zero_grad=True)
+            if not in_graph and not self._adam_in_graph:  # (an eager direct step after a capture already stepped Adam)
+                ops.adam_step(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.n_steps, lr=self.lr,
+                              grad_scale=1.0 / self.world, zero_grad=True)
             loss = _LazyLoss(loss)
         else:
             from .rendering import render_rays
@@ -214,6 +267,16 @@ class Trainer:
             res = render_rays(self.models, self.args, rays, ts)
             loss_fn = self.loss_fn or (lambda r, t: satnerf_loss(r, t, getattr(self.args, "sc_lambda", 0.0)))
             loss = loss_fn(res, rgbs)
+            if depth is not None:
+                d_rays, d_ts, d_depths = depth
+                noise_std = self.args.noise_std
+                self.args.noise_std = noise_std * 0.9  # main.py:132 decays the noise before the depth batch is rendered
+                try:
+                    res_d = render_rays(self.models, self.args, d_rays, d_ts)
+                finally:
+                    self.args.noise_std = noise_std
+                w = 1.0 if getattr(self.args, "ds_noweights", False) else d_depths[:, 1]
+                loss = loss + depth_loss(res_d, d_depths[:, 0], w, float(self.args.ds_lambda))
             loss.backward()
             if self.world > 1:
                 dist.all_reduce(self.state.grads, op=dist.ReduceOp.SUM)

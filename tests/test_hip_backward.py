@@ -220,3 +220,93 @@ def test_trainer_direct_step_with_128_samples_uses_separate_kernels():
     target = torch.rand(256, 3, generator=torch.Generator().manual_seed(4)) * 0.2 + 0.4
     losses = [tr.step(rays.to(DEV), ts.to(DEV), target.to(DEV)).item() for _ in range(20)]
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
+
+
+def _depth_setup(n_color=128, n_depth=96, tau=4):
+    from satnerf_amd.models import load_model
+
+    args = O.default_args(mlp_mode="bf16x3", ds_lambda=1000.0)
+    params = O.procedural_satnerf_params(256, tau, seed=31)
+    embw = O.procedural_uniform((30, tau), 1.0, 32)
+    m = load_model(args)
+    m.load_state_dict(params)
+    emb = torch.nn.Embedding(30, tau)
+    emb.load_state_dict({"weight": embw})
+    rays, ts = O.synthetic_rays(n_color, seed=33)
+    d_rays, d_ts = O.synthetic_rays(n_depth, seed=34)
+    g = torch.Generator().manual_seed(35)
+    target = torch.rand(n_color, 3, generator=g)
+    depths = torch.stack([0.2 + 0.5 * torch.rand(n_depth, generator=g), 0.5 + torch.rand(n_depth, generator=g)], 1)
+    return args, params, embw, {"coarse": m.to(DEV), "t": emb.to(DEV)}, (rays, ts, target), (d_rays, d_ts, depths)
+
+
+def test_depth_supervision_pass_matches_oracle_autograd():
+    """Trainer._depth_pass (main.py:134-141 + metrics.DepthLoss) against autograd through the oracle on the same jitter."""
+    from satnerf_amd.train import Trainer
+
+    args, params, embw, models, _, (d_rays, d_ts, depths) = _depth_setup()
+    tr = Trainer(models, args, use_graph=False)
+    assert tr.direct
+    tr.models["coarse"].repack("bf16x3", backward=True)
+    torch.manual_seed(77)
+    loss = tr._depth_pass(d_rays.to(DEV), d_ts.to(DEV), depths.to(DEV), 0.0)
+    torch.manual_seed(77)
+    u = torch.rand(d_rays.shape[0], args.n_samples, device=DEV).cpu()
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    eo = embw.clone().requires_grad_(True)
+    res = O.render_rays({"coarse": po, "t": eo}, O.default_args(), d_rays, d_ts, O.ReplayRng([u, torch.zeros_like(u)]))
+    lo = O.depth_loss(res, depths[:, 0], depths[:, 1], lambda_ds=1000.0)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 1e-4 * abs(lo.item())
+    sd = dict(models["coarse"].named_parameters())
+    errs = {k: maxnorm_rel(sd[k].grad.cpu(), po[k].grad) for k in po if po[k].grad is not None and po[k].grad.abs().max() > 0}
+    assert "sigma_from_xyz.0.weight" in errs and "fc_net.0.weight" in errs
+    worst = max(errs, key=errs.get)
+    print("depth pass worst", worst, f"{errs[worst]:.1e}")
+    assert errs[worst] < GRAD_TOL, errs
+    # heads that depth does not reach stay at zero gradient
+    for k in ("rgb_from_xyzdir.0.weight", "beta_from_xyz.0.weight", "sun_v_net.0.weight"):
+        assert sd[k].grad.abs().max().item() == 0.0
+
+
+def test_depth_supervised_step_direct_matches_autograd_path_and_graph():
+    from satnerf_amd import rendering
+    from satnerf_amd.data import DepthBank, RayBank
+    from satnerf_amd.train import Trainer, depth_loss, satnerf_loss
+
+    args, params, embw, models, color, depth = _depth_setup()
+    color = tuple(t.to(DEV) for t in color)
+    depth = tuple(t.to(DEV) for t in depth)
+    rays, ts, target = color
+    # direct, eager: colour + depth gradients in one flat buffer
+    tr = Trainer(models, args, use_graph=False)
+    torch.manual_seed(5)
+    parts = tr._forward_backward(rays, ts, target, depth=depth)
+    g_direct = tr.state.grads.clone()
+    # same draws through render_rays + autograd + the torch losses
+    tr.state.zero_grad()
+    torch.manual_seed(5)
+    u1 = torch.rand(rays.shape[0], 64, device=DEV)
+    u2 = torch.rand(depth[0].shape[0], 64, device=DEV)
+    with rendering.replay_rng([u1, torch.zeros_like(u1)]):
+        res = rendering.render_rays(models, args, rays, ts)
+    with rendering.replay_rng([u2, torch.zeros_like(u2)]):
+        res_d = rendering.render_rays(models, args, depth[0], depth[1])
+    la = satnerf_loss(res, target) + depth_loss(res_d, depth[2][:, 0], depth[2][:, 1], 1000.0)
+    la.backward()
+    assert abs(parts.sum().item() - la.item()) < 1e-4 * abs(la.item())
+    assert maxnorm_rel(g_direct.cpu(), tr.state.grads.cpu()) < 1e-4
+    tr.state.zero_grad()
+    # a depth batch without ds_lambda is refused
+    with pytest.raises(ValueError):
+        Trainer(models, O.default_args(mlp_mode="bf16x3"), use_graph=False).step(rays, ts, target, depth=depth)
+    # graph-captured steps from the banks: the loss (dominated by the depth term) goes down
+    trg = Trainer(models, args, use_graph=True)
+    bank = RayBank(rays, target, ts, batch_size=64, seed=1)
+    dbank = DepthBank(depth[0], depth[2], depth[1], batch_size=48, seed=2)
+    losses = [trg.step_from_bank(bank, dbank).item() for _ in range(25)]
+    assert trg._graph is not None and len(trg._static) == 6
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < 0.7 * losses[0], losses
+    # past ds_drop the caller stops passing the depth batch: a second graph shape is captured transparently
+    l_plain = trg.step_from_bank(bank).item()
+    assert len(trg._static) == 3 and l_plain == l_plain
