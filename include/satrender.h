@@ -144,6 +144,19 @@ int sr_grad_tail(const float* partial, const int32_t* gidx, const float* gscale,
 int sr_adam_step_graph(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                        float beta2, float eps, float grad_scale, float* state, int zero_grad, void* stream);
 
+/* ---- whole-image evaluation -------------------------------------------------------------
+ * sr_composite_image: compositing (models/satnerf.py:52-70) that keeps per ray only what
+ * eval_satnerf.save_nerf_output_to_images writes per pixel (eval_satnerf.py:106-146): image (N,13) =
+ * [rgb(3) clamped, depth, sum w, sum w*sun, sum w*albedo(3), sum w*beta, sum w*sky(3)] -- 52 B/ray instead of 2,576 B.
+ * sr_latlonalt_from_depth: SatelliteDataset.get_latlonalt_from_nerf_prediction (datasets/satellite.py:246-275) with
+ * sat_utils.ecef_to_latlon_custom (sat_utils.py:76-95), in fp64: point = (o + d*depth) * range + center (ECEF, `center` =
+ * 3 HOST doubles) -> lat, lon (degrees), alt (m), each (N,) fp64 on the device. */
+int sr_composite_image(const float* z_vals, const float* sigma, const float* noise, float noise_std, const float* albedo,
+                       const float* sun_v, const float* beta, const float* sky, int64_t n_rays, int n_samples, float* image,
+                       void* stream);
+int sr_latlonalt_from_depth(const float* rays, int ray_stride, const float* depth, int64_t n_rays, const double* center,
+                            double range, double* lat, double* lon, double* alt, void* stream);
+
 /* ---- training-step kernels --------------------------------------------------------------
  * sr_satnerf_loss: metrics.SatNerfLoss for the coarse model (metrics.py:21-25,56-73): value = sum of
  * loss_parts[0 .. ceil(N/4)), and grad_scale * dLoss/d{rgb (N,3), weights (N,S), beta (N,S)} in g_*.

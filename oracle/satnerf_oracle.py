@@ -442,6 +442,37 @@ def depth_loss(res, target, weights=1.0, lambda_ds=1.0):
     return (lambda_ds / 3.0) * torch.mean(weights * (res["depth_coarse"] - target) ** 2)
 
 
+def latlonalt_from_depth(rays, depth, center, scene_range):
+    """``SatelliteDataset.get_latlonalt_from_nerf_prediction`` (``datasets/satellite.py:246-275``) +
+    ``sat_utils.ecef_to_latlon_custom`` (``sat_utils.py:76-95``), numpy fp64: returns (lats, lons, alts)."""
+    import numpy as np
+
+    rays = rays.double().numpy() if torch.is_tensor(rays) else np.asarray(rays, dtype=np.float64)
+    depth = depth.double().numpy() if torch.is_tensor(depth) else np.asarray(depth, dtype=np.float64)
+    xyz = (rays[:, 0:3] + rays[:, 3:6] * depth.reshape(-1, 1)) * float(scene_range)
+    x, y, z = xyz[:, 0] + center[0], xyz[:, 1] + center[1], xyz[:, 2] + center[2]
+    a, e = 6378137.0, 8.1819190842622e-2
+    asq, esq = a ** 2, e ** 2
+    b = np.sqrt(asq * (1 - esq))
+    bsq = b ** 2
+    ep = np.sqrt((asq - bsq) / bsq)
+    p = np.sqrt(x ** 2 + y ** 2)
+    th = np.arctan2(a * z, b * p)
+    lon = np.arctan2(y, x)
+    lat = np.arctan2(z + (ep ** 2) * b * (np.sin(th) ** 3), p - esq * a * (np.cos(th) ** 3))
+    n = a / np.sqrt(1 - esq * (np.sin(lat) ** 2))
+    alt = p / np.cos(lat) - n
+    return lat * 180 / np.pi, lon * 180 / np.pi, alt
+
+
+def image_outputs(res, typ):
+    """The per-pixel reductions of ``eval_satnerf.save_nerf_output_to_images`` (``eval_satnerf.py:106-146``)."""
+    w = res[f"weights_{typ}"].unsqueeze(-1)
+    return {"rgb": res[f"rgb_{typ}"], "depth": res[f"depth_{typ}"], "acc": res[f"weights_{typ}"].sum(-1),
+            "sun": torch.sum(w * res[f"sun_{typ}"], -2), "albedo": torch.sum(w * res[f"albedo_{typ}"], -2),
+            "beta": torch.sum(w * res[f"beta_{typ}"], -2), "sky": torch.sum(w * res[f"sky_{typ}"], -2)}
+
+
 def default_args(**kw):
     """The ``args`` attributes the hot path reads, with BASELINE config-2 defaults."""
     a = dict(model="sat-nerf", n_samples=64, n_importance=0, chunk=5120, noise_std=0.0, sc_lambda=0.0,

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SATRENDER_LIB") or os.path.join(_HERE, "csrc", "libsa
 MODE_BF16 = 1
 MODE_BF16X3 = 3
 
-_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_vp, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 
 
 class MlpInputs(C.Structure):
@@ -32,6 +32,8 @@ SIGNATURES = {
     "sr_pack_stream": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "sr_dpre_elems_per_tile": (_i64, [_i]),
     "sr_unpack_grads": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _vp]),
+    "sr_composite_image": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp]),
+    "sr_latlonalt_from_depth": (_i, [_vp, _i, _vp, _i64, _vp, _d, _vp, _vp, _vp, _vp]),
     "sr_wgrad_plan": (_i, [_vp, _i, _i64, _i, _vp]),
     "sr_satnerf_mlp_bwd": (_i, [_i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sr_satnerf_wgrad": (_i, [_i, _i, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp]),

@@ -222,6 +222,87 @@ __global__ void __launch_bounds__(256) composite_fwd_kernel(const float* __restr
   }
 }
 
+// Whole-image evaluation: the same compositing, keeping per ray only what
+// eval_satnerf.save_nerf_output_to_images writes per pixel (eval_satnerf.py:106-146) instead of 2,576 B of per-sample outputs:
+// image[r] = { rgb(3) clamped, depth, acc = sum w, sum w*sun, sum w*albedo (3), sum w*beta, sum w*sky (3) }.
+constexpr int kImageFloats = 13;
+__global__ void __launch_bounds__(256) composite_image_kernel(const float* __restrict__ z, const float* __restrict__ sigma,
+                                                             const float* __restrict__ noise, float noise_std,
+                                                             const float* __restrict__ albedo, const float* __restrict__ sun_v,
+                                                             const float* __restrict__ beta, const float* __restrict__ sky, long n_rays,
+                                                             int S, float* __restrict__ image) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
+  if (r >= n_rays) return;
+  const long base = r * S;
+  const float k0 = sky[r * 3], k1 = sky[r * 3 + 1], k2 = sky[r * 3 + 2];
+  float carry = 1.f, v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // rgb(3) depth acc sun albedo(3); beta apart
+  float bsum = 0.f;
+  for (int j0 = 0; j0 < S; j0 += 64) {
+    const int j = j0 + lane;
+    const bool on = j < S;
+    float delta, dens, alpha = 0.f;
+    if (on) alpha_of(z, sigma, noise, noise_std, base, j, S, delta, dens, alpha);
+    float f;
+    {
+#pragma clang fp contract(off)
+      f = on ? (1.0f - alpha) + 1e-10f : 1.f;
+    }
+    const float incl = wave_scan_mul(f, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.f;
+    const float T = carry * excl;
+    carry = carry * __shfl(incl, 63, 64);
+    if (on) {
+      const float w = alpha * T;
+      const float* a = albedo + (base + j) * 3;
+      const float sv = sun_v[base + j];
+      v[0] += w * a[0] * (sv + (1.f - sv) * k0), v[1] += w * a[1] * (sv + (1.f - sv) * k1), v[2] += w * a[2] * (sv + (1.f - sv) * k2);
+      v[3] += w * z[base + j], v[4] += w, v[5] += w * sv;
+      v[6] += w * a[0], v[7] += w * a[1], v[8] += w * a[2];
+      bsum += w * beta[base + j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) v[i] = wave_sum(v[i]);
+  bsum = wave_sum(bsum);
+  if (lane == 0) {
+    float* o = image + r * kImageFloats;
+    o[0] = fminf(fmaxf(v[0], 0.f), 1.f), o[1] = fminf(fmaxf(v[1], 0.f), 1.f), o[2] = fminf(fmaxf(v[2], 0.f), 1.f);
+    o[3] = v[3], o[4] = v[4], o[5] = v[5], o[6] = v[6], o[7] = v[7], o[8] = v[8], o[9] = bsum;
+    o[10] = v[4] * k0, o[11] = v[4] * k1, o[12] = v[4] * k2;  // sky is constant along the ray
+  }
+}
+
+// depth -> scene point -> ECEF -> geodetic, in fp64 (datasets/satellite.py:246-275 + sat_utils.py:76-95): one thread per ray.
+__global__ void __launch_bounds__(256) latlonalt_kernel(const float* __restrict__ rays, int ray_stride, const float* __restrict__ depth,
+                                                       long n, double cx, double cy, double cz, double range, double* __restrict__ lat,
+                                                       double* __restrict__ lon, double* __restrict__ alt) {
+#pragma clang fp contract(off)
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* r = rays + i * ray_stride;
+  const double d = (double)depth[i];
+  const double x = ((double)r[0] + (double)r[3] * d) * range + cx;
+  const double y = ((double)r[1] + (double)r[4] * d) * range + cy;
+  const double zz = ((double)r[2] + (double)r[5] * d) * range + cz;
+  const double a = 6378137.0, e = 8.1819190842622e-2;
+  const double asq = a * a, esq = e * e;
+  const double b = sqrt(asq * (1 - esq));
+  const double bsq = b * b;
+  const double ep = sqrt((asq - bsq) / bsq);
+  const double p = sqrt(x * x + y * y);
+  const double th = atan2(a * zz, b * p);
+  const double lo = atan2(y, x);
+  const double sth = sin(th), cth = cos(th);
+  const double la = atan2(zz + (ep * ep) * b * (sth * sth * sth), p - esq * a * (cth * cth * cth));
+  const double sla = sin(la);
+  const double N = a / sqrt(1 - esq * (sla * sla));
+  alt[i] = p / cos(la) - N;
+  lon[i] = lo * 180 / 3.141592653589793;
+  lat[i] = la * 180 / 3.141592653589793;
+}
+
 // Closed-form backward (extended with a transparency gradient):
 //   G_j   = g_w_j + g_depth z_j + sum_c ghat_c albedo_jc irr_jc
 //   dalpha_j = G_j T_j - ( sum_{k>j} (G_k w_k + gT_k T_k) ) / (1 - alpha_j + 1e-10)
@@ -643,6 +724,27 @@ extern "C" int sr_composite_bwd(const float* z_vals, const float* sigma, const f
                      (hipStream_t)stream, z_vals, sigma, noise, noise_std, albedo, sun_v, sky, weights, transparency, (long)n_rays,
                      n_samples, clamp_rgb, g_rgb, g_depth, g_weights, g_transparency, d_sigma, d_albedo, d_sun_v, d_sky);
   return check_launch("composite_bwd_kernel");
+}
+
+extern "C" int sr_composite_image(const float* z_vals, const float* sigma, const float* noise, float noise_std, const float* albedo,
+                                  const float* sun_v, const float* beta, const float* sky, int64_t n_rays, int n_samples, float* image,
+                                  void* stream) {
+  SR_REQUIRE(z_vals && sigma && albedo && sun_v && beta && sky && image, "sr_composite_image: null pointer");
+  SR_REQUIRE(n_samples >= 1, "sr_composite_image: n_samples must be >= 1");
+  if (n_rays <= 0) return 0;
+  hipLaunchKernelGGL(composite_image_kernel, dim3((unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(256), 0, (hipStream_t)stream,
+                     z_vals, sigma, noise, noise_std, albedo, sun_v, beta, sky, (long)n_rays, n_samples, image);
+  return check_launch("composite_image_kernel");
+}
+
+extern "C" int sr_latlonalt_from_depth(const float* rays, int ray_stride, const float* depth, int64_t n_rays, const double* center, double range,
+                                       double* lat, double* lon, double* alt, void* stream) {
+  SR_REQUIRE(rays && depth && center && lat && lon && alt, "sr_latlonalt_from_depth: null pointer");
+  SR_REQUIRE(ray_stride >= 6, "sr_latlonalt_from_depth: ray_stride must be >= 6 (got %d)", ray_stride);
+  if (n_rays <= 0) return 0;
+  hipLaunchKernelGGL(latlonalt_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rays, ray_stride, depth,
+                     (long)n_rays, center[0], center[1], center[2], range, lat, lon, alt);
+  return check_launch("latlonalt_kernel");
 }
 
 extern "C" int sr_sample_pdf_merge(const float* z_coarse, const float* weights_coarse, const float* u, int64_t n_rays, int n_samples,

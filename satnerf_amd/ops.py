@@ -164,6 +164,34 @@ def composite_bwd(z, sigma, noise, noise_std, albedo, sun_v, sky_rgb, weights, t
     return d_sigma, d_albedo, d_sun, d_sky
 
 
+IMAGE_COLUMNS = {"rgb": (0, 3), "depth": (3, 4), "acc": (4, 5), "sun": (5, 6), "albedo": (6, 9), "beta": (9, 10), "sky": (10, 13)}
+
+
+def composite_image(z, sigma, noise, noise_std, albedo, sun_v, beta, sky_rgb):
+    """Compositing reduced to the per-pixel images of eval_satnerf.save_nerf_output_to_images: (N,13), see IMAGE_COLUMNS."""
+    n, s = z.shape
+    image = torch.empty(n, 13, dtype=torch.float32, device=z.device)
+    _lib.call("sr_composite_image", _p(_chk(z, "z")), _p(_chk(sigma, "sigma")), _p(_chk(noise, "noise", allow_none=True)), float(noise_std),
+              _p(_chk(albedo, "albedo")), _p(_chk(sun_v, "sun_v")), _p(_chk(beta, "beta")), _p(_chk(sky_rgb, "sky")), n, s, _p(image), _stream())
+    return image
+
+
+def latlonalt_from_depth(rays, depth, center, scene_range):
+    """(lat, lon, alt) fp64 device tensors of the points rays_o + rays_d * depth, de-normalised by ``scene_range`` / ``center``."""
+    import ctypes
+
+    rays, stride = _rows(rays, "rays", 6)
+    n = rays.shape[0]
+    if depth.reshape(-1).shape[0] != n:
+        raise ValueError("depth must have one value per ray")
+    depth = _chk(depth.reshape(-1).contiguous().float(), "depth")
+    c = (ctypes.c_double * 3)(*[float(v) for v in center])
+    out = torch.empty(3, n, dtype=torch.float64, device=rays.device)
+    _lib.call("sr_latlonalt_from_depth", _p(rays), stride, _p(depth), n, ctypes.addressof(c), float(scene_range), out[0].data_ptr(),
+              out[1].data_ptr(), out[2].data_ptr(), _stream())
+    return out[0], out[1], out[2]
+
+
 def sample_pdf(bins, weights, u, eps=1e-5):
     n, nb = bins.shape
     _chk(bins, "bins"), _chk(weights, "weights"), _chk(u, "u")

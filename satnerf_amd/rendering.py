@@ -98,6 +98,27 @@ def _inference(model, args, rays, z, ts, emb_weight, dir_cols, noise):
             "sun": sun_v.unsqueeze(-1), "sky": sky.unsqueeze(1).expand(n, s, 3), "beta": beta.view(n, s, 1)}
 
 
+def inference(model, args, rays_xyz, z_vals, rays_d=None, sun_d=None, rays_t=None):
+    """``models.satnerf.inference`` (models/satnerf.py:4-79) with its own signature: explicit sample positions ``rays_xyz``
+    (N,S,3), depths ``z_vals`` (N,S), per-ray ``sun_d`` (N,3) and per-ray embedding VECTORS ``rays_t`` (N,tau); ``rays_d`` is
+    accepted and unused, as in the reference's sat-nerf variant.  Compatibility entry point (no grad): ``render_rays`` does
+    not go through it -- it hands rays to the fused kernel, which forms the points itself."""
+    if sun_d is None or rays_t is None:
+        raise TypeError("sat-nerf inference needs sun_d and rays_t (models/satnerf.py:199,204)")
+    if not rays_xyz.is_cuda:
+        raise RuntimeError("rays_xyz must be on the GPU: satnerf_amd has no CPU path")
+    n, s = rays_xyz.shape[0], rays_xyz.shape[1]
+    with torch.no_grad():
+        out = model(rays_xyz.reshape(-1, 3), input_sun_dir=torch.repeat_interleave(sun_d, s, dim=0),
+                    input_t=torch.repeat_interleave(rays_t, s, dim=0), mlp_mode=_mode_of(args)).view(n, s, 9)
+        albedo, sigma, sun_v, sky, beta = out[..., 0:3].contiguous(), out[..., 3].contiguous(), out[..., 4].contiguous(), out[..., 5:8], out[..., 8:9]
+        noise = _rng.randn(n, s, rays_xyz.device)  # models/satnerf.py:58 -- always drawn
+        weights, transparency, depth, rgb = ops.composite(z_vals.contiguous().float(), sigma, noise if args.noise_std != 0 else None, args.noise_std,
+                                                          albedo, sun_v, sky[:, 0].contiguous())
+    return {"rgb": rgb, "depth": depth, "weights": weights, "transparency": transparency, "albedo": albedo, "sun": sun_v.unsqueeze(-1),
+            "sky": sky, "beta": beta}
+
+
 def render_rays(models, args, rays, ts):
     """Render a chunk of rays: stratified sampling -> fused Sat-NeRF MLP -> compositing [-> fine pass]."""
     n_samples, n_importance, variant = args.n_samples, args.n_importance, args.model
@@ -150,6 +171,65 @@ def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
     else:
         u = _rng.rand(n, N_importance, bins.device)
     return ops.sample_pdf(bins.contiguous().float(), weights.contiguous().float(), u, eps)
+
+
+@torch.no_grad()
+def render_image_outputs(models, rays, ts, args):
+    """Whole-image evaluation: ``batched_inference`` + the per-pixel reductions of
+    ``eval_satnerf.save_nerf_output_to_images`` (eval_satnerf.py:106-146) fused into the compositing kernel.
+
+    Returns {"typ", "rgb" (N,3), "depth" (N,), "acc" (N,), "sun" (N,1), "albedo" (N,3), "beta" (N,1), "sky" (N,3)} for the finest
+    model present: rgb/depth are ``results[f"rgb_{typ}"]`` / ``results[f"depth_{typ}"]`` and the others
+    ``sum(weights.unsqueeze(-1) * results[key], -2)`` -- 52 B/ray leave the GPU kernels instead of 2,576 B (x2 with a fine model).
+    Same random-draw order per chunk as ``render_rays``."""
+    if args.model != "sat-nerf":
+        raise NotImplementedError(f"model {args.model}: only sat-nerf is built on the HIP path (SURVEY.md section 8)")
+    if ts is None:
+        raise TypeError("sat-nerf needs per-ray image indices ts")
+    if not rays.is_cuda:
+        raise RuntimeError("rays must be on the GPU: satnerf_amd has no CPU path")
+    n_total, s, n_imp = rays.shape[0], args.n_samples, args.n_importance
+    typ = "fine" if n_imp > 0 else "coarse"
+    emb = (models["t"].weight.data if hasattr(models["t"], "weight") else models["t"]).contiguous().float()
+    image = torch.empty(n_total, 13, dtype=torch.float32, device=rays.device)
+    mode = _mode_of(args)
+    for i in range(0, n_total, args.chunk):
+        r = rays[i:i + args.chunk].contiguous().float()
+        t = ts[i:i + args.chunk].contiguous().long().view(-1)
+        n, dev = r.shape[0], r.device
+        z = ops.ray_sample(r, _rng.rand(n, s, dev), s)
+
+        def heads(model, z_cur):
+            hi, lo, l0 = model.packed(mode)
+            sk = model.sky_color
+            sky = ops.sky(r[:, 8:11], sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data)
+            k = z_cur.shape[1]
+            albedo, sigma, sun_v, beta = ops.satnerf_mlp(r[:, 0:3], r[:, 3:6], r[:, 8:11], z_cur, emb, t, n * k, k, model.feat, model.t_embedding_dims,
+                                                         mode, hi, lo, l0)
+            noise = _rng.randn(n, k, dev)  # models/satnerf.py:58 -- always drawn
+            return (z_cur, sigma.view(n, k), noise if args.noise_std != 0 else None, args.noise_std, albedo.view(n, k, 3), sun_v.view(n, k)), beta.view(n, k), sky
+
+        comp, beta, sky = heads(models["coarse"], z)
+        if args.sc_lambda > 0:
+            _rng.randn(n, s, dev)  # the solar-correction pass of render_rays draws here; its outputs are not image outputs
+        if n_imp > 0:
+            weights = ops.composite(*comp, sky)[0]
+            z_fine = ops.sample_pdf_merge(z, weights, _rng.rand(n, n_imp, dev))
+            comp, beta, sky = heads(models["fine"], z_fine)
+        image[i:i + n] = ops.composite_image(*comp, beta, sky)
+    out = {k: image[:, a:b] for k, (a, b) in ops.IMAGE_COLUMNS.items()}
+    out["depth"], out["acc"] = out["depth"][:, 0], out["acc"][:, 0]
+    out["typ"] = typ
+    return out
+
+
+def latlonalt_from_depth(rays, depth, center, scene_range):
+    """``SatelliteDataset.get_latlonalt_from_nerf_prediction`` (datasets/satellite.py:246-275) on the GPU in fp64:
+    ``center`` (3,) / ``scene_range`` are the dataset's ECEF normalisation (datasets/satellite.py:225-226).  Returns
+    (lats, lons, alts) as fp64 device tensors (the reference returns numpy arrays: ``.cpu().numpy()`` them)."""
+    if not rays.is_cuda:
+        raise RuntimeError("rays must be on the GPU: satnerf_amd has no CPU path")
+    return ops.latlonalt_from_depth(rays.float(), depth.to(rays.device), center, scene_range)
 
 
 class GraphedRenderer:

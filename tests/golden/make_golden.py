@@ -127,10 +127,32 @@ def render_case(name, n_rays, ray_seed, **kw):
     save(name, **arrays)
 
 
+def latlonalt_case():
+    """datasets/satellite.py:246-275 (depth -> ECEF -> lat/lon/alt, fp64) on synthetic rays around a JAX-like scene centre."""
+    from types import SimpleNamespace
+
+    import sat_utils as ref_sat_utils
+    from datasets.satellite import SatelliteDataset
+
+    rays, _ = O.synthetic_rays(200, seed=41)
+    g = torch.Generator().manual_seed(42)
+    depth = 0.05 + 0.9 * torch.rand(200, generator=g)
+    lat0, lon0, alt0 = 30.3165, -81.6633, 12.0
+    cx, cy, cz = ref_sat_utils.latlon_to_ecef_custom(lat0, lon0, alt0)
+    ds = SimpleNamespace(center=np.array([cx, cy, cz], dtype=np.float64), range=np.float64(431.7))
+    lats, lons, alts = SatelliteDataset.get_latlonalt_from_nerf_prediction(ds, rays, depth)
+    save("latlonalt", rays=rays, depth=depth, center=ds.center, range=ds.range, lats=lats, lons=lons, alts=alts)
+
+
 def main():
-    argparse.ArgumentParser(description=__doc__).parse_args()
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("--only", default=None, help="regenerate one fixture group (latlonalt)")
+    only = ap.parse_args().only
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if only == "latlonalt":
+        return latlonalt_case()
+    latlonalt_case()
 
     # full render_rays variants (SURVEY.md 8c)
     render_case("satnerf_coarse", 96, 11)

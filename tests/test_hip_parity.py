@@ -350,3 +350,65 @@ def test_graphed_renderer_matches_eager_and_keeps_the_rng_stream():
     out = rendering.batched_inference(m2, rays, ts, args2)
     assert out["rgb_coarse"].shape == (300, 3) and out["weights_coarse"].shape == (300, 64)
     assert torch.isfinite(out["rgb_coarse"]).all()
+
+
+def test_public_inference_signature_matches_render_rays():
+    """rendering.inference(model, args, rays_xyz, z_vals, rays_d, sun_d, rays_t) -- the reference's models.satnerf.inference
+    signature with explicit points and embedding vectors -- agrees with the fused ray path on the same depths and noise."""
+    from satnerf_amd import ops, rendering
+
+    g = load_golden("satnerf_noise")
+    args = golden_cfg(g)
+    args.mlp_mode = "bf16x3"
+    models = build_models(args)
+    rays, ts = g["rays"].to(DEV), g["ts"].to(DEV)
+    draws = [d.to(DEV) for d in golden_draws(g)]
+    with torch.no_grad(), rendering.replay_rng(draws):
+        want = rendering.render_rays(models, args, rays, ts)
+    z = ops.ray_sample(rays, draws[0], args.n_samples)
+    xyz = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]
+    with rendering.replay_rng([draws[1]]):
+        got = rendering.inference(models["coarse"], args, xyz, z, rays_d=rays[:, 3:6], sun_d=rays[:, 8:11], rays_t=models["t"](ts))
+    assert set(got) == {"rgb", "depth", "weights", "transparency", "albedo", "sun", "sky", "beta"}
+    for k in got:
+        assert got[k].shape == want[f"{k}_coarse"].shape, k
+        assert maxnorm_rel(got[k].cpu(), want[f"{k}_coarse"].cpu()) < 2e-5, k
+    with pytest.raises(TypeError):
+        rendering.inference(models["coarse"], args, xyz, z)
+
+
+@pytest.mark.parametrize("name", ["satnerf_fine", "satnerf_noise", "satnerf_sc", "satnerf_s50_ragged"])
+def test_render_image_outputs_match_reductions_of_the_reference_results(name):
+    """render_image_outputs == save_nerf_output_to_images' reductions (eval_satnerf.py:106-146) of the reference's own
+    render_rays outputs (golden), on the same draws -- coarse and coarse+fine, noise, the solar-correction draw order,
+    and a chunk size that leaves a ragged last chunk."""
+    from satnerf_amd import rendering
+
+    g = load_golden(name)
+    args = golden_cfg(g)
+    args.mlp_mode = "bf16x3"
+    models = build_models(args)
+    typ = "fine" if args.n_importance > 0 else "coarse"
+    want = O.image_outputs({k[4:]: v for k, v in g.items() if k.startswith("out_")}, typ)
+    with rendering.replay_rng([d.to(DEV) for d in golden_draws(g)]):
+        got = rendering.render_image_outputs(models, g["rays"].to(DEV), g["ts"].to(DEV), args)
+    assert got["typ"] == typ
+    for k, v in want.items():
+        assert tuple(got[k].shape) == tuple(v.shape), (k, got[k].shape, v.shape)
+        assert maxnorm_rel(got[k].cpu(), v) < 1e-4, (k, maxnorm_rel(got[k].cpu(), v))
+
+
+def test_latlonalt_kernel_matches_reference_golden():
+    import numpy as np
+
+    from satnerf_amd import rendering
+
+    g = load_golden("latlonalt")
+    lat, lon, alt = rendering.latlonalt_from_depth(g["rays"].to(DEV), g["depth"].to(DEV), np.asarray(g["center"]), float(g["range"]))
+    assert lat.dtype == torch.float64 and lat.shape == (200,)
+    assert np.abs(lat.cpu().numpy() - np.asarray(g["lats"])).max() < 1e-11   # degrees (1e-11 deg ~ 1 micrometre)
+    assert np.abs(lon.cpu().numpy() - np.asarray(g["lons"])).max() < 1e-11
+    assert np.abs(alt.cpu().numpy() - np.asarray(g["alts"])).max() < 1e-7    # metres
+    # a strided view of wider rows and a ragged size
+    lat2, _, alt2 = rendering.latlonalt_from_depth(g["rays"].to(DEV)[:77], g["depth"].to(DEV)[:77], np.asarray(g["center"]), float(g["range"]))
+    assert torch.equal(lat2, lat[:77]) and torch.equal(alt2, alt[:77])

@@ -112,3 +112,14 @@ def test_procedural_params_are_reproducible():
     assert abs(a["fc_net.0.weight"].abs().max().item() - 1 / 3) < 1e-3
     b = O.procedural_satnerf_params(256, 4, seed=1)
     assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_latlonalt_restatement_matches_reference():
+    """depth -> ECEF -> lat/lon/alt (datasets/satellite.py:246-275, sat_utils.py:76-95) against the reference's own output."""
+    import numpy as np
+
+    g = load_golden("latlonalt")
+    lat, lon, alt = O.latlonalt_from_depth(g["rays"], g["depth"], np.asarray(g["center"]), float(g["range"]))
+    assert np.abs(lat - np.asarray(g["lats"])).max() < 1e-12
+    assert np.abs(lon - np.asarray(g["lons"])).max() < 1e-12
+    assert np.abs(alt - np.asarray(g["alts"])).max() < 1e-8  # metres; p/cos(lat) - N cancels ~6.4e6 m
