@@ -144,6 +144,35 @@ int sr_grad_tail(const float* partial, const int32_t* gidx, const float* gscale,
 int sr_adam_step_graph(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                        float beta2, float eps, float grad_scale, float* state, int zero_grad, void* stream);
 
+/* ---- layer-by-layer path for widths the fused kernel does not cover (fc_units != 256; opt.py:50 defaults to 512) ----
+ * One nn.Linear of models/satnerf.py:104-153 per call, its input being the concatenation of one or two sources with the
+ * PREVIOUS layer's activation applied on load (tensors between layers are pre-activations):
+ *   acat[p][f] = act_s(src_s.x[(p / row_div_s) * ld_s + f - off_s]),  act = none | sin(w0 x) (Siren, models/nerf.py:23-33) | relu
+ *   sr_linear_fwd:        y[p][n] = out_act(sum_f acat[p][f] * weight[n][f] + bias[n])          (weight (n_out, K) row-major)
+ *   sr_linear_bwd_input:  d_src[p][k] = (sum_n G[p][n] * weight[n][col0 + k]) * act'(target.x[p][k])   (autograd grad_input)
+ *   sr_linear_bwd_weight: d_weight[n][f] += sum_p G[p][n] * acat[p][f],  d_bias[n] += sum_p G[p][n]     (fp32 atomics)
+ * with G[p][n] = gy[p][n] * out_act'(y[p][n]) (y = the activated forward output; may be NULL for SR_OUT_NONE).
+ * out_act: softplus (sigma, beta), sigmoid (sun), sigmoid*1.002-0.001 (rgb, models/satnerf.py:195-196).
+ * fp32 in / fp32 out, bf16 hi/lo split 3-pass MFMA inside (~1e-6 relative).  sr_points_along: xyz[p] = o + d * z. */
+enum { SR_ACT_NONE = 0, SR_ACT_SIN = 1, SR_ACT_RELU = 2 };
+enum { SR_OUT_NONE = 0, SR_OUT_SOFTPLUS = 1, SR_OUT_SIGMOID = 2, SR_OUT_SIGMOID_RGB = 3 };
+typedef struct sr_linear_src {
+  const float* x; /* (ceil(P / row_div), >= k) fp32 */
+  int ld;         /* row stride in floats */
+  int k;          /* columns taken from this source */
+  int act;        /* SR_ACT_* applied on load */
+  float w0;       /* sin(w0 * x) */
+  int row_div;    /* point p reads row p / row_div: 1 = per point, n_samples = per ray */
+} sr_linear_src;
+int sr_linear_fwd(const sr_linear_src* src, int n_src, const float* weight, const float* bias, int64_t n_points, int n_out,
+                  int out_act, float* y, int ldy, void* stream);
+int sr_linear_bwd_input(const float* gy, int ldg, const float* y, int ldy, int out_act, const float* weight, int k_total, int col0,
+                        const sr_linear_src* target, int64_t n_points, int n_out, float* d_src, int ldd, void* stream);
+int sr_linear_bwd_weight(const float* gy, int ldg, const float* y, int ldy, int out_act, const sr_linear_src* src, int n_src,
+                         int64_t n_points, int n_out, float* d_weight, float* d_bias, void* stream);
+int sr_points_along(const float* rays, int ray_stride, int dir_col, const float* z_vals, int64_t n_rays, int n_samples, float* xyz,
+                    void* stream);
+
 /* ---- whole-image evaluation -------------------------------------------------------------
  * sr_composite_image: compositing (models/satnerf.py:52-70) that keeps per ray only what
  * eval_satnerf.save_nerf_output_to_images writes per pixel (eval_satnerf.py:106-146): image (N,13) =

@@ -22,6 +22,13 @@ class MlpInputs(C.Structure):
                 ("z", _vp), ("temb", _vp), ("ts", _vp), ("n_points", _i64), ("n_samples", _i)]
 
 
+class LinearSrc(C.Structure):
+    _fields_ = [("x", _vp), ("ld", _i), ("k", _i), ("act", _i), ("w0", _f), ("row_div", _i)]
+
+
+ACT_NONE, ACT_SIN, ACT_RELU = 0, 1, 2
+OUT_NONE, OUT_SOFTPLUS, OUT_SIGMOID, OUT_SIGMOID_RGB = 0, 1, 2, 3
+
 # name -> (restype, argtypes); must list every symbol of include/satrender.h (tests/test_cabi.py checks this)
 SIGNATURES = {
     "sr_version": (_i, []),
@@ -34,6 +41,10 @@ SIGNATURES = {
     "sr_unpack_grads": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _vp]),
     "sr_composite_image": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp]),
     "sr_latlonalt_from_depth": (_i, [_vp, _i, _vp, _i64, _vp, _d, _vp, _vp, _vp, _vp]),
+    "sr_linear_fwd": (_i, [C.POINTER(LinearSrc), _i, _vp, _vp, _i64, _i, _i, _vp, _i, _vp]),
+    "sr_linear_bwd_input": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i, C.POINTER(LinearSrc), _i64, _i, _vp, _i, _vp]),
+    "sr_linear_bwd_weight": (_i, [_vp, _i, _vp, _i, _i, C.POINTER(LinearSrc), _i, _i64, _i, _vp, _vp, _vp]),
+    "sr_points_along": (_i, [_vp, _i, _i, _vp, _i64, _i, _vp, _vp]),
     "sr_wgrad_plan": (_i, [_vp, _i, _i64, _i, _vp]),
     "sr_satnerf_mlp_bwd": (_i, [_i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sr_satnerf_wgrad": (_i, [_i, _i, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp]),

@@ -93,6 +93,16 @@ def render_rays_train(models, args, rays, ts, rng):
             model._trigger = torch.zeros(1, device=dev, requires_grad=True)
         noise = rng.randn(n, z_cur.shape[1], dev)
         keys = ("rgb", "depth", "weights", "transparency", "albedo", "sun", "sky", "beta")
+        if not model.fused:  # layer-by-layer path: every Linear is its own autograd Function (satnerf_amd.generic)
+            from .generic import inference_pass
+
+            res = inference_pass(model, args, rays, z_cur, ts, emb_module, (3, 6), noise)
+            if args.sc_lambda > 0:
+                sc = inference_pass(model, args, rays, z_cur, ts, emb_module, (8, 11), rng.randn(n, z_cur.shape[1], dev))
+                res["weights_sc"], res["transparency_sc"], res["sun_sc"] = sc["weights"], sc["transparency"], sc["sun"]
+            for k, v in res.items():
+                result[f"{k}_{typ}"] = v
+            return
         out = _InferenceFn.apply(model._trigger, model, emb_module, args, rays, z_cur, ts, (3, 6), noise, mode)
         res = dict(zip(keys, out))
         res["sky"] = res["sky"].unsqueeze(1).expand(n, z_cur.shape[1], 3)

@@ -109,9 +109,12 @@ class SatNeRF(_FlatParamModule):
         super().__init__()
         if mapping or not siren:
             raise NotImplementedError("Sat-NeRF runs with mapping=False, siren=True (models/__init__.py:12); other variants are not built")
-        if layers != 8 or list(skips) != [4]:
-            raise NotImplementedError("the fused kernel is built for layers=8, skips=[4]")
+        if layers < 1 or feat < 2 or feat % 2:
+            raise ValueError("SatNeRF needs layers >= 1 and an even feat")
         self.layers, self.skips, self.feat = layers, list(skips), feat
+        # the fused register-resident kernel is built for the BASELINE shape; everything else (opt.py's default fc_units=512
+        # included) runs layer by layer through satnerf_amd.generic
+        self.fused = feat == 256 and layers == 8 and list(skips) == [4]
         self.t_embedding_dims = t_embedding_dims
         self.mapping = [nn.Identity(), nn.Identity()]  # plain list, not registered (models/satnerf.py:101)
         self.input_sizes = [3, 0]
@@ -218,8 +221,14 @@ class SatNeRF(_FlatParamModule):
         sun = input_sun_dir.contiguous().float()
         t = input_t.contiguous().float()
         b = xyz.shape[0]
-        hi, lo, l0 = self.packed(mode)
-        albedo, sigma, sun_v, beta = ops.satnerf_mlp(xyz, None, sun, None, t, None, b, 1, self.feat, self.t_embedding_dims, mode, hi, lo, l0)
+        if self.fused:
+            hi, lo, l0 = self.packed(mode)
+            albedo, sigma, sun_v, beta = ops.satnerf_mlp(xyz, None, sun, None, t, None, b, 1, self.feat, self.t_embedding_dims, mode, hi, lo, l0)
+        else:
+            from .generic import satnerf_points
+
+            with torch.no_grad():
+                albedo, sigma, sun_v, beta = satnerf_points(self, xyz, sun, t, 1)
         if sigma_only:
             return sigma.unsqueeze(1)
         sk = self.sky_color

@@ -164,6 +164,65 @@ def composite_bwd(z, sigma, noise, noise_std, albedo, sun_v, sky_rgb, weights, t
     return d_sigma, d_albedo, d_sun, d_sky
 
 
+# ----------------------------------------------------------------------------------- layer-by-layer path (any width)
+ACTS = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "sin": _lib.ACT_SIN, "relu": _lib.ACT_RELU}
+OUT_ACTS = {None: _lib.OUT_NONE, "none": _lib.OUT_NONE, "softplus": _lib.OUT_SOFTPLUS, "sigmoid": _lib.OUT_SIGMOID, "sigmoid_rgb": _lib.OUT_SIGMOID_RGB}
+
+
+def _linear_srcs(srcs, n_points):
+    """srcs: 1 or 2 tuples (x (rows, k) fp32 with unit inner stride, act, w0, row_div) -> ctypes array (keeps the tensors alive)."""
+    if not 1 <= len(srcs) <= 2:
+        raise ValueError("a linear layer takes one or two concatenated sources")
+    arr = (_lib.LinearSrc * len(srcs))()
+    for a, (x, act, w0, row_div) in zip(arr, srcs):
+        x, ld = _rows(x, "linear source", 1)
+        if x.shape[0] * row_div < n_points:
+            raise ValueError(f"linear source has {x.shape[0]} rows x row_div {row_div} < {n_points} points")
+        a.x, a.ld, a.k, a.act, a.w0, a.row_div = x.data_ptr(), ld, x.shape[1], ACTS[act], float(w0), int(row_div)
+    return arr
+
+
+def linear_fwd(srcs, weight, bias, n_points, out_act=None):
+    """One nn.Linear on the concatenation of ``srcs`` (activation applied on load) -> (P, n_out) fp32, see sr_linear_fwd."""
+    arr = _linear_srcs(srcs, n_points)
+    n_out = weight.shape[0]
+    if weight.shape[1] != sum(x.shape[1] for x, *_ in srcs):
+        raise ValueError(f"weight is {tuple(weight.shape)} but the sources have {sum(x.shape[1] for x, *_ in srcs)} columns")
+    y = torch.empty(n_points, n_out, dtype=torch.float32, device=weight.device)
+    _lib.call("sr_linear_fwd", arr, len(srcs), _p(_chk(weight, "weight")), _p(_chk(bias, "bias", allow_none=True)), n_points, n_out, OUT_ACTS[out_act],
+              _p(y), n_out, _stream())
+    return y
+
+
+def linear_bwd_input(gy, y, out_act, weight, col0, target, n_points):
+    """Gradient w.r.t. one source (pre-activation): (P, k); ``target`` = (x, act, w0, row_div) of that source."""
+    arr = _linear_srcs([target], n_points if target[3] == 1 else target[0].shape[0] * target[3])
+    k = target[0].shape[1]
+    d = torch.empty(n_points, k, dtype=torch.float32, device=gy.device)
+    _lib.call("sr_linear_bwd_input", _p(_chk(gy, "gy")), gy.shape[1], _p(_chk(y, "y", allow_none=True)), 0 if y is None else y.shape[1], OUT_ACTS[out_act],
+              _p(_chk(weight, "weight")), weight.shape[1], col0, arr, n_points, weight.shape[0], _p(d), k, _stream())
+    return d
+
+
+def linear_bwd_weight(gy, y, out_act, srcs, n_points, n_out, want_bias=True):
+    arr = _linear_srcs(srcs, n_points)
+    k = sum(x.shape[1] for x, *_ in srcs)
+    dw = torch.zeros(n_out, k, dtype=torch.float32, device=gy.device)
+    db = torch.zeros(n_out, dtype=torch.float32, device=gy.device) if want_bias else None
+    _lib.call("sr_linear_bwd_weight", _p(_chk(gy, "gy")), gy.shape[1], _p(_chk(y, "y", allow_none=True)), 0 if y is None else y.shape[1], OUT_ACTS[out_act],
+              arr, len(srcs), n_points, n_out, _p(dw), _p(db), _stream())
+    return dw, db
+
+
+def points_along(rays, dir_col, z):
+    """xyz (N*S, 3) = rays[:, 0:3] + rays[:, dir_col:dir_col+3] * z (rendering.py:81)."""
+    rays, stride = _rows(rays, "rays", dir_col + 3)
+    n, s = z.shape
+    xyz = torch.empty(n * s, 3, dtype=torch.float32, device=rays.device)
+    _lib.call("sr_points_along", _p(rays), stride, dir_col, _p(_chk(z, "z")), n, s, _p(xyz), _stream())
+    return xyz
+
+
 IMAGE_COLUMNS = {"rgb": (0, 3), "depth": (3, 4), "acc": (4, 5), "sun": (5, 6), "albedo": (6, 9), "beta": (9, 10), "sky": (10, 13)}
 
 

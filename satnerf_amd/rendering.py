@@ -84,6 +84,10 @@ def _mode_of(args):
 def _inference(model, args, rays, z, ts, emb_weight, dir_cols, noise):
     """models/satnerf.inference (models/satnerf.py:4-79) for the points rays[:, 0:3] + rays[:, dir_cols] * z."""
     n, s = z.shape
+    if not model.fused:  # widths / depths outside the fused kernel: layer by layer (satnerf_amd.generic)
+        from .generic import inference_pass
+
+        return inference_pass(model, args, rays, z, ts, emb_weight, dir_cols, noise)
     mode = _mode_of(args)
     hi, lo, l0 = model.packed(mode)
     albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, dir_cols[0]:dir_cols[1]], rays[:, 8:11], z, emb_weight, ts, n * s, s,
@@ -200,12 +204,17 @@ def render_image_outputs(models, rays, ts, args):
         z = ops.ray_sample(r, _rng.rand(n, s, dev), s)
 
         def heads(model, z_cur):
-            hi, lo, l0 = model.packed(mode)
             sk = model.sky_color
             sky = ops.sky(r[:, 8:11], sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data)
             k = z_cur.shape[1]
-            albedo, sigma, sun_v, beta = ops.satnerf_mlp(r[:, 0:3], r[:, 3:6], r[:, 8:11], z_cur, emb, t, n * k, k, model.feat, model.t_embedding_dims,
-                                                         mode, hi, lo, l0)
+            if model.fused:
+                hi, lo, l0 = model.packed(mode)
+                albedo, sigma, sun_v, beta = ops.satnerf_mlp(r[:, 0:3], r[:, 3:6], r[:, 8:11], z_cur, emb, t, n * k, k, model.feat,
+                                                             model.t_embedding_dims, mode, hi, lo, l0)
+            else:
+                from .generic import satnerf_points
+
+                albedo, sigma, sun_v, beta = satnerf_points(model, ops.points_along(r, 3, z_cur), r[:, 8:11], emb[t], k)
             noise = _rng.randn(n, k, dev)  # models/satnerf.py:58 -- always drawn
             return (z_cur, sigma.view(n, k), noise if args.noise_std != 0 else None, args.noise_std, albedo.view(n, k, 3), sun_v.view(n, k)), beta.view(n, k), sky
 

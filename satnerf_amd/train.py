@@ -123,7 +123,7 @@ class Trainer:
         self._adam_in_graph = False
         self.loss_fn = loss_fn
         self.direct = (loss_fn is None and p.is_cuda and getattr(args, "sc_lambda", 0.0) == 0 and args.n_importance == 0
-                       and args.model == "sat-nerf")
+                       and args.model == "sat-nerf" and getattr(models["coarse"], "fused", False))
         self.use_graph = use_graph and self.direct
         self._graph, self._static = None, None
         self.last_rgb = None

@@ -310,3 +310,56 @@ def test_depth_supervised_step_direct_matches_autograd_path_and_graph():
     # past ds_drop the caller stops passing the depth batch: a second graph shape is captured transparently
     l_plain = trg.step_from_bank(bank).item()
     assert len(trg._static) == 3 and l_plain == l_plain
+
+
+@pytest.mark.parametrize("feat,tau,sc", [(512, 16, 0.0), (128, 4, 0.1)])
+def test_layer_path_gradients_vs_oracle_autograd(feat, tau, sc):
+    """Widths outside the fused kernel train through autograd over the per-layer HIP Functions: gradients of every parameter
+    and of the embedding against autograd through the oracle on the same draws (solar-correction pass included)."""
+    from satnerf_amd import rendering
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import satnerf_loss
+
+    args = O.default_args(fc_units=feat, t_embbeding_tau=tau, sc_lambda=sc)
+    params = O.procedural_satnerf_params(feat, tau, seed=51)
+    embw = O.procedural_uniform((30, tau), 1.0, 52)
+    m = load_model(args)
+    m.load_state_dict(params)
+    assert not m.fused
+    emb = torch.nn.Embedding(30, tau)
+    emb.load_state_dict({"weight": embw})
+    models = {"coarse": m.to(DEV), "t": emb.to(DEV)}
+    n = 40
+    rays, ts = O.synthetic_rays(n, seed=53)
+    g = torch.Generator().manual_seed(54)
+    draws = [torch.rand(n, 64, generator=g), torch.randn(n, 64, generator=g)] + ([torch.randn(n, 64, generator=g)] if sc > 0 else [])
+    target = torch.rand(n, 3, generator=g)
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    eo = embw.clone().requires_grad_(True)
+    lo = O.satnerf_loss(O.render_rays({"coarse": po, "t": eo}, args, rays, ts, O.ReplayRng(draws)), target, lambda_sc=sc)
+    lo.backward()
+    with rendering.replay_rng([d.to(DEV) for d in draws]):
+        res = rendering.render_rays(models, args, rays.to(DEV), ts.to(DEV))
+    lh = satnerf_loss(res, target.to(DEV), lambda_sc=sc)
+    lh.backward()
+    assert abs(lh.item() - lo.item()) < 1e-4 * abs(lo.item())
+    sd = dict(models["coarse"].named_parameters())
+    errs = {k: maxnorm_rel(sd[k].grad.cpu(), po[k].grad) for k in po}
+    errs["embedding"] = maxnorm_rel(models["t"].weight.grad.cpu(), eo.grad)
+    worst = max(errs, key=errs.get)
+    print(feat, tau, "worst", worst, f"{errs[worst]:.1e}")
+    assert errs[worst] < 1e-3, errs
+
+
+def test_trainer_runs_width_512_through_autograd_path():
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    torch.manual_seed(0)
+    args = O.default_args(fc_units=512)
+    tr = Trainer({"coarse": load_model(args).to(DEV), "t": torch.nn.Embedding(30, 4).to(DEV)}, args)
+    assert not tr.direct
+    rays, ts = O.synthetic_rays(256, seed=3)
+    target = torch.rand(256, 3, generator=torch.Generator().manual_seed(4)) * 0.2 + 0.4
+    losses = [tr.step(rays.to(DEV), ts.to(DEV), target.to(DEV)).item() for _ in range(12)]
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses

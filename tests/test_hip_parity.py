@@ -223,11 +223,69 @@ def test_large_batch_properties_full_size():
         assert torch.equal(full[k], torch.cat([a[k], b[k]], 0)), k
 
 
-def test_unsupported_width_raises():
-    _, _, load_model = _lazy()
-    m = load_model(O.default_args(fc_units=512)).to(DEV)
-    with pytest.raises(Exception):
-        m(torch.zeros(4, 3, device=DEV), input_sun_dir=torch.zeros(4, 3, device=DEV), input_t=torch.zeros(4, 4, device=DEV))
+def test_width_512_golden_through_the_layer_path():
+    """fc_units=512, tau=16 (opt.py's default width; run_all.sh trains Sat-NeRF with it): the reference's own render_rays
+    output, through the layer-by-layer MFMA path (satnerf_amd.generic, csrc/linear.hip)."""
+    _, rendering, _ = _lazy()
+    g = load_golden("satnerf_feat512")
+    args = golden_cfg(g)
+    assert args.fc_units == 512
+    models = build_models(args)
+    assert not models["coarse"].fused
+    with torch.no_grad(), rendering.replay_rng([d.to(DEV) for d in golden_draws(g)]):
+        res = rendering.render_rays(models, args, g["rays"].to(DEV), g["ts"].to(DEV))
+    expected = {k[4:]: v for k, v in g.items() if k.startswith("out_")}
+    assert set(res) == set(expected)
+    worst = {k: maxnorm_rel(res[k].cpu(), v) for k, v in expected.items()}
+    print({k: f"{e:.1e}" for k, e in worst.items()})
+    assert max(worst.values()) < 1e-4, worst
+    # the reference-signature forward on points agrees too, and the image-output path accepts the model
+    m = models["coarse"]
+    n, s = g["rays"].shape[0], args.n_samples
+    out = m(torch.rand(130, 3, device=DEV), input_sun_dir=torch.rand(130, 3, device=DEV), input_t=torch.rand(130, 16, device=DEV))
+    assert out.shape == (130, 9) and torch.isfinite(out).all()
+    with rendering.replay_rng([d.to(DEV) for d in golden_draws(g)]):
+        img = rendering.render_image_outputs(models, g["rays"].to(DEV), g["ts"].to(DEV), args)
+    assert maxnorm_rel(img["rgb"].cpu(), expected["rgb_coarse"]) < 1e-4 and maxnorm_rel(img["depth"].cpu(), expected["depth_coarse"]) < 1e-4
+
+
+@pytest.mark.parametrize("k1,k2,n_out,act1,out_act,div2", [(3, 0, 64, None, None, 1), (200, 3, 136, "sin", None, 1), (96, 16, 1, None, "softplus", 8),
+                                                           (130, 0, 3, "sin", "sigmoid_rgb", 1), (64, 5, 70, "relu", "sigmoid", 4)])
+def test_linear_layer_kernels_vs_torch(k1, k2, n_out, act1, out_act, div2):
+    """sr_linear_fwd / bwd_input / bwd_weight against fp64 torch on ragged sizes, two sources, per-ray rows, every activation."""
+    ops, _, _ = _lazy()
+    g = torch.Generator().manual_seed(k1 * 7 + n_out)
+    p = 8 * 37  # not a multiple of the 128-row tile
+    x1 = torch.randn(p, k1, generator=g)
+    x2 = torch.randn(p // div2, k2, generator=g) if k2 else None
+    w = torch.randn(n_out, k1 + k2, generator=g) / (k1 + k2) ** 0.5
+    b = torch.randn(n_out, generator=g)
+    gy = torch.randn(p, n_out, generator=g)
+    w0 = 1.7
+
+    def ref(x1, x2, w, b):
+        a = torch.sin(w0 * x1) if act1 == "sin" else torch.relu(x1) if act1 == "relu" else x1
+        if x2 is not None:
+            a = torch.cat([a, torch.repeat_interleave(x2, div2, 0)], 1)
+        pre = a @ w.T + b
+        return {None: pre, "softplus": torch.nn.functional.softplus(pre), "sigmoid": torch.sigmoid(pre),
+                "sigmoid_rgb": torch.sigmoid(pre) * 1.002 - 0.001}[out_act]
+
+    d = [t.double().requires_grad_(True) if t is not None else None for t in (x1, x2, w, b)]
+    y_ref = ref(*d)
+    y_ref.backward(gy.double())
+    dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    srcs = [(dev(x1), act1, w0, 1)] + ([(dev(x2), None, 1.0, div2)] if k2 else [])
+    y = ops.linear_fwd(srcs, dev(w), dev(b), p, out_act)
+    assert maxnorm_rel(y.cpu().double(), y_ref.detach()) < 2e-5  # bf16 hi/lo 3-pass drops lo*lo (~2^-17)
+    yy = y if out_act else None
+    d1 = ops.linear_bwd_input(dev(gy), yy, out_act, dev(w), 0, srcs[0], p)
+    assert maxnorm_rel(d1.cpu().double(), d[0].grad) < 5e-5
+    if k2:
+        d2 = ops.linear_bwd_input(dev(gy), yy, out_act, dev(w), k1, srcs[1], p)
+        assert maxnorm_rel(d2.view(p // div2, div2, k2).sum(1).cpu().double(), d[1].grad) < 5e-5
+    dw, db = ops.linear_bwd_weight(dev(gy), yy, out_act, srcs, p, n_out)
+    assert maxnorm_rel(dw.cpu().double(), d[2].grad) < 5e-5 and maxnorm_rel(db.cpu().double(), d[3].grad) < 5e-5
 
 
 def _oracle_vs_hip(args, n_rays, seed, tol, sample=None, check=("rgb", "depth", "weights", "beta")):
