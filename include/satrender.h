@@ -172,6 +172,9 @@ int sr_linear_bwd_weight(const float* gy, int ldg, const float* y, int ldy, int 
                          int64_t n_points, int n_out, float* d_weight, float* d_bias, void* stream);
 int sr_points_along(const float* rays, int ray_stride, int dir_col, const float* z_vals, int64_t n_rays, int n_samples, float* xyz,
                     void* stream);
+/* Mapping.forward of the classic nerf (models/nerf.py:36-69): x (rows, dim) -> out (rows, 2*n_freqs*dim) =
+ * [sin(2^0 x), cos(2^0 x), sin(2^1 x), cos(2^1 x), ...], no identity term */
+int sr_positional_map(const float* x, int ld, int dim, int64_t rows, int n_freqs, float* out, void* stream);
 
 /* ---- whole-image evaluation -------------------------------------------------------------
  * sr_composite_image: compositing (models/satnerf.py:52-70) that keeps per ray only what

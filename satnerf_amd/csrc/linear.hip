@@ -196,6 +196,22 @@ __global__ void __launch_bounds__(256) points_along_kernel(const float* __restri
   xyz[p * 3] = r[0] + r[dir_col] * zz, xyz[p * 3 + 1] = r[1] + r[dir_col + 1] * zz, xyz[p * 3 + 2] = r[2] + r[dir_col + 2] * zz;
 }
 
+// Mapping.forward (models/nerf.py:53-69): out[r] = [sin(2^0 x), cos(2^0 x), sin(2^1 x), cos(2^1 x), ...], x = the row's `dim`
+// values, NO identity term; frequencies up to 2^9 on coordinates up to ~6 reach thousands of radians, hence the library
+// sinf/cosf (full range reduction) instead of the revolution-based fast path.
+__global__ void __launch_bounds__(256) positional_map_kernel(const float* __restrict__ x, int ld, int dim, long rows, int n_freqs,
+                                                            float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int width = 2 * n_freqs * dim;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= rows * width) return;
+  const long r = e / width;
+  const int c = (int)(e - r * width);
+  const int f = c / (2 * dim), fn = (c / dim) & 1, ch = c % dim;
+  const float arg = (float)(1 << f) * x[r * ld + ch];
+  out[e] = fn ? cosf(arg) : sinf(arg);
+}
+
 static int copy_src(const sr_linear_src& in, LinSrc& o, const char* what) {
   SR_REQUIRE(in.x != nullptr && in.k >= 1 && in.ld >= in.k && in.row_div >= 1, "%s: bad source (k=%d ld=%d row_div=%d)", what, in.k, in.ld, in.row_div);
   SR_REQUIRE(in.act == SR_ACT_NONE || in.act == SR_ACT_SIN || in.act == SR_ACT_RELU, "%s: unknown activation %d", what, in.act);
@@ -217,6 +233,15 @@ extern "C" int sr_points_along(const float* rays, int ray_stride, int dir_col, c
   hipLaunchKernelGGL(points_along_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rays, ray_stride, dir_col, z_vals, n,
                      n_samples, xyz);
   return check_launch("points_along_kernel");
+}
+
+extern "C" int sr_positional_map(const float* x, int ld, int dim, int64_t rows, int n_freqs, float* out, void* stream) {
+  SR_REQUIRE(x && out, "sr_positional_map: null pointer");
+  SR_REQUIRE(dim >= 1 && ld >= dim && n_freqs >= 1 && n_freqs <= 24, "sr_positional_map: bad sizes (dim %d, ld %d, %d frequencies)", dim, ld, n_freqs);
+  const long n = (long)rows * 2 * n_freqs * dim;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(positional_map_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, dim, (long)rows, n_freqs, out);
+  return check_launch("positional_map_kernel");
 }
 
 extern "C" int sr_linear_fwd(const sr_linear_src* src, int n_src, const float* weight, const float* bias, int64_t n_points, int n_out, int out_act,

@@ -75,9 +75,9 @@ class _CompositeFn(torch.autograd.Function):
     """Compositing (models/satnerf.py:52-70): sr_composite_fwd / sr_composite_bwd."""
 
     @staticmethod
-    def forward(ctx, z, sigma, noise, noise_std, albedo, sun_v, sky):
-        weights, transparency, depth, rgb = ops.composite(z, sigma, noise, noise_std, albedo, sun_v, sky)
-        ctx.noise_std = noise_std
+    def forward(ctx, z, sigma, noise, noise_std, albedo, sun_v, sky, clamp_rgb=True):
+        weights, transparency, depth, rgb = ops.composite(z, sigma, noise, noise_std, albedo, sun_v, sky, clamp_rgb=clamp_rgb)
+        ctx.noise_std, ctx.clamp_rgb = noise_std, clamp_rgb
         ctx.save_for_backward(z, sigma, noise, albedo, sun_v, sky, weights, transparency)
         return rgb, depth, weights, transparency
 
@@ -86,8 +86,10 @@ class _CompositeFn(torch.autograd.Function):
         z, sigma, noise, albedo, sun_v, sky, weights, transparency = ctx.saved_tensors
         c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
         d_sigma, d_albedo, d_sun, d_sky = ops.composite_bwd(z, sigma, noise, ctx.noise_std, albedo, sun_v, sky, weights, transparency, c(g_rgb),
-                                                           c(g_depth), c(g_w), c(g_t))
-        return None, d_sigma, None, None, d_albedo, d_sun, d_sky
+                                                           c(g_depth), c(g_w), c(g_t), clamp_rgb=ctx.clamp_rgb)
+        if sun_v is None:
+            d_sun = d_sky = None
+        return None, d_sigma, None, None, d_albedo, d_sun, d_sky, None
 
 
 def satnerf_points(model, xyz, sun_rows, t_rows, row_div):
@@ -119,6 +121,37 @@ def satnerf_points(model, xyz, sun_rows, t_rows, row_div):
     b = lin(feats, model.beta_from_xyz[0], x2=t_rows, div2=row_div)
     beta = lin(b, model.beta_from_xyz[2], act1="sin", out="softplus")
     return rgb, sigma.view(-1), sun_v.view(-1), beta.view(-1)
+
+
+def nerf_points(model, xyz, dir_rows, row_div, sigma_only=False):
+    """Classic ``NeRF.forward`` (models/nerf.py:184-227) for P points: positional maps, ReLU trunk with the encoded-xyz skip,
+    colour head on [feats | map(dir)].  Returns rgb (P,3) (None if sigma_only), sigma (P,)."""
+    p = xyz.shape[0]
+
+    def lin(x1, layer, act1=None, x2=None, act2=None, div2=1, out=None):
+        return _LinearFn.apply(x1, x2, layer.weight, layer.bias, (act1, 1.0, 1, act2, 1.0, div2, out, p))
+
+    e = ops.positional_map(xyz, model.mapping_sizes[0])
+    fc = model.fc_net
+    pre = lin(e, fc[0])
+    for i in range(1, model.layers):
+        pre = lin(e, fc[2 * i], x2=pre, act2="relu") if i in model.skips else lin(pre, fc[2 * i], act1="relu")
+    sigma = lin(pre, model.sigma_from_xyz[0], act1="relu", out="softplus").view(-1)
+    if sigma_only:
+        return None, sigma
+    feats = lin(pre, model.feats_from_xyz, act1="relu")
+    h = lin(feats, model.rgb_from_xyzdir[0], x2=ops.positional_map(dir_rows, model.mapping_sizes[1]), div2=row_div)
+    return lin(h, model.rgb_from_xyzdir[2], act1="relu", out="sigmoid_rgb"), sigma
+
+
+def nerf_inference_pass(model, args, rays, z, noise):
+    """Classic ``models.nerf.inference`` (models/nerf.py:71-133): no sun / sky / clamp; rays are (N,8)."""
+    n, s = z.shape
+    rgbs, sigma = nerf_points(model, ops.points_along(rays, 3, z), rays[:, 3:6], s)
+    noise_std = float(args.noise_std)
+    rgb, depth, weights, transparency = _CompositeFn.apply(z, sigma.view(n, s), noise if noise_std != 0 else None, noise_std, rgbs.view(n, s, 3), None,
+                                                          None, False)
+    return {"rgb": rgb, "depth": depth, "weights": weights, "transparency": transparency}
 
 
 def inference_pass(model, args, rays, z, ts, emb, dir_cols, noise):

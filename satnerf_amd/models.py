@@ -236,10 +236,52 @@ class SatNeRF(_FlatParamModule):
         return torch.cat([albedo, sigma.unsqueeze(1), sun_v.unsqueeze(1), sky, beta.unsqueeze(1)], 1)
 
 
+class NeRF(_FlatParamModule):
+    """Classic NeRF (models/nerf.py:135-227): positional encoding, ReLU trunk, direction-conditioned colour head; same
+    ``state_dict`` keys.  BASELINE configs[0] is a CPU plumbing run in the reference; here it runs layer by layer through the
+    same MFMA GEMM as the non-256 Sat-NeRF widths (satnerf_amd.generic)."""
+
+    number_of_outputs = 4
+    fused = False
+
+    def __init__(self, layers=8, feat=256, mapping=True, mapping_sizes=[10, 4], skips=[4], siren=False):
+        super().__init__()
+        if not mapping or siren:
+            raise NotImplementedError("classic NeRF runs with mapping=True, siren=False (models/__init__.py:8)")
+        self.layers, self.skips, self.feat = layers, list(skips), feat
+        self.mapping_sizes = list(mapping_sizes)
+        self.input_sizes = [3, 3]
+        self.rgb_padding = 0.001
+        in_xyz, in_dir = 2 * mapping_sizes[0] * 3, 2 * mapping_sizes[1] * 3
+        nl = nn.ReLU()
+        fc = [nn.Linear(in_xyz, feat), nl]
+        for i in range(1, layers):
+            fc += [nn.Linear(feat + in_xyz if i in skips else feat, feat), nl]
+        self.fc_net = nn.Sequential(*fc)
+        self.sigma_from_xyz = nn.Sequential(nn.Linear(feat, 1), nn.Softplus())
+        self.feats_from_xyz = nn.Linear(feat, feat)
+        self.rgb_from_xyzdir = nn.Sequential(nn.Linear(feat + in_dir, feat // 2), nl, nn.Linear(feat // 2, 3), nn.Sigmoid())
+        self._flatten()
+
+    def forward(self, input_xyz, input_dir=None, sigma_only=False):
+        from .generic import nerf_points
+
+        if input_dir is None and not sigma_only:
+            raise TypeError("NeRF.forward needs input_dir (models/nerf.py:213)")
+        xyz = input_xyz.contiguous().float()
+        with torch.no_grad():
+            rgb, sigma = nerf_points(self, xyz, None if input_dir is None else input_dir.contiguous().float(), 1, sigma_only=sigma_only)
+        if sigma_only:
+            return sigma.unsqueeze(1)
+        return torch.cat([rgb, sigma.unsqueeze(1)], 1)
+
+
 def load_model(args):
     """``models.load_model`` (models/__init__.py:6-15)."""
     if args.model == "sat-nerf":
         return SatNeRF(layers=args.fc_layers, feat=args.fc_units, t_embedding_dims=args.t_embbeding_tau)
-    if args.model in ("nerf", "s-nerf"):
-        raise NotImplementedError(f"model {args.model}: only the sat-nerf variant of the hot path is built (SURVEY.md section 8)")
+    if args.model == "nerf":
+        return NeRF(layers=args.fc_layers, feat=args.fc_units)
+    if args.model == "s-nerf":
+        raise NotImplementedError("model s-nerf is out of scope (SURVEY.md section 2); sat-nerf and nerf are built")
     raise ValueError(f"model {args.model} is not valid")

@@ -214,6 +214,14 @@ def linear_bwd_weight(gy, y, out_act, srcs, n_points, n_out, want_bias=True):
     return dw, db
 
 
+def positional_map(x, n_freqs):
+    """``Mapping.forward`` (models/nerf.py:53-69): (rows, dim) -> (rows, 2*n_freqs*dim)."""
+    x, ld = _rows(x, "x", 1)
+    out = torch.empty(x.shape[0], 2 * n_freqs * x.shape[1], dtype=torch.float32, device=x.device)
+    _lib.call("sr_positional_map", _p(x), ld, x.shape[1], x.shape[0], n_freqs, _p(out), _stream())
+    return out
+
+
 def points_along(rays, dir_col, z):
     """xyz (N*S, 3) = rays[:, 0:3] + rays[:, dir_col:dir_col+3] * z (rendering.py:81)."""
     rays, stride = _rows(rays, "rays", dir_col + 3)

@@ -126,8 +126,10 @@ def inference(model, args, rays_xyz, z_vals, rays_d=None, sun_d=None, rays_t=Non
 def render_rays(models, args, rays, ts):
     """Render a chunk of rays: stratified sampling -> fused Sat-NeRF MLP -> compositing [-> fine pass]."""
     n_samples, n_importance, variant = args.n_samples, args.n_importance, args.model
+    if variant == "nerf":
+        return _render_rays_nerf(models, args, rays)
     if variant != "sat-nerf":
-        raise NotImplementedError(f"model {variant}: only sat-nerf is built on the HIP path (SURVEY.md section 8)")
+        raise NotImplementedError(f"model {variant}: sat-nerf and nerf are built on the HIP path (s-nerf: SURVEY.md section 2, out of scope)")
     if ts is None:
         raise TypeError("sat-nerf needs per-ray image indices ts (rendering.py:100 would fail in torch.cat)")
     if not rays.is_cuda:
@@ -160,6 +162,28 @@ def render_rays(models, args, rays, ts):
         u = _rng.rand(n, n_importance, dev)
         z_fine = ops.sample_pdf_merge(z, result["weights_coarse"], u)
         run("fine", z_fine)
+    return result
+
+
+def _render_rays_nerf(models, args, rays):
+    """``render_rays`` for the classic nerf (rendering.py:126-128,141-153; BASELINE configs[0]): rays are (N,8), no ts; every
+    layer runs through the MFMA GEMM of the layer-by-layer path and is differentiable when grad is enabled."""
+    from .generic import nerf_inference_pass
+
+    if not rays.is_cuda:
+        raise RuntimeError("rays must be on the GPU: satnerf_amd has no CPU path")
+    rays = rays.contiguous().float()
+    n, dev, s = rays.shape[0], rays.device, args.n_samples
+    grad = torch.is_grad_enabled() and any(p.requires_grad for p in models["coarse"].parameters())
+    result = {}
+    with contextlib.nullcontext() if grad else torch.no_grad():
+        z = ops.ray_sample(rays, _rng.rand(n, s, dev), s)
+        for k, v in nerf_inference_pass(models["coarse"], args, rays, z, _rng.randn(n, s, dev)).items():
+            result[f"{k}_coarse"] = v
+        if args.n_importance > 0:
+            z_fine = ops.sample_pdf_merge(z, result["weights_coarse"].detach(), _rng.rand(n, args.n_importance, dev))
+            for k, v in nerf_inference_pass(models["fine"], args, rays, z_fine, _rng.randn(n, z_fine.shape[1], dev)).items():
+                result[f"{k}_fine"] = v
     return result
 
 

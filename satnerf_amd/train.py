@@ -28,6 +28,14 @@ def satnerf_loss(res, target, lambda_sc=0.0, beta_min=0.05):
     return loss
 
 
+def nerf_loss(res, target):
+    """``metrics.NerfLoss`` (metrics.py:8-19): MSE of the coarse [+ fine] colour."""
+    loss = torch.mean((res["rgb_coarse"] - target) ** 2)
+    if "rgb_fine" in res:
+        loss = loss + torch.mean((res["rgb_fine"] - target) ** 2)
+    return loss
+
+
 def depth_loss(res, targets, weights=1.0, lambda_ds=1.0):
     """``metrics.DepthLoss`` (metrics.py:75-92): lambda_ds/3 * mean(weights * (depth - target)^2), coarse [+ fine]."""
     lam = lambda_ds / 3.0
@@ -114,7 +122,7 @@ class Trainer:
 
     def __init__(self, models, args, world_size=1, lr=5e-4, loss_fn=None, use_graph=True):
         self.models, self.args, self.world, self.lr = models, args, world_size, lr
-        mods = [models["coarse"]] + ([models["fine"]] if "fine" in models else []) + [models["t"]]
+        mods = [models["coarse"]] + ([models["fine"]] if "fine" in models else []) + ([models["t"]] if "t" in models else [])
         self.state = FlatState(mods)
         p = self.state.params
         self.exp_avg, self.exp_avg_sq = torch.zeros_like(p), torch.zeros_like(p)
@@ -265,7 +273,8 @@ class Trainer:
             from .rendering import render_rays
 
             res = render_rays(self.models, self.args, rays, ts)
-            loss_fn = self.loss_fn or (lambda r, t: satnerf_loss(r, t, getattr(self.args, "sc_lambda", 0.0)))
+            loss_fn = self.loss_fn or (nerf_loss if self.args.model == "nerf" else
+                                       lambda r, t: satnerf_loss(r, t, getattr(self.args, "sc_lambda", 0.0)))  # metrics.load_loss
             loss = loss_fn(res, rgbs)
             if depth is not None:
                 d_rays, d_ts, d_depths = depth

@@ -470,3 +470,27 @@ def test_latlonalt_kernel_matches_reference_golden():
     # a strided view of wider rows and a ragged size
     lat2, _, alt2 = rendering.latlonalt_from_depth(g["rays"].to(DEV)[:77], g["depth"].to(DEV)[:77], np.asarray(g["center"]), float(g["range"]))
     assert torch.equal(lat2, lat[:77]) and torch.equal(alt2, alt[:77])
+
+
+def test_classic_nerf_golden_coarse_and_fine():
+    """BASELINE configs[0] (classic nerf, (N,8) rays, coarse + fine with importance sampling): the reference's render_rays
+    output through the layer-by-layer HIP path."""
+    _, rendering, load_model = _lazy()
+    g = load_golden("nerf_coarse_fine")
+    args = golden_cfg(g)
+    assert args.model == "nerf"
+    models = {}
+    for typ, seed in (("coarse", 1), ("fine", 2)):
+        m = load_model(args)
+        m.load_state_dict(O.procedural_nerf_params(args.fc_units, seed=seed))
+        models[typ] = m.to(DEV).eval()
+    with torch.no_grad(), rendering.replay_rng([d.to(DEV) for d in golden_draws(g)]):
+        res = rendering.render_rays(models, args, g["rays"].to(DEV), None)
+    expected = {k[4:]: v for k, v in g.items() if k.startswith("out_")}
+    assert set(res) == set(expected)
+    worst = {k: maxnorm_rel(res[k].cpu(), v) for k, v in expected.items()}
+    print({k: f"{e:.1e}" for k, e in worst.items()})
+    assert max(worst.values()) < 1e-4, worst
+    out = models["coarse"](torch.rand(70, 3, device=DEV) * 4, input_dir=torch.rand(70, 3, device=DEV))
+    assert out.shape == (70, 4) and torch.isfinite(out).all()
+    assert models["coarse"](torch.rand(70, 3, device=DEV), sigma_only=True).shape == (70, 1)
