@@ -73,71 +73,208 @@ __device__ __forceinline__ float out_act_grad(float y, int oa) {  // derivative 
   return 1.f;
 }
 
-__device__ __forceinline__ float fetch_acat(const LinParams& q, long p, int f, bool ones_col) {
-  if (f < q.s[0].k) return apply_act(q.s[0].x[(p / q.s[0].row_div) * q.s[0].ld + f], q.s[0].act, q.s[0].w0);
-  f -= q.s[0].k;
-  if (q.n_src > 1 && f < q.s[1].k) return apply_act(q.s[1].x[(p / q.s[1].row_div) * q.s[1].ld + f], q.s[1].act, q.s[1].w0);
-  return (ones_col && f == (q.n_src > 1 ? q.s[1].k : 0)) ? 1.f : 0.f;
+struct Vec4 {
+  float v[4];
+};
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+__device__ __forceinline__ Vec4 load4(const float* p) {  // 4 consecutive floats, one 16-byte load when aligned
+  Vec4 r;
+  if (aligned16(p)) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    r.v[0] = t.x, r.v[1] = t.y, r.v[2] = t.z, r.v[3] = t.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r.v[e] = p[e];
+  }
+  return r;
 }
-__device__ __forceinline__ float fetch_g(const LinParams& q, long p, int n) {
-  const float g = q.gy[p * q.ldg + n];
-  return q.out_act == SR_OUT_NONE ? g : g * out_act_grad(q.y[p * q.ldy + n], q.out_act);
+__device__ __forceinline__ long row_of(long p, int div) { return div == 1 ? p : (long)((unsigned long)p / (unsigned)div); }
+
+// acat[p][f0 .. f0+3]: r0 / r1 = row p of the two sources (already divided by row_div)
+__device__ __forceinline__ Vec4 acat4(const LinParams& q, const float* r0, const float* r1, int f0, bool ones_col) {
+  Vec4 r;
+  const int k0 = q.s[0].k;
+  if (f0 + 4 <= k0) {
+    r = load4(r0 + f0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r.v[e] = apply_act(r.v[e], q.s[0].act, q.s[0].w0);
+  } else if (q.n_src > 1 && f0 >= k0 && f0 - k0 + 4 <= q.s[1].k) {
+    r = load4(r1 + (f0 - k0));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r.v[e] = apply_act(r.v[e], q.s[1].act, q.s[1].w0);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int f = f0 + e;
+      float v = 0.f;
+      if (f < k0) v = apply_act(r0[f], q.s[0].act, q.s[0].w0);
+      else if (q.n_src > 1 && f - k0 < q.s[1].k) v = apply_act(r1[f - k0], q.s[1].act, q.s[1].w0);
+      else if (ones_col && f == q.ktot) v = 1.f;
+      r.v[e] = v;
+    }
+  }
+  return r;
+}
+// G[p][n0 .. n0+3] = gy * out_act'(y), zero past n_lim
+__device__ __forceinline__ Vec4 g4(const LinParams& q, const float* gyrow, const float* yrow, int n0, int n_lim) {
+  Vec4 r;
+  if (n0 + 4 <= n_lim) {
+    r = load4(gyrow + n0);
+    if (q.out_act != SR_OUT_NONE) {
+      const Vec4 y = load4(yrow + n0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r.v[e] *= out_act_grad(y.v[e], q.out_act);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = 0.f;
+      if (n0 + e < n_lim) v = q.out_act == SR_OUT_NONE ? gyrow[n0 + e] : gyrow[n0 + e] * out_act_grad(yrow[n0 + e], q.out_act);
+      r.v[e] = v;
+    }
+  }
+  return r;
+}
+__device__ __forceinline__ Vec4 w4(const float* p, int i0, int lim) {  // p[i0 .. i0+3], zero past lim
+  Vec4 r;
+  if (i0 + 4 <= lim) r = load4(p + i0);
+  else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r.v[e] = i0 + e < lim ? p[i0 + e] : 0.f;
+  }
+  return r;
 }
 
 constexpr int kBM = 128, kBN = 128, kBK = 32, kRow = 40;  // LDS row = 32 bf16 + 8 of padding (80 B: 16-byte aligned fragments)
 constexpr int kPlane = kBM * kRow;                          // halfwords per plane
 
-// Aop(i, k) / Bop(j, k) for the three products
-template <int KIND>
-__device__ __forceinline__ float fetch_a(const LinParams& q, long i, long k) {
-  if (i >= q.M || k >= q.K) return 0.f;
-  if (KIND == kFwd) return fetch_acat(q, i, (int)k, false);
-  if (KIND == kDx) return fetch_g(q, i, (int)k);
-  return fetch_g(q, k, (int)i);
+__device__ __forceinline__ void split4(const Vec4& x, uint2& hi, uint2& lo) {
+  uint32_t h0, l0, h1, l1;
+  split_bf16x2(x.v[0], x.v[1], h0, l0);
+  split_bf16x2(x.v[2], x.v[3], h1, l1);
+  hi = make_uint2(h0, h1), lo = make_uint2(l0, l1);
 }
-template <int KIND>
-__device__ __forceinline__ float fetch_b(const LinParams& q, long j, long k) {
-  if (j >= q.N || k >= q.K) return 0.f;
-  if (KIND == kFwd) return q.w[j * q.ldw + k];
-  if (KIND == kDx) return q.w[k * q.ldw + q.col0 + j];
-  return fetch_acat(q, k, (int)j, true);
+// 4 consecutive k of one tile row -> one 8-byte store per plane
+__device__ __forceinline__ void put_k4(uint16_t* plane_hi, int row, int k, const Vec4& x) {
+  uint2 hi, lo;
+  split4(x, hi, lo);
+  *reinterpret_cast<uint2*>(plane_hi + row * kRow + k) = hi;
+  *reinterpret_cast<uint2*>(plane_hi + kPlane + row * kRow + k) = lo;
+}
+// 4 consecutive tile rows at one k -> transposed 2-byte stores
+__device__ __forceinline__ void put_r4(uint16_t* plane_hi, int row, int k, const Vec4& x) {
+  uint2 hi, lo;
+  split4(x, hi, lo);
+  uint16_t* p = plane_hi + row * kRow + k;
+  p[0] = (uint16_t)hi.x, p[kRow] = (uint16_t)(hi.x >> 16), p[2 * kRow] = (uint16_t)hi.y, p[3 * kRow] = (uint16_t)(hi.y >> 16);
+  p += kPlane;
+  p[0] = (uint16_t)lo.x, p[kRow] = (uint16_t)(lo.x >> 16), p[2 * kRow] = (uint16_t)lo.y, p[3 * kRow] = (uint16_t)(lo.y >> 16);
 }
 
+// Staging.  Operands whose memory runs along the contraction index (FWD A and B, DX A) are moved as 4 consecutive k of one row
+// per thread (thread -> k = 4*(t&7), rows (t>>3) + 32*it: the row pointers are computed once per kernel); operands whose memory
+// runs along the row index (DX B, DW A and B) as 4 consecutive rows at one k (thread -> rows 4*(t&31), k = (t>>5) + 8*it).
 template <int KIND>
 __global__ void __launch_bounds__(256) linear_kernel(const LinParams q) {
   __shared__ __attribute__((aligned(16))) uint16_t lds[4 * kPlane];  // A hi, A lo, B hi, B lo
+  uint16_t* const lds_a = lds;
+  uint16_t* const lds_b = lds + 2 * kPlane;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long i0 = (long)blockIdx.y * kBM, j0 = (long)blockIdx.x * kBN;
   const long k_begin = (long)blockIdx.z * q.kchunk;
   long k_end = k_begin + q.kchunk;
   if (k_end > q.K) k_end = q.K;
-  // operand memory is contiguous along k (FWD both, DX A) or along the row index (DX B, DW both): consecutive threads follow it
-  constexpr bool kARowMajor = KIND == kDw, kBRowMajor = KIND != kFwd;
   const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+  const int kq = (tid & 7) * 4, rq = tid >> 3;        // k-major staging
+  const int r4 = (tid & 31) * 4, kr = tid >> 5;       // row-major staging
+
+  // row pointers of the k-major operands (fixed over the k loop)
+  const float *pa0[4] = {}, *pa1[4] = {}, *pb[4] = {};
+  bool va[4] = {}, vb[4] = {};
+  if (KIND == kFwd || KIND == kDx) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const long i = i0 + rq + 32 * it;
+      va[it] = i < q.M;
+      const long ic = va[it] ? i : 0;
+      if (KIND == kFwd) {
+        pa0[it] = q.s[0].x + row_of(ic, q.s[0].row_div) * q.s[0].ld;
+        pa1[it] = q.n_src > 1 ? q.s[1].x + row_of(ic, q.s[1].row_div) * q.s[1].ld : nullptr;
+      } else {
+        pa0[it] = q.gy + ic * q.ldg;
+        pa1[it] = q.out_act != SR_OUT_NONE ? q.y + ic * q.ldy : nullptr;
+      }
+    }
+  }
+  if (KIND == kFwd) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const long j = j0 + rq + 32 * it;
+      vb[it] = j < q.N;
+      pb[it] = q.w + (vb[it] ? j : 0) * q.ldw;
+    }
+  }
+  const Vec4 zero4 = {{0.f, 0.f, 0.f, 0.f}};
 
   f32x16 acc[2][2] = {};
   for (long kt = k_begin; kt < k_end; kt += kBK) {
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      int r, k;
-      if (kARowMajor) r = tid & 127, k = (tid >> 7) + 2 * it;
-      else k = tid & 31, r = (tid >> 5) + 8 * it;
-      float v = 0.f;
-      if (kt + k < k_end) v = fetch_a<KIND>(q, i0 + r, kt + k);
-      const uint32_t hi = pack_bf16x2(v, 0.f) & 0xffffu;
-      lds[r * kRow + k] = (uint16_t)hi;
-      lds[kPlane + r * kRow + k] = (uint16_t)(pack_bf16x2(v - bf16_lo_to_f32(hi), 0.f) & 0xffffu);
+    const int klim = (int)(k_end - kt < kBK ? k_end - kt : kBK);  // valid k in this tile
+    // ---- A tile
+    if (KIND == kFwd || KIND == kDx) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        Vec4 x = zero4;
+        if (va[it] && kq < klim) {
+          const int f0 = (int)kt + kq;
+          x = KIND == kFwd ? acat4(q, pa0[it], pa1[it], f0, false) : g4(q, pa0[it], pa1[it], f0, (int)q.K);
+          if (kq + 4 > klim) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (kq + e >= klim) x.v[e] = 0.f;
+          }
+        }
+        put_k4(lds_a, rq + 32 * it, kq, x);
+      }
+    } else {  // DW: Aop(i = n, k = p) = G[p][n], memory along n
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int k = kr + 8 * it;
+        Vec4 x = zero4;
+        if (k < klim && i0 + r4 < q.M) {
+          const long p = kt + k;
+          x = g4(q, q.gy + p * q.ldg, q.out_act != SR_OUT_NONE ? q.y + p * q.ldy : nullptr, (int)i0 + r4, (int)q.M);
+        }
+        put_r4(lds_a, r4, k, x);
+      }
     }
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      int r, k;
-      if (kBRowMajor) r = tid & 127, k = (tid >> 7) + 2 * it;
-      else k = tid & 31, r = (tid >> 5) + 8 * it;
-      float v = 0.f;
-      if (kt + k < k_end) v = fetch_b<KIND>(q, j0 + r, kt + k);
-      const uint32_t hi = pack_bf16x2(v, 0.f) & 0xffffu;
-      lds[2 * kPlane + r * kRow + k] = (uint16_t)hi;
-      lds[3 * kPlane + r * kRow + k] = (uint16_t)(pack_bf16x2(v - bf16_lo_to_f32(hi), 0.f) & 0xffffu);
+    // ---- B tile
+    if (KIND == kFwd) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        Vec4 x = zero4;
+        if (vb[it] && kq < klim) x = w4(pb[it], (int)kt + kq, (int)k_end);
+        put_k4(lds_b, rq + 32 * it, kq, x);
+      }
+    } else if (KIND == kDx) {  // Bop(j, k = n) = W[n][col0 + j], memory along j
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int k = kr + 8 * it;
+        Vec4 x = zero4;
+        if (k < klim && j0 + r4 < q.N) x = w4(q.w + (kt + k) * q.ldw + q.col0, (int)j0 + r4, (int)q.N);
+        put_r4(lds_b, r4, k, x);
+      }
+    } else {  // DW: Bop(j = f, k = p) = acat[p][f], memory along f
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int k = kr + 8 * it;
+        Vec4 x = zero4;
+        if (k < klim && j0 + r4 < q.N) {
+          const long p = kt + k;
+          x = acat4(q, q.s[0].x + row_of(p, q.s[0].row_div) * q.s[0].ld,
+                    q.n_src > 1 ? q.s[1].x + row_of(p, q.s[1].row_div) * q.s[1].ld : nullptr, (int)j0 + r4, true);
+        }
+        put_r4(lds_b, r4, k, x);
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -146,8 +283,8 @@ __global__ void __launch_bounds__(256) linear_kernel(const LinParams q) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int ra = (wm * 64 + t * 32 + l31) * kRow + ks * 16 + h * 8, rb = (wn * 64 + t * 32 + l31) * kRow + ks * 16 + h * 8;
-        ah[t] = *reinterpret_cast<const uint4*>(lds + ra), al[t] = *reinterpret_cast<const uint4*>(lds + kPlane + ra);
-        bh[t] = *reinterpret_cast<const uint4*>(lds + 2 * kPlane + rb), bl[t] = *reinterpret_cast<const uint4*>(lds + 3 * kPlane + rb);
+        ah[t] = *reinterpret_cast<const uint4*>(lds_a + ra), al[t] = *reinterpret_cast<const uint4*>(lds_a + kPlane + ra);
+        bh[t] = *reinterpret_cast<const uint4*>(lds_b + rb), bl[t] = *reinterpret_cast<const uint4*>(lds_b + kPlane + rb);
       }
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
