@@ -148,10 +148,10 @@ def main():
         use_graph = [True]
 
         def step(i):
-            rays_b, ts_b, _ = bank.next_batch()
             if use_graph[0]:
-                graphed(rays_b, ts_b)
+                graphed.render_next(bank)  # batch gathered straight into the graph's static inputs
             else:
+                rays_b, ts_b, _ = bank.next_batch()
                 with torch.no_grad():
                     rendering.render_rays(models, args, rays_b, ts_b)
 

@@ -81,7 +81,7 @@ def _mode_of(args):
     return getattr(args, "mlp_mode", None) or _MODE
 
 
-def _inference(model, args, rays, z, ts, emb_weight, dir_cols, noise):
+def _inference(model, args, rays, z, ts, emb_weight, dir_cols, noise, sky=None):
     """models/satnerf.inference (models/satnerf.py:4-79) for the points rays[:, 0:3] + rays[:, dir_cols] * z."""
     n, s = z.shape
     if not model.fused:  # widths / depths outside the fused kernel: layer by layer (satnerf_amd.generic)
@@ -92,8 +92,9 @@ def _inference(model, args, rays, z, ts, emb_weight, dir_cols, noise):
     hi, lo, l0 = model.packed(mode)
     albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, dir_cols[0]:dir_cols[1]], rays[:, 8:11], z, emb_weight, ts, n * s, s,
                                                  model.feat, model.t_embedding_dims, mode, hi, lo, l0)
-    sk = model.sky_color
-    sky = ops.sky(rays[:, 8:11], sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data)
+    if sky is None:
+        sk = model.sky_color
+        sky = ops.sky(rays[:, 8:11], sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data)
     sigma, sun_v = sigma.view(n, s), sun_v.view(n, s)
     albedo = albedo.view(n, s, 3)
     use_noise = args.noise_std != 0
@@ -144,12 +145,19 @@ def render_rays(models, args, rays, ts):
     emb = models["t"].weight.data if hasattr(models["t"], "weight") else models["t"]
     emb = emb.contiguous().float()
 
-    z = ops.ray_sample(rays, _rng.rand(n, n_samples, dev), n_samples)  # rendering.py:62-78 (perturb = 1)
+    coarse = models["coarse"]
+    sky_of = {}
+    if getattr(coarse, "fused", False):  # stratified depths (rendering.py:62-78, perturb = 1) + the coarse sky head in one launch
+        sk = coarse.sky_color
+        z, sky_of["coarse"] = ops.ray_setup(rays, _rng.rand(n, n_samples, dev), n_samples, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data,
+                                            sk[2].bias.data)
+    else:
+        z = ops.ray_sample(rays, _rng.rand(n, n_samples, dev), n_samples)
     result = {}
 
     def run(typ, z_cur):
         noise = _rng.randn(n, z_cur.shape[1], dev)  # models/satnerf.py:58 -- always drawn
-        res = _inference(models[typ], args, rays, z_cur, ts, emb, (3, 6), noise)
+        res = _inference(models[typ], args, rays, z_cur, ts, emb, (3, 6), noise, sky_of.get(typ))
         if args.sc_lambda > 0:  # solar correction: same depths along the sun direction (rendering.py:102-108)
             noise_sc = _rng.randn(n, z_cur.shape[1], dev)
             sc = _inference(models[typ], args, rays, z_cur, ts, emb, (8, 11), noise_sc)
@@ -272,28 +280,36 @@ class GraphedRenderer:
     (profiles/r01_bench_forward.json).  The captured graph contains the same launches (including the RNG draws, which advance
     torch's generator exactly as eager calls would), so results and the random stream are unchanged.  Outputs are views of
     static buffers: they are overwritten by the next call -- clone what must survive.  Weights may change between calls
-    (the pack kernels are part of the graph) but not be re-allocated.
+    (their streams are re-packed before the replay when they did) but not be re-allocated.
     """
 
     def __init__(self, models, args, n_rays, device):
         self.models, self.args, self.n = models, args, n_rays
         self.rays = torch.zeros(n_rays, 11, device=device)
         self.ts = torch.zeros(n_rays, dtype=torch.int64, device=device)
+        self._rgbs = torch.zeros(n_rays, 3, device=device)  # gather target for a ray bank's colours (unused by rendering)
         self.graph, self.out = None, None
+        self._packed_for = {}
 
-    def _run(self):
+    def _refresh_weights(self):
+        """Weight streams are re-packed (eagerly, into the fixed buffers the graph reads) only when the parameters changed."""
         mode = _mode_of(self.args)
         for typ in ("coarse", "fine"):
-            if typ in self.models:
-                self.models[typ].repack(mode)  # unconditional pack into fixed buffers: safe to capture
+            m = self.models.get(typ)
+            if m is None or not getattr(m, "fused", False):
+                continue
+            stamp = (m.weights_version(), m.flat_params().data_ptr(), mode)
+            if self._packed_for.get(typ) != stamp:
+                m.repack(mode)
+                self._packed_for[typ] = (m.weights_version(), m.flat_params().data_ptr(), mode)
+
+    def _run(self):
         return render_rays(self.models, self.args, self.rays, self.ts)
 
     @torch.no_grad()
-    def __call__(self, rays, ts):
-        if rays.shape[0] != self.n:
-            raise ValueError(f"GraphedRenderer was built for {self.n} rays, got {rays.shape[0]}")
-        self.rays.copy_(rays)
-        self.ts.copy_(ts.view(-1))
+    def replay(self):
+        """Render the rays currently in ``self.rays`` / ``self.ts`` (fill them in place, e.g. ``RayBank.next_batch(out=...)``)."""
+        self._refresh_weights()
         if self.graph is None:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -306,6 +322,21 @@ class GraphedRenderer:
                 self.out = self._run()
         self.graph.replay()
         return self.out
+
+    def render_next(self, bank):
+        """Gather the bank's next batch straight into the static inputs and render it."""
+        if bank.batch_size != self.n:
+            raise ValueError(f"GraphedRenderer was built for {self.n} rays, the bank serves {bank.batch_size}")
+        bank.next_batch(out=(self.rays, self.ts, self._rgbs))
+        return self.replay()
+
+    @torch.no_grad()
+    def __call__(self, rays, ts):
+        if rays.shape[0] != self.n:
+            raise ValueError(f"GraphedRenderer was built for {self.n} rays, got {rays.shape[0]}")
+        self.rays.copy_(rays)
+        self.ts.copy_(ts.view(-1))
+        return self.replay()
 
 
 @torch.no_grad()
