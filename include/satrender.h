@@ -103,10 +103,11 @@ int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, int mode, con
  * those outputs (g_* may be NULL = 0); bwd_stream = packed transposed weights (sr_pack_stream with
  * packing.backward_maps).  Outputs: dpre (sr_dpre_elems_per_tile(feat) * ceil(P/32) bf16) and d_t (P,tau) fp32, the
  * gradient w.r.t. each point's embedding vector (NULL to skip).
- * sr_satnerf_wgrad: weight-gradient GEMMs dpre x acts over all points.  `blocks` (n_blocks x 8 int32, device) lists the job
- * blocks (row_frag0, n_row, col_frag0, n_col, col_kind, n_slices, first_slice, -; packing.backward_maps); every block is
- * cut into n_slices contiguous ranges of 32-point tiles (split-K), one workgroup each, writing slice s to
- * partial + s * (256*256 + 256*32) floats; reduce with sr_unpack_grads.
+ * sr_satnerf_wgrad: weight-gradient GEMMs dpre x acts over all points.  `blocks` (n_blocks x 12 int32, device) lists the job
+ * blocks (rf0 nr0 rf1 nr1 | cf0 nc0 cf1 nc1 | col_kind n_slices first_slice -: up to two ranges of dpre row fragments and of
+ * activation column fragments, <= 16 each; packing.backward_maps); every block is cut into n_slices contiguous ranges of
+ * 32-point tiles (split-K), one workgroup each, writing slice s to partial + s * (256*256 + 256*32) floats; reduce with
+ * sr_unpack_grads.
  * sr_wgrad_plan (host, no GPU work): fills n_slices / first_slice of a HOST copy of the table for n_points points and at
  * most n_wg workgroups (n_wg <= 0: the current device's CU count); *n_slices = total slices. */
 int sr_satnerf_mlp_bwd(int feat, int tau, int64_t n_points, const uint16_t* bwd_stream, const uint16_t* acts,

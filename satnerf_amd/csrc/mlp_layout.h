@@ -126,17 +126,19 @@ struct BwdStream {
 };
 
 // ---- weight-gradient partial blocks (wgrad.hip) -------------------------------------------------------------------
-// One split-K slice of one job block: 256 x 256 main block + 256 x 32 aux columns, fp32.  Job table row (8 int32):
-// row_frag0, n_row, col_frag0, n_col, col_kind, n_slices, first_slice, - ; slices of all blocks are numbered consecutively
-// (sr_wgrad_plan) and slice s lives at partial + s * kWgBlockFloats.
+// One split-K slice of one job block: 256 x 256 main block + 256 x 32 aux columns, fp32.  Job table row (kWgTableInts int32):
+//   rf0 nr0 rf1 nr1 | cf0 nc0 cf1 nc1 | col_kind n_slices first_slice -
+// = up to two ranges of dpre row fragments (nr0 + nr1 <= 16), up to two ranges of activation column fragments (nc0 + nc1 <= 16);
+// slices of all blocks are numbered consecutively (sr_wgrad_plan) and slice s lives at partial + s * kWgBlockFloats.
 constexpr int kWgBlockFloats = 256 * 256 + 256 * 32;
+constexpr int kWgTableInts = 12, kWgSlices = 9, kWgFirstSlice = 10;
 
 #ifdef __HIPCC__
 // sum over the slices of element k = block * kWgBlockFloats + offset
 __device__ __forceinline__ float wg_sum_slices(const float* __restrict__ partial, const int* __restrict__ blocks, int k) {
   const int b = k / kWgBlockFloats, w = k - b * kWgBlockFloats;
-  const int ns = blocks[8 * b + 5];
-  const float* p = partial + (long)blocks[8 * b + 6] * kWgBlockFloats + w;
+  const int ns = blocks[kWgTableInts * b + kWgSlices];
+  const float* p = partial + (long)blocks[kWgTableInts * b + kWgFirstSlice] * kWgBlockFloats + w;
   float s = 0.f;
   for (int sp = 0; sp < ns; ++sp) s += p[(long)sp * kWgBlockFloats];
   return s;

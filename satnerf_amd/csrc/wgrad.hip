@@ -24,7 +24,7 @@ namespace sr {
 struct WgradParams {
   const uint4* dpre;
   const uint4* acts;
-  const int* blocks;  // 8 ints per block: row_frag0, n_row (<=16), col_frag0, n_col (0..16), col_kind, n_slices, first_slice, -
+  const int* blocks;  // kWgTableInts ints per block (mlp_layout.h): two row ranges, two column ranges, kind, n_slices, first_slice
   float* partial;
   long n_tiles;
   int n_blocks;
@@ -75,17 +75,19 @@ __global__ void __launch_bounds__(512) wgrad_kernel(const WgradParams prm) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int* d = prm.blocks;  // find the job block this slice belongs to
-  for (int b = 0; b + 1 < prm.n_blocks && (int)blockIdx.x >= d[6] + d[5]; ++b) d += 8;
-  const int rf0 = d[0], nr = d[1], cf0 = d[2], nc = d[3], kind = d[4];
-  const long tiles_per_split = (prm.n_tiles + d[5] - 1) / d[5];
-  const long t_begin = (long)((int)blockIdx.x - d[6]) * tiles_per_split;
+  for (int b = 0; b + 1 < prm.n_blocks && (int)blockIdx.x >= d[kWgFirstSlice] + d[kWgSlices]; ++b) d += kWgTableInts;
+  const int rf0 = d[0], nr0 = d[1], rf1 = d[2], nr = d[1] + d[3], cf0 = d[4], nc0 = d[5], cf1 = d[6], nc = d[5] + d[7], kind = d[8];
+  const long tiles_per_split = (prm.n_tiles + d[kWgSlices] - 1) / d[kWgSlices];
+  const long t_begin = (long)((int)blockIdx.x - d[kWgFirstSlice]) * tiles_per_split;
   long t_end = t_begin + tiles_per_split;
   if (t_end > prm.n_tiles) t_end = prm.n_tiles;
   const int nt = t_end > t_begin ? (int)(t_end - t_begin) : 0;
 
   // staging: wave w moves row fragments w, w+8 and column fragments w, w+8; waves 0,1 also move the aux fragments
-  const int fr0 = rf0 + (wave < nr ? wave : nr - 1), fr1 = rf0 + (wave + 8 < nr ? wave + 8 : nr - 1);
-  const int fc0 = nc > 0 ? cf0 + (wave < nc ? wave : nc - 1) : 0, fc1 = nc > 0 ? cf0 + (wave + 8 < nc ? wave + 8 : nc - 1) : 0;
+  auto row_frag = [&](int q) { return q < nr0 ? rf0 + q : rf1 + q - nr0; };  // fragment at row / column position q of the block
+  auto col_frag = [&](int q) { return q < nc0 ? cf0 + q : cf1 + q - nc0; };
+  const int fr0 = row_frag(wave < nr ? wave : nr - 1), fr1 = row_frag(wave + 8 < nr ? wave + 8 : nr - 1);
+  const int fc0 = nc > 0 ? col_frag(wave < nc ? wave : nc - 1) : 0, fc1 = nc > 0 ? col_frag(wave + 8 < nc ? wave + 8 : nc - 1) : 0;
   const int fa = wave < prm.auxs ? wave : prm.auxs - 1;  // aux fragments are the first fragments of the activation tile
   const int src_unit = lane < 32 ? lane : 32 + ((lane - 8) & 31);  // LDS position `lane` <- this 16-byte unit of the fragment
   const uint32_t ring = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
@@ -374,9 +376,11 @@ extern "C" int sr_wgrad_plan(int32_t* blocks, int n_blocks, int64_t n_points, in
 #endif
   int first = 0;
   for (int b = 0; b < n_blocks; ++b) {
-    SR_REQUIRE(blocks[8 * b + 1] >= 1 && blocks[8 * b + 1] <= 16 && blocks[8 * b + 3] >= 0 && blocks[8 * b + 3] <= 16,
-               "sr_wgrad_plan: block %d has %d row / %d column fragments (1..16 / 0..16)", b, blocks[8 * b + 1], blocks[8 * b + 3]);
-    blocks[8 * b + 5] = (int)per_block, blocks[8 * b + 6] = first, first += (int)per_block;
+    int32_t* t = blocks + kWgTableInts * b;
+    const int nr = t[1] + t[3], nc = t[5] + t[7];
+    SR_REQUIRE(t[1] >= 1 && t[3] >= 0 && nr <= 16 && t[5] >= 0 && t[7] >= 0 && nc <= 16,
+               "sr_wgrad_plan: block %d has %d row / %d column fragments (1..16 / 0..16)", b, nr, nc);
+    t[kWgSlices] = (int)per_block, t[kWgFirstSlice] = first, first += (int)per_block;
   }
   *n_slices = first;
   return 0;

@@ -189,7 +189,6 @@ def forward_maps(feat=256, tau=4):
 
 # ------------------------------------------------------------------------------------------------ backward
 KIND_BF16, KIND_PHASE = 0, 1
-WG_ROWS = 16   # the weight-gradient kernel computes up to (16 row fragments) x (16 column fragments) = 256 x 256 per workgroup
 WG_BLOCK_FLOATS = 256 * 256 + 256 * 32  # ... plus its 32 aux columns
 
 
@@ -200,44 +199,76 @@ def feat_to_slot(n):
     return inv
 
 
+WG_TABLE_INTS = 12  # ints per job block: rf0 nr0 rf1 nr1 | cf0 nc0 cf1 nc1 | col_kind n_slices first_slice 0
+
+
+class _Blocks:
+    """Job table of the weight-gradient kernel.  A block = up to 16 dpre ROW fragments x up to 16 activation COLUMN fragments
+    (each given as at most two contiguous fragment ranges) + the rows x aux-slot columns; a workgroup's time per point tile does
+    not depend on how full its block is (profiles/r01_ab_variants.txt), so narrow layers are packed together -- the cross
+    products nobody asked for are computed and ignored."""
+
+    def __init__(self):
+        self.rows, self.cols, self.kind = [], [], []
+
+    def add(self, row_ranges, col_ranges, kind):
+        rows = [f for f0, n in row_ranges for f in range(f0, f0 + n)]
+        cols = [f for f0, n in col_ranges for f in range(f0, f0 + n)]
+        assert 1 <= len(rows) <= 16 and len(cols) <= 16 and len(row_ranges) <= 2 and len(col_ranges) <= 2
+        self.rows.append(rows), self.cols.append(cols), self.kind.append(kind)
+        self._ranges = getattr(self, "_ranges", []) + [(list(row_ranges), list(col_ranges))]
+
+    def table(self):
+        out = np.zeros((len(self.rows), WG_TABLE_INTS), np.int32)
+        for b, (rr, cr) in enumerate(self._ranges):
+            rr = rr + [(0, 0)] * (2 - len(rr))
+            cr = cr + [(0, 0)] * (2 - len(cr))
+            out[b, 0:4] = [rr[0][0], rr[0][1], rr[1][0], rr[1][1]]
+            out[b, 4:8] = [cr[0][0], cr[0][1], cr[1][0], cr[1][1]]
+            out[b, 8] = self.kind[b]
+        return out
+
+    def find(self, row_frag, col_frag):
+        """(block, row position, column position) of the block holding both fragments (col_frag None: any block with the row)."""
+        for b, (rows, cols) in enumerate(zip(self.rows, self.cols)):
+            if row_frag in rows and (col_frag is None or col_frag in cols):
+                return b, rows.index(row_frag), (cols.index(col_frag) if col_frag is not None else 0)
+        raise KeyError((row_frag, col_frag))
+
+
 class _Job:
-    """Weight-gradient GEMMs of one layer group: dW[row slot][col slot] = sum_points dpre[row] * act[col].
+    """Weight-gradient GEMMs of one layer group: dW[row slot][col slot] = sum_points dpre[row] * act[col]; ``rf0`` = first
+    dpre fragment of its rows, ``col_segs`` = first activation fragment of each input segment.  Positions are looked up in the
+    block table, wherever the packing put the fragments."""
 
-    ``row_groups`` = [(first dpre fragment, n fragments <= 16)], ``col_segs`` = [(first activation fragment, n <= 16, kind)];
-    one block per (row group, column segment); every block also produces its rows x aux-slot columns.  A job without
-    column segments (fc_net.0: inputs are the aux slots only) gets one aux-only block per row group."""
-
-    def __init__(self, blocks, row_groups, col_segs):
-        self.row_groups, self.col_segs = row_groups, col_segs
-        self.block = {}
-        for gi, (rf0, nr) in enumerate(row_groups):
-            for si, (cf0, nc, kind) in enumerate(col_segs or [(0, 0, KIND_BF16)]):
-                self.block[(gi, si)] = len(blocks)
-                blocks.append([rf0, nr, cf0, nc, kind, 0, 0, 0])
-
-    def _group_of(self, row_slot):
-        row_slot = np.asarray(row_slot)
-        starts = np.cumsum([0] + [16 * nr for _, nr in self.row_groups])
-        gi = np.searchsorted(starts, row_slot, side="right") - 1
-        return gi, row_slot - starts[gi]
+    def __init__(self, table, rf0, col_segs):
+        self.table, self.rf0, self.col_segs = table, rf0, col_segs
 
     def pos(self, row_slot, seg, col_slot):
-        """position of dW[row_slot][col_slot of segment seg] in the partial buffer (row_slot counts across the job's row groups)."""
-        gi, local = self._group_of(row_slot)
-        base = np.vectorize(lambda g: self.block[(int(g), seg)])(gi)
-        return base * WG_BLOCK_FLOATS + local * 256 + np.asarray(col_slot)
+        row_slot, col_slot = np.broadcast_arrays(np.asarray(row_slot), np.asarray(col_slot))
+        out = np.empty(row_slot.shape, np.int64)
+        for i in np.ndindex(row_slot.shape):
+            r, c = int(row_slot[i]), int(col_slot[i])
+            b, rp, cp = self.table.find(self.rf0 + r // 16, self.col_segs[seg] + c // 16)
+            out[i] = b * WG_BLOCK_FLOATS + (16 * rp + r % 16) * 256 + 16 * cp + c % 16
+        return out
 
     def pos_aux(self, row_slot, aux_slot):
-        gi, local = self._group_of(row_slot)
-        base = np.vectorize(lambda g: self.block[(int(g), 0)])(gi)
-        return base * WG_BLOCK_FLOATS + 256 * 256 + local * 32 + np.asarray(aux_slot)
+        row_slot, aux_slot = np.broadcast_arrays(np.asarray(row_slot), np.asarray(aux_slot))
+        out = np.empty(row_slot.shape, np.int64)
+        for i in np.ndindex(row_slot.shape):
+            r = int(row_slot[i])
+            b, rp, _ = self.table.find(self.rf0 + r // 16, None)
+            out[i] = b * WG_BLOCK_FLOATS + 256 * 256 + (16 * rp + r % 16) * 32 + int(aux_slot[i])
+        return out
 
 
 @functools.lru_cache(maxsize=8)
 def backward_maps(feat=256, tau=4):
     """Gather maps of the transposed (dX) stream, the weight-gradient job table and the gradient scatter map.
 
-    Returns dict(idx, scale: bwd stream;  blocks int32 [n_blocks, 8] = (row_frag0, n_row<=16, col_frag0, n_col<=16, col_kind, 0,0,0);
+    Returns dict(idx, scale: bwd stream;  blocks int32 [n_blocks, 12] = (rf0, nr0, rf1, nr1, cf0, nc0, cf1, nc1, col_kind, 0, 0, 0):
+    up to two row / two column fragment ranges per block (block_rows / block_cols list the fragments);
     gidx int32 [n_params] position of each parameter's gradient in the block-partial buffer (-1: not produced here),
     gscale fp32 [n_params]).
     """
@@ -287,15 +318,24 @@ def backward_maps(feat=256, tau=4):
     a_frag = lambda l: A + 16 * l  # noqa: E731
     ACT_FEATS, ACT_RGBH, ACT_S1, ACT_E1, ACT_S2, ACT_S3 = A + 128, A + 144, A + 152, A + 160, A + 168, A + 176
     DP_FEATS, DP_SIGMA, DP_RGBH, DP_S2, DP_S3, DP_HEAD = 128, 144, 145, 169, 177, 185
-    blocks = []
-    jobs = {"L0": _Job(blocks, [(0, 16)], [])}
+    tab = _Blocks()
     for l in range(1, 8):
-        jobs[f"L{l}"] = _Job(blocks, [(16 * l, 16)], [(a_frag(l - 1), 16, KIND_PHASE)])
-    jobs["G1"] = _Job(blocks, [(DP_FEATS, 16), (DP_SIGMA, 1)], [(a_frag(7), 16, KIND_PHASE)])
-    jobs["G2"] = _Job(blocks, [(DP_RGBH, 16), (DP_RGBH + 16, 8)], [(ACT_FEATS, 16, KIND_BF16)])
-    jobs["S2"] = _Job(blocks, [(DP_S2, 8)], [(ACT_S1, 8, KIND_PHASE)])
-    jobs["S3"] = _Job(blocks, [(DP_S3, 8)], [(ACT_S2, 8, KIND_PHASE)])
-    jobs["H"] = _Job(blocks, [(DP_HEAD, 1)], [(ACT_RGBH, 8, KIND_PHASE), (ACT_S3, 8, KIND_PHASE), (ACT_E1, 8, KIND_PHASE)])
+        tab.add([(16 * l, 16)], [(a_frag(l - 1), 16)], KIND_PHASE)
+    tab.add([(DP_FEATS, 16)], [(a_frag(7), 16)], KIND_PHASE)                          # feats_from_xyz
+    tab.add([(DP_SIGMA, 1), (0, 8)], [(a_frag(7), 16)], KIND_PHASE)                   # sigma head + first half of fc_net.0 (aux columns only)
+    tab.add([(DP_RGBH, 16)], [(ACT_FEATS, 16)], KIND_BF16)                            # rgb hidden + sun hidden 1
+    tab.add([(DP_RGBH + 16, 8), (8, 8)], [(ACT_FEATS, 16)], KIND_BF16)                # beta hidden + second half of fc_net.0
+    tab.add([(DP_S2, 8), (DP_S3, 8)], [(ACT_S1, 8), (ACT_S2, 8)], KIND_PHASE)         # sun hidden 2 and 3
+    tab.add([(DP_HEAD, 1)], [(ACT_RGBH, 8), (ACT_S3, 8)], KIND_PHASE)                 # rgb and sun output rows
+    tab.add([(DP_HEAD, 1)], [(ACT_E1, 8)], KIND_PHASE)                                # beta output row
+    jobs = {"L0": _Job(tab, 0, [])}
+    for l in range(1, 8):
+        jobs[f"L{l}"] = _Job(tab, 16 * l, [a_frag(l - 1)])
+    jobs["G1"] = _Job(tab, DP_FEATS, [a_frag(7)])      # rows 0..255 feats, 256.. sigma (DP_SIGMA = DP_FEATS + 16)
+    jobs["G2"] = _Job(tab, DP_RGBH, [ACT_FEATS])
+    jobs["S2"] = _Job(tab, DP_S2, [ACT_S1])
+    jobs["S3"] = _Job(tab, DP_S3, [ACT_S2])
+    jobs["H"] = _Job(tab, DP_HEAD, [ACT_RGBH, ACT_S3, ACT_E1])
 
     gidx = np.full(n_params, -1, np.int64)
     gscale = np.zeros(n_params, np.float32)
@@ -348,5 +388,5 @@ def backward_maps(feat=256, tau=4):
     put("sun_v_net.6.bias", jobs["H"], inv16[[3]], "aux", AUXC.AUX_ONE)
     put("beta_from_xyz.2.weight", jobs["H"], inv16[[4]], 2, inv128)
     put("beta_from_xyz.2.bias", jobs["H"], inv16[[4]], "aux", AUXC.AUX_ONE)
-    return dict(idx=idx, scale=scale, blocks=np.asarray(blocks, np.int32), gidx=gidx.astype(np.int32), gscale=gscale,
+    return dict(idx=idx, scale=scale, blocks=tab.table(), block_rows=tab.rows, block_cols=tab.cols, gidx=gidx.astype(np.int32), gscale=gscale,
                 n_params=n_params, auxs=auxs, offsets=offsets)

@@ -168,11 +168,12 @@ class Emulator:
         slotmat = lambda fr: np.concatenate([f.reshape(2, 32, 8).transpose(0, 2, 1).reshape(16, 32) for f in fr], 0)  # noqa: E731
         partial = np.zeros((bm["blocks"].shape[0], packing.WG_BLOCK_FLOATS))
         aux_m = slotmat(acts[0:self.auxs])
-        for b, (rf0, nr, cf0, nc, kind, *_) in enumerate(bm["blocks"]):
-            r = slotmat(dpre[rf0:rf0 + nr])
+        for b, (rows, cols) in enumerate(zip(bm["block_rows"], bm["block_cols"])):
+            nr, nc = len(rows), len(cols)
+            r = slotmat([dpre[f] for f in rows])
             main, aux = partial[b, :256 * 256].reshape(256, 256), partial[b, 256 * 256:].reshape(256, 32)
             if nc > 0:
-                main[:16 * nr, :16 * nc] = r @ slotmat(acts[cf0:cf0 + nc]).T
+                main[:16 * nr, :16 * nc] = r @ slotmat([acts[f] for f in cols]).T
             aux[:16 * nr, :16 * self.auxs] = r @ aux_m.T
         pf = partial.reshape(-1)
         grad = np.where(bm["gidx"] >= 0, pf[np.maximum(bm["gidx"], 0)] * bm["gscale"], 0.0)

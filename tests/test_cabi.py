@@ -68,14 +68,14 @@ def test_wgrad_plan_host_only(handle):
         n = ctypes.c_int(0)
         rc = handle.sr_wgrad_plan(blocks.ctypes.data_as(ctypes.c_void_p), blocks.shape[0], n_points, n_wg, ctypes.byref(n))
         assert rc == 0
-        ns, first = blocks[:, 5], blocks[:, 6]
+        ns, first = blocks[:, 9], blocks[:, 10]
         tiles = (n_points + 31) // 32
         assert (ns >= 1).all() and (ns <= tiles).all()
         assert (first == np.concatenate([[0], np.cumsum(ns)[:-1]])).all() and n.value == ns.sum()
         assert n.value <= max(n_wg, blocks.shape[0])
         if tiles >= 1024 and n_wg >= 2 * blocks.shape[0]:
             assert n.value > n_wg - blocks.shape[0]  # the launch fills the chip
-        assert (blocks[:, :5] == blocks0[:, :5]).all()
+        assert (blocks[:, :9] == blocks0[:, :9]).all()
     bad = np.ascontiguousarray(blocks0.copy())
     bad[0, 1] = 17
     assert handle.sr_wgrad_plan(bad.ctypes.data_as(ctypes.c_void_p), bad.shape[0], 65536, 256, ctypes.byref(n)) != 0

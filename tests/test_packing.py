@@ -72,7 +72,7 @@ def test_emulated_backward_dataflow_matches_autograd(tau):
     em.forward_tile(xyz.numpy(), sun.numpy(), t.detach().numpy())
     grad, d_t = em.backward_tile(ga.numpy(), gs.numpy(), gv.numpy(), gb.numpy())
     bm = packing.backward_maps(256, tau)
-    assert bm["blocks"].shape == (17, 8) and (bm["gidx"] < 0).sum() == 899  # only the sky head is produced elsewhere
+    assert bm["blocks"].shape == (14, 12) and (bm["gidx"] < 0).sum() == 899  # only the sky head is produced elsewhere
     for k, (o, shp) in bm["offsets"].items():
         if k.startswith("sky"):
             continue
