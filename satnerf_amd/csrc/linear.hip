@@ -161,19 +161,33 @@ __device__ __forceinline__ void put_k4(uint16_t* plane_hi, int row, int k, const
   *reinterpret_cast<uint2*>(plane_hi + row * kRow + k) = hi;
   *reinterpret_cast<uint2*>(plane_hi + kPlane + row * kRow + k) = lo;
 }
-// 4 consecutive tile rows at one k -> transposed 2-byte stores
-__device__ __forceinline__ void put_r4(uint16_t* plane_hi, int row, int k, const Vec4& x) {
-  uint2 hi, lo;
-  split4(x, hi, lo);
-  uint16_t* p = plane_hi + row * kRow + k;
-  p[0] = (uint16_t)hi.x, p[kRow] = (uint16_t)(hi.x >> 16), p[2 * kRow] = (uint16_t)hi.y, p[3 * kRow] = (uint16_t)(hi.y >> 16);
-  p += kPlane;
-  p[0] = (uint16_t)lo.x, p[kRow] = (uint16_t)(lo.x >> 16), p[2 * kRow] = (uint16_t)lo.y, p[3 * kRow] = (uint16_t)(lo.y >> 16);
+// Row-major operands (memory runs along the tile's ROW index: DX B, DW A and B) are staged as "fragments", the layout the
+// weight-gradient kernel uses (wgrad.hip): fragment f = rows 16f..16f+15 of the tile x 32 k, made of 16-byte units
+// (hslot h, k) = rows 16f + 8h .. +7 at one k; [hslot 0: k = 0..31][hslot 1 rotated by 8 k][64 B gap].  A thread stores 8
+// consecutive rows of one k with ONE 16-byte store per plane, and ds_read_b64_tr_b16 hands every lane the 8 consecutive k of
+// its row -- the same operand the k-major image gives through ds_read_b128.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int kFragBytes = 1088, kFragPlane = 8 * kFragBytes;  // 8 fragments = 128 rows; bytes per plane (<= 2 * kPlane)
+__device__ __forceinline__ void put_r8(char* plane_hi, int row8, int k, const Vec4& x0, const Vec4& x1) {
+  uint2 h0, l0, h1, l1;
+  split4(x0, h0, l0), split4(x1, h1, l1);
+  const int f = row8 >> 1, pos = (row8 & 1) ? 32 + ((k + 8) & 31) : k;
+  char* p = plane_hi + f * kFragBytes + pos * 16;
+  *reinterpret_cast<uint4*>(p) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  *reinterpret_cast<uint4*>(p + kFragPlane) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+// MFMA operand (8 bf16 per lane: row lane&31 of the 32-row pair `frag_pair`, k = 16 ks + 8 (lane>>5) .. +7) from a fragment plane
+__device__ __forceinline__ uint4 operand_tr(const char* plane, int frag_pair, int off0, int off1) {
+  const char* p = plane + frag_pair * 2 * kFragBytes;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + off0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + off1));
+  const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+  return make_uint4(a.x, a.y, b.x, b.y);
 }
 
 // Staging.  Operands whose memory runs along the contraction index (FWD A and B, DX A) are moved as 4 consecutive k of one row
 // per thread (thread -> k = 4*(t&7), rows (t>>3) + 32*it: the row pointers are computed once per kernel); operands whose memory
-// runs along the row index (DX B, DW A and B) as 4 consecutive rows at one k (thread -> rows 4*(t&31), k = (t>>5) + 8*it).
+// runs along the row index (DX B, DW A and B) as 8 consecutive rows at one k (thread -> rows 8*(t&15), k = (t>>4) + 16*it).
 // 4 waves per SIMD (<= 128 VGPRs, a handful of spilled values): the kernel is single-buffered and lives on occupancy to hide its
 // global-load latency -- 512 x 512 forward 316 -> 244 us against 3 waves at 168 VGPRs; prefetching the next tile into registers
 // instead (200 VGPRs, 2 waves) was slower, 365 us.
@@ -189,7 +203,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
   if (k_end > q.K) k_end = q.K;
   const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
   const int kq = (tid & 7) * 4, rq = tid >> 3;        // k-major staging
-  const int r4 = (tid & 31) * 4, kr = tid >> 5;       // row-major staging
+  const int r8 = tid & 15, kr = tid >> 4;             // row-major staging: 8 rows 8*r8.. at k = kr + 16*it
+  char* const frag_a = reinterpret_cast<char*>(lds_a);
+  char* const frag_b = reinterpret_cast<char*>(lds_b);
+  // transposed-read offsets of this lane (wgrad.hip): lane = (hh, rh, m, qq); k = 16 ks + 8 hh + 4 rd + m
+  int tr_off[2][2];
+  {
+    const int hh = lane >> 5, rh = (lane >> 4) & 1, m = (lane >> 2) & 3, qq = lane & 3;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int rd = 0; rd < 2; ++rd) {
+        const int kk = 16 * ks + 8 * hh + 4 * rd + m;
+        tr_off[ks][rd] = rh * kFragBytes + ((qq >> 1) ? 512 + ((kk + 8) & 31) * 16 : kk * 16) + (qq & 1) * 8;
+      }
+  }
 
   // row pointers of the k-major operands (fixed over the k loop)
   const float *pa0[4] = {}, *pa1[4] = {}, *pb[4] = {};
@@ -240,14 +268,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
       }
     } else {  // DW: Aop(i = n, k = p) = G[p][n], memory along n
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int k = kr + 8 * it;
-        Vec4 x = zero4;
-        if (k < klim && i0 + r4 < q.M) {
+      for (int it = 0; it < 2; ++it) {
+        const int k = kr + 16 * it;
+        Vec4 x0 = zero4, x1 = zero4;
+        if (k < klim && i0 + 8 * r8 < q.M) {
           const long p = kt + k;
-          x = g4(q, q.gy + p * q.ldg, q.out_act != SR_OUT_NONE ? q.y + p * q.ldy : nullptr, (int)i0 + r4, (int)q.M);
+          const float *gr = q.gy + p * q.ldg, *yr = q.out_act != SR_OUT_NONE ? q.y + p * q.ldy : nullptr;
+          x0 = g4(q, gr, yr, (int)i0 + 8 * r8, (int)q.M), x1 = g4(q, gr, yr, (int)i0 + 8 * r8 + 4, (int)q.M);
         }
-        put_r4(lds_a, r4, k, x);
+        put_r8(frag_a, r8, k, x0, x1);
       }
     }
     // ---- B tile
@@ -260,23 +289,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
       }
     } else if (KIND == kDx) {  // Bop(j, k = n) = W[n][col0 + j], memory along j
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int k = kr + 8 * it;
-        Vec4 x = zero4;
-        if (k < klim && j0 + r4 < q.N) x = w4(q.w + (kt + k) * q.ldw + q.col0, (int)j0 + r4, (int)q.N);
-        put_r4(lds_b, r4, k, x);
+      for (int it = 0; it < 2; ++it) {
+        const int k = kr + 16 * it;
+        Vec4 x0 = zero4, x1 = zero4;
+        if (k < klim && j0 + 8 * r8 < q.N) {
+          const float* wr = q.w + (kt + k) * q.ldw + q.col0;
+          x0 = w4(wr, (int)j0 + 8 * r8, (int)q.N), x1 = w4(wr, (int)j0 + 8 * r8 + 4, (int)q.N);
+        }
+        put_r8(frag_b, r8, k, x0, x1);
       }
     } else {  // DW: Bop(j = f, k = p) = acat[p][f], memory along f
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int k = kr + 8 * it;
-        Vec4 x = zero4;
-        if (k < klim && j0 + r4 < q.N) {
+      for (int it = 0; it < 2; ++it) {
+        const int k = kr + 16 * it;
+        Vec4 x0 = zero4, x1 = zero4;
+        if (k < klim && j0 + 8 * r8 < q.N) {
           const long p = kt + k;
-          x = acat4(q, q.s[0].x + row_of(p, q.s[0].row_div) * q.s[0].ld,
-                    q.n_src > 1 ? q.s[1].x + row_of(p, q.s[1].row_div) * q.s[1].ld : nullptr, (int)j0 + r4, true);
+          const float* s0 = q.s[0].x + row_of(p, q.s[0].row_div) * q.s[0].ld;
+          const float* s1 = q.n_src > 1 ? q.s[1].x + row_of(p, q.s[1].row_div) * q.s[1].ld : nullptr;
+          x0 = acat4(q, s0, s1, (int)j0 + 8 * r8, true), x1 = acat4(q, s0, s1, (int)j0 + 8 * r8 + 4, true);
         }
-        put_r4(lds_b, r4, k, x);
+        put_r8(frag_b, r8, k, x0, x1);
       }
     }
     __syncthreads();
@@ -286,8 +319,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int ra = (wm * 64 + t * 32 + l31) * kRow + ks * 16 + h * 8, rb = (wn * 64 + t * 32 + l31) * kRow + ks * 16 + h * 8;
-        ah[t] = *reinterpret_cast<const uint4*>(lds_a + ra), al[t] = *reinterpret_cast<const uint4*>(lds_a + kPlane + ra);
-        bh[t] = *reinterpret_cast<const uint4*>(lds_b + rb), bl[t] = *reinterpret_cast<const uint4*>(lds_b + kPlane + rb);
+        if (KIND == kDw) {
+          ah[t] = operand_tr(frag_a, wm * 2 + t, tr_off[ks][0], tr_off[ks][1]);
+          al[t] = operand_tr(frag_a + kFragPlane, wm * 2 + t, tr_off[ks][0], tr_off[ks][1]);
+        } else {
+          ah[t] = *reinterpret_cast<const uint4*>(lds_a + ra), al[t] = *reinterpret_cast<const uint4*>(lds_a + kPlane + ra);
+        }
+        if (KIND != kFwd) {
+          bh[t] = operand_tr(frag_b, wn * 2 + t, tr_off[ks][0], tr_off[ks][1]);
+          bl[t] = operand_tr(frag_b + kFragPlane, wn * 2 + t, tr_off[ks][0], tr_off[ks][1]);
+        } else {
+          bh[t] = *reinterpret_cast<const uint4*>(lds_b + rb), bl[t] = *reinterpret_cast<const uint4*>(lds_b + kPlane + rb);
+        }
       }
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
