@@ -375,7 +375,7 @@ __device__ __forceinline__ float fetch_g(const LinParams& q, long p, int n) {
 }
 
 // d_bias[n] += sum_p G[p][n]: block = 64 columns x a slab of rows, thread (column, row phase), LDS reduce, one atomic per column
-constexpr int kColsumRows = 2048;
+constexpr int kColsumRows = 512;  // rows per block: enough blocks (and 4 loads in flight per thread) to run at memory speed
 __global__ void __launch_bounds__(256) colsum_kernel(const LinParams q) {
   __shared__ float part[4][64];
   const int c = threadIdx.x & 63, ph = threadIdx.x >> 6;
@@ -384,8 +384,13 @@ __global__ void __launch_bounds__(256) colsum_kernel(const LinParams q) {
   long p1 = p0 + kColsumRows;
   if (p1 > q.K) p1 = q.K;
   float s = 0.f;
-  if (n < q.M)
-    for (long p = p0 + ph; p < p1; p += 4) s += fetch_g(q, p, n);
+  if (n < q.M) {
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long p = p0 + ph;
+    for (; p + 12 < p1; p += 16) s += fetch_g(q, p, n), s1 += fetch_g(q, p + 4, n), s2 += fetch_g(q, p + 8, n), s3 += fetch_g(q, p + 12, n);
+    for (; p < p1; p += 4) s += fetch_g(q, p, n);
+    s += s1 + s2 + s3;
+  }
   part[ph][c] = s;
   __syncthreads();
   if (ph == 0 && n < q.M) unsafeAtomicAdd(q.dbias + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
