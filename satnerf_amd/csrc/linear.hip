@@ -436,20 +436,20 @@ using namespace sr;
 
 extern "C" int sr_points_along(const float* rays, int ray_stride, int dir_col, const float* z_vals, int64_t n_rays, int n_samples, float* xyz,
                                void* stream) {
-  SR_REQUIRE(rays && z_vals && xyz, "sr_points_along: null pointer");
   SR_REQUIRE(dir_col >= 3 && ray_stride >= dir_col + 3 && n_samples >= 1, "sr_points_along: bad layout (stride %d, dir_col %d)", ray_stride, dir_col);
   const long n = (long)n_rays * n_samples;
   if (n <= 0) return 0;
+  SR_REQUIRE(rays && z_vals && xyz, "sr_points_along: null pointer");
   hipLaunchKernelGGL(points_along_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rays, ray_stride, dir_col, z_vals, n,
                      n_samples, xyz);
   return check_launch("points_along_kernel");
 }
 
 extern "C" int sr_positional_map(const float* x, int ld, int dim, int64_t rows, int n_freqs, float* out, void* stream) {
-  SR_REQUIRE(x && out, "sr_positional_map: null pointer");
   SR_REQUIRE(dim >= 1 && ld >= dim && n_freqs >= 1 && n_freqs <= 24, "sr_positional_map: bad sizes (dim %d, ld %d, %d frequencies)", dim, ld, n_freqs);
   const long n = (long)rows * 2 * n_freqs * dim;
   if (n <= 0) return 0;
+  SR_REQUIRE(x && out, "sr_positional_map: null pointer");
   hipLaunchKernelGGL(positional_map_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, dim, (long)rows, n_freqs, out);
   return check_launch("positional_map_kernel");
 }

@@ -729,9 +729,9 @@ extern "C" int sr_composite_bwd(const float* z_vals, const float* sigma, const f
 extern "C" int sr_composite_image(const float* z_vals, const float* sigma, const float* noise, float noise_std, const float* albedo,
                                   const float* sun_v, const float* beta, const float* sky, int64_t n_rays, int n_samples, float* image,
                                   void* stream) {
+  if (n_rays <= 0) return 0;  // empty batch: nothing to do (empty tensors carry null pointers)
   SR_REQUIRE(z_vals && sigma && albedo && sun_v && beta && sky && image, "sr_composite_image: null pointer");
   SR_REQUIRE(n_samples >= 1, "sr_composite_image: n_samples must be >= 1");
-  if (n_rays <= 0) return 0;
   hipLaunchKernelGGL(composite_image_kernel, dim3((unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(256), 0, (hipStream_t)stream,
                      z_vals, sigma, noise, noise_std, albedo, sun_v, beta, sky, (long)n_rays, n_samples, image);
   return check_launch("composite_image_kernel");
@@ -739,9 +739,9 @@ extern "C" int sr_composite_image(const float* z_vals, const float* sigma, const
 
 extern "C" int sr_latlonalt_from_depth(const float* rays, int ray_stride, const float* depth, int64_t n_rays, const double* center, double range,
                                        double* lat, double* lon, double* alt, void* stream) {
+  if (n_rays <= 0) return 0;
   SR_REQUIRE(rays && depth && center && lat && lon && alt, "sr_latlonalt_from_depth: null pointer");
   SR_REQUIRE(ray_stride >= 6, "sr_latlonalt_from_depth: ray_stride must be >= 6 (got %d)", ray_stride);
-  if (n_rays <= 0) return 0;
   hipLaunchKernelGGL(latlonalt_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rays, ray_stride, depth,
                      (long)n_rays, center[0], center[1], center[2], range, lat, lon, alt);
   return check_launch("latlonalt_kernel");

@@ -175,6 +175,8 @@ def _linear_srcs(srcs, n_points):
         raise ValueError("a linear layer takes one or two concatenated sources")
     arr = (_lib.LinearSrc * len(srcs))()
     for a, (x, act, w0, row_div) in zip(arr, srcs):
+        if act not in ACTS:
+            raise ValueError(f"unknown activation {act!r} (one of {sorted(k for k in ACTS if k)})")
         x, ld = _rows(x, "linear source", 1)
         if x.shape[0] * row_div < n_points:
             raise ValueError(f"linear source has {x.shape[0]} rows x row_div {row_div} < {n_points} points")
@@ -184,6 +186,8 @@ def _linear_srcs(srcs, n_points):
 
 def linear_fwd(srcs, weight, bias, n_points, out_act=None):
     """One nn.Linear on the concatenation of ``srcs`` (activation applied on load) -> (P, n_out) fp32, see sr_linear_fwd."""
+    if out_act not in OUT_ACTS:
+        raise ValueError(f"unknown output activation {out_act!r} (one of {sorted(k for k in OUT_ACTS if k)})")
     arr = _linear_srcs(srcs, n_points)
     n_out = weight.shape[0]
     if weight.shape[1] != sum(x.shape[1] for x, *_ in srcs):

@@ -494,3 +494,46 @@ def test_classic_nerf_golden_coarse_and_fine():
     out = models["coarse"](torch.rand(70, 3, device=DEV) * 4, input_dir=torch.rand(70, 3, device=DEV))
     assert out.shape == (70, 4) and torch.isfinite(out).all()
     assert models["coarse"](torch.rand(70, 3, device=DEV), sigma_only=True).shape == (70, 1)
+
+
+def test_edge_cases_empty_and_ragged_inputs_of_the_newer_entry_points():
+    """Zero rays, sample counts that are not a multiple of the 64-lane wave, one-ray batches and bad arguments for the entry
+    points added after the first parity round (image outputs, lat/lon/alt, layer path, wgrad plan)."""
+    import numpy as np
+
+    ops, rendering, load_model = _lazy()
+    # zero-size calls return empty results without launching
+    z0 = torch.empty(0, 50, device=DEV)
+    img = ops.composite_image(z0, z0, None, 0.0, torch.empty(0, 50, 3, device=DEV), z0, z0, torch.empty(0, 3, device=DEV))
+    assert img.shape == (0, 13)
+    lat, lon, alt = ops.latlonalt_from_depth(torch.empty(0, 11, device=DEV), torch.empty(0, device=DEV), np.zeros(3), 1.0)
+    assert lat.shape == (0,) and lat.dtype == torch.float64
+    assert ops.positional_map(torch.empty(0, 3, device=DEV), 10).shape == (0, 60)
+    # S = 50 (ragged wave) image outputs equal the reductions of the full outputs; a single ray works
+    args = O.default_args(n_samples=50, mlp_mode="bf16x3")
+    models = build_models(args)
+    rays, ts = O.synthetic_rays(33, seed=71)
+    rays, ts = rays.to(DEV), ts.to(DEV)
+    g = torch.Generator().manual_seed(72)
+    draws = [torch.rand(33, 50, generator=g).to(DEV), torch.randn(33, 50, generator=g).to(DEV)]
+    with torch.no_grad(), rendering.replay_rng(draws):
+        full = rendering.render_rays(models, args, rays, ts)
+    with rendering.replay_rng(draws):
+        img = rendering.render_image_outputs(models, rays, ts, args)
+    want = O.image_outputs({k: v.cpu() for k, v in full.items()}, "coarse")
+    for k, v in want.items():
+        assert maxnorm_rel(img[k].cpu(), v) < 1e-5, k
+    with rendering.replay_rng([d[:1] for d in draws]):
+        one = rendering.render_image_outputs(models, rays[:1], ts[:1], args)
+    assert maxnorm_rel(one["rgb"].cpu(), img["rgb"][:1].cpu()) < 1e-6
+    # argument errors are Python exceptions, not launches
+    with pytest.raises(ValueError):
+        ops.linear_fwd([(torch.zeros(4, 8, device=DEV), "tanh", 1.0, 1)], torch.zeros(3, 8, device=DEV), None, 4)  # unknown activation
+    with pytest.raises((ValueError, KeyError)):
+        ops.linear_fwd([(torch.zeros(4, 8, device=DEV), None, 1.0, 1)], torch.zeros(3, 9, device=DEV), None, 4)    # weight / source mismatch
+    with pytest.raises(ValueError):
+        ops.latlonalt_from_depth(rays, torch.zeros(5, device=DEV), np.zeros(3), 1.0)                               # depth count
+    with pytest.raises(RuntimeError):
+        rendering.render_image_outputs(models, rays.cpu(), ts.cpu(), args)                                         # no CPU path
+    with pytest.raises(NotImplementedError):
+        load_model(O.default_args(model="s-nerf"))
