@@ -130,6 +130,12 @@ int sr_embedding_bwd(const float* d_t, const int64_t* ts, int64_t n_rays, int n_
  *   the loss partial sums (ceil(N/4)) and optionally the rendered rgb (N,3). */
 int sr_ray_setup(const float* rays, int ray_stride, const float* u, int64_t n_rays, int n_samples, int hidden, const float* w1,
                  const float* b1, const float* w2, const float* b2, float* z_vals, float* sky, void* stream);
+/* the same with the stratified jitter u ~ U[0,1) (rendering.py:77) drawn INSIDE the kernel: Philox-4x32-10 keyed by `seed`,
+ * counter = (ray, sample, step) with the step read from the 1-float device counter `step_counter` (NULL = 0; the counter
+ * sr_pack_all ticks) -- a captured training step then needs no RNG launch */
+int sr_ray_setup_rng(const float* rays, int ray_stride, uint64_t seed, const float* step_counter, int64_t n_rays, int n_samples,
+                     int hidden, const float* w1, const float* b1, const float* w2, const float* b2, float* z_vals, float* sky,
+                     void* stream);
 int sr_render_loss(const float* z_vals, const float* sigma, const float* noise, float noise_std, const float* albedo,
                    const float* sun_v, const float* beta, const float* sky, const float* target, int64_t n_rays, int n_samples,
                    float beta_min, float* loss_parts, float* rgb, float* d_sigma, float* d_albedo, float* d_sun_v, float* g_beta,

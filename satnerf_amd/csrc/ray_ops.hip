@@ -116,14 +116,27 @@ __global__ void __launch_bounds__(256) sky_kernel(const float* __restrict__ sun,
 }
 
 // ---- sampling + sky head in one launch (training fast path), one wave per ray ---------------------------------------------------
+// Philox-4x32-10 (Salmon et al., SC'11): counter-based, so a captured launch draws fresh jitter on every replay from a
+// device-side step counter -- no RNG kernel, no generator-state bookkeeping in the graph.
+__device__ __forceinline__ void philox4x32(uint32_t k0, uint32_t k1, uint32_t c[4]) {
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[0] = n0, c[1] = (uint32_t)p1, c[2] = n2, c[3] = (uint32_t)p0;
+    k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+  }
+}
+
 __global__ void __launch_bounds__(256) ray_setup_kernel(const float* __restrict__ rays, int ray_stride, const float* __restrict__ u, long n_rays,
                                                        int S, int hidden, const float* __restrict__ w1, const float* __restrict__ b1,
                                                        const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ z_out,
-                                                       float* __restrict__ sky) {
+                                                       float* __restrict__ sky, unsigned long long seed, const float* __restrict__ step_counter) {
   const int lane = threadIdx.x & 63;
   const long r = (long)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
   if (r >= n_rays) return;
   const float* ray = rays + r * ray_stride;
+  const uint32_t rng_step = step_counter ? (uint32_t)step_counter[0] : 0u;
   {
 #pragma clang fp contract(off)
     const float near = ray[6], far = ray[7];
@@ -134,7 +147,15 @@ __global__ void __launch_bounds__(256) ray_setup_kernel(const float* __restrict_
       if (j > 0) lower = 0.5f * (lerp_near_far(near, far, linspace01(j - 1, S, step)) + zj);
       if (j < S - 1) upper = 0.5f * (zj + lerp_near_far(near, far, linspace01(j + 1, S, step)));
       const float span = upper - lower;
-      const float jit = span * u[r * S + j];
+      float uj;
+      if (u) {
+        uj = u[r * S + j];
+      } else {  // uniform in [0,1) with 24 random bits: counter = (ray, sample / 4, step), key = seed
+        uint32_t c[4] = {static_cast<uint32_t>(r), static_cast<uint32_t>(static_cast<unsigned long long>(r) >> 32), static_cast<uint32_t>(j >> 2), rng_step};
+        philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), c);
+        uj = (float)(c[j & 3] >> 8) * 5.9604644775390625e-8f;
+      }
+      const float jit = span * uj;
       z_out[r * S + j] = lower + jit;
     }
   }
@@ -684,7 +705,19 @@ extern "C" int sr_ray_setup(const float* rays, int ray_stride, const float* u, i
   SR_REQUIRE(ray_stride >= 11 && n_samples >= 2, "sr_ray_setup: ray_stride>=11 and n_samples>=2 required");
   if (n_rays <= 0) return 0;
   hipLaunchKernelGGL(ray_setup_kernel, dim3((unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(256), 0, (hipStream_t)stream, rays,
-                     ray_stride, u, (long)n_rays, n_samples, hidden, w1, b1, w2, b2, z_vals, sky);
+                     ray_stride, u, (long)n_rays, n_samples, hidden, w1, b1, w2, b2, z_vals, sky, 0ull, (const float*)nullptr);
+  return check_launch("ray_setup_kernel");
+}
+
+extern "C" int sr_ray_setup_rng(const float* rays, int ray_stride, uint64_t seed, const float* step_counter, int64_t n_rays, int n_samples,
+                                int hidden, const float* w1, const float* b1, const float* w2, const float* b2, float* z_vals, float* sky,
+                                void* stream) {
+  SR_REQUIRE(rays && w1 && b1 && w2 && b2 && z_vals && sky, "sr_ray_setup_rng: null pointer");
+  SR_REQUIRE(ray_stride >= 11 && n_samples >= 2, "sr_ray_setup_rng: ray_stride>=11 and n_samples>=2 required");
+  if (n_rays <= 0) return 0;
+  hipLaunchKernelGGL(ray_setup_kernel, dim3((unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(256), 0, (hipStream_t)stream, rays,
+                     ray_stride, (const float*)nullptr, (long)n_rays, n_samples, hidden, w1, b1, w2, b2, z_vals, sky, (unsigned long long)seed,
+                     step_counter);
   return check_launch("ray_setup_kernel");
 }
 

@@ -127,7 +127,11 @@ class Trainer:
         p = self.state.params
         self.exp_avg, self.exp_avg_sq = torch.zeros_like(p), torch.zeros_like(p)
         self.n_steps = 0
-        self.adam_state = torch.zeros(1, dtype=torch.float32, device=p.device)  # optimizer step count for the in-graph Adam
+        # device-side step counter, ticked by the step's first launch: the in-graph Adam's step count and the step of the
+        # in-kernel jitter RNG of captured steps
+        self.adam_state = torch.zeros(1, dtype=torch.float32, device=p.device)
+        self._kernel_rng = False
+        self._seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
         self._adam_in_graph = False
         self.loss_fn = loss_fn
         self.direct = (loss_fn is None and p.is_cuda and getattr(args, "sc_lambda", 0.0) == 0 and args.n_importance == 0
@@ -148,15 +152,19 @@ class Trainer:
         n, s = rays.shape[0], args.n_samples
         mode = _mode_of(args)
         feat, tau = model.feat, model.t_embedding_dims
-        model.repack(mode, backward=True, tick=self.adam_state if (self.world == 1 and self._adam_in_graph) else None)
+        ticking = self._kernel_rng or (self.world == 1 and self._adam_in_graph)
+        model.repack(mode, backward=True, tick=self.adam_state if ticking else None)
         hi, lo, l0 = model.packed(mode)
         bstream, maps = model.packed_backward()
         sk = model.sky_color
-        u = torch.rand(n, s, device=rays.device)  # rendering.py:77
+        # stratified jitter (rendering.py:77): torch's generator when run eagerly; inside a captured step the kernel draws it
+        # itself (Philox keyed by the seed, stepping with the device counter) -- one launch and the graph's RNG bookkeeping less
+        u = None if self._kernel_rng else torch.rand(n, s, device=rays.device)
         noise_std = float(args.noise_std)
         # models/satnerf.py:58 draws randn even when noise_std == 0; the draw is skipped then (results are identical)
         nz = torch.randn(n, s, device=rays.device) if noise_std != 0 else None
-        z, sky = ops.ray_setup(rays, u, s, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data)
+        z, sky = ops.ray_setup(rays, u, s, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data, seed=self._seed,
+                               step_counter=self.adam_state)
         acts = ops.acts_workspace(n * s, feat, rays.device)
         albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, 3:6], rays[:, 8:11], z, emb.weight.data, ts, n * s, s, feat, tau, mode,
                                                      hi, lo, l0, acts=acts)
@@ -193,9 +201,10 @@ class Trainer:
         hi, lo, l0 = model.packed(mode)
         bstream, maps = model.packed_backward()
         sk = model.sky_color
-        u = torch.rand(n, s, device=rays.device)
+        u = None if self._kernel_rng else torch.rand(n, s, device=rays.device)
         nz = torch.randn(n, s, device=rays.device) if noise_std != 0 else None
-        z, sky = ops.ray_setup(rays, u, s, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data)
+        z, sky = ops.ray_setup(rays, u, s, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data, seed=self._seed + 1,
+                               step_counter=self.adam_state)
         acts = ops.acts_workspace(n * s, feat, rays.device)
         albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, 3:6], rays[:, 8:11], z, emb.weight.data, ts, n * s, s, feat, tau, mode,
                                                      hi, lo, l0, acts=acts)
@@ -214,6 +223,7 @@ class Trainer:
     def _capture(self, inputs):
         self._static = tuple(t.clone() for t in inputs)
         self._adam_in_graph = self.world == 1
+        self._kernel_rng = float(self.args.noise_std) == 0.0  # (a noisy step still draws randn from torch's generator)
         snapshot = (self.state.params.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.adam_state.clone())
         run = lambda: self._forward_backward(*self._static[:3], depth=self._static[3:] or None)  # noqa: E731
         side = torch.cuda.Stream()

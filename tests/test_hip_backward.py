@@ -405,3 +405,37 @@ def test_classic_nerf_gradients_and_training():
     assert not tr.direct
     losses = [tr.step(rays.to(DEV), None, target.to(DEV)).item() for _ in range(8)]
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
+
+
+def test_in_kernel_jitter_is_uniform_reproducible_and_steps():
+    """sr_ray_setup_rng: the Philox jitter lands every depth inside its stratum, is uniform, repeats for the same (seed, step)
+    and changes with either; the sky head equals the plain launch."""
+    from satnerf_amd import ops
+    from satnerf_amd.models import load_model
+
+    m = load_model(O.default_args()).to(DEV)
+    sk = m.sky_color
+    w = (sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data)
+    rays, _ = O.synthetic_rays(2048, seed=81)
+    rays = rays.to(DEV)
+    step = torch.zeros(1, device=DEV)
+    z0, sky0 = ops.ray_setup(rays, None, 64, *w, seed=123, step_counter=step)
+    z0b, _ = ops.ray_setup(rays, None, 64, *w, seed=123, step_counter=step)
+    assert torch.equal(z0, z0b)
+    step += 1
+    z1, _ = ops.ray_setup(rays, None, 64, *w, seed=123, step_counter=step)
+    z2, _ = ops.ray_setup(rays, None, 64, *w, seed=124, step_counter=step)
+    assert not torch.equal(z0, z1) and not torch.equal(z1, z2)
+    lo, sky_ref = ops.ray_setup(rays, torch.zeros(2048, 64, device=DEV), 64, *w)
+    hi, _ = ops.ray_setup(rays, torch.ones(2048, 64, device=DEV), 64, *w)
+    assert torch.equal(sky0, sky_ref)
+    u = ((z1 - lo) / (hi - lo)).flatten()
+    assert (u >= 0).all() and (u < 1.0 + 1e-6).all()
+    assert abs(u.mean().item() - 0.5) < 5e-3 and abs(u.var().item() - 1 / 12) < 2e-3
+    hist = torch.histc(u.clamp(0, 1 - 1e-7), bins=16, min=0, max=1) / u.numel()
+    assert (hist - 1 / 16).abs().max().item() < 4e-3
+    # neighbouring samples and rays are uncorrelated
+    uu = ((z1 - lo) / (hi - lo))
+    c1 = torch.corrcoef(torch.stack([uu[:, :-1].flatten(), uu[:, 1:].flatten()]))[0, 1].abs().item()
+    c2 = torch.corrcoef(torch.stack([uu[:-1].flatten(), uu[1:].flatten()]))[0, 1].abs().item()
+    assert c1 < 2e-2 and c2 < 2e-2
