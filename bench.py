@@ -206,7 +206,7 @@ def main():
         roof = {"bound": "hbm", "achieved": kernels[dom]["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
     # HBM bytes per launch from the PMC passes committed in profiles/r01_train_pmc.csv (2*FETCH_SIZE + WRITE_SIZE, KiB, gfx950
     # correction per MI355X_MICROARCH.md); rocprofv3 counters cannot be read from inside this process
-    pmc_traffic = {"mlp_fwd": 389.7e6 + 12.5e6, "mlp_bwd": 366.9e6 + 391.1e6, "wgrad": 858.6e6 + 61.9e6} if phase == "train" else {}
+    pmc_traffic = {"mlp_fwd": 389.7e6 + 12.5e6, "mlp_bwd": 366.9e6 + 391.1e6, "wgrad": 860.6e6 + 61.9e6} if phase == "train" else {}
     roof.update(kernel=KERNEL_NAMES[dom], frac=roof["achieved"] / roof["peak"], traffic=pmc_traffic.get(dom), kernel_ms=k_ms,
                 algorithmic_flop_per_launch=kernels[dom]["flop"], algorithmic_bytes_per_launch=kernels[dom]["bytes"],
                 timing="HIP events around eager launches of the same step, after the timed region", all_kernels=kernels)
