@@ -128,6 +128,11 @@ int sr_embedding_bwd(const float* d_t, const int64_t* ts, int64_t n_rays, int n_
  * sr_render_loss = sr_composite_fwd -> sr_satnerf_loss -> sr_composite_bwd for n_samples <= 64, one wave per ray:
  *   outputs the MLP-backward inputs d_sigma (N,S), d_albedo (N,S,3), d_sun_v (N,S), g_beta (N,S), the per-ray d_sky (N,3),
  *   the loss partial sums (ceil(N/4)) and optionally the rendered rgb (N,3). */
+/* sr_depth_loss: metrics.DepthLoss for the coarse model (metrics.py:75-92; main.py:134-141): value = sum(loss_parts[0 ..
+ * ceil(N/256))) = lambda_ds/3 * mean(w * (depth - target)^2), g_depth (N) its gradient; depths (N, stride) = [target, weight, ...],
+ * use_weights = 0 is --ds_noweights. */
+int sr_depth_loss(const float* depth, const float* depths, int depths_stride, int use_weights, int64_t n_rays, float lambda_ds,
+                  float* loss_parts, float* g_depth, void* stream);
 int sr_ray_setup(const float* rays, int ray_stride, const float* u, int64_t n_rays, int n_samples, int hidden, const float* w1,
                  const float* b1, const float* w2, const float* b2, float* z_vals, float* sky, void* stream);
 /* the same with the stratified jitter u ~ U[0,1) (rendering.py:77) drawn INSIDE the kernel: Philox-4x32-10 keyed by `seed`,

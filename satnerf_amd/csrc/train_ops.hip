@@ -53,6 +53,28 @@ __global__ void __launch_bounds__(256) satnerf_loss_kernel(const float* __restri
   }
 }
 
+// ---- metrics.DepthLoss (metrics.py:75-92), coarse model: lambda_ds/3 * mean(w * (depth - target)^2) and its gradient ------------
+// depths (N, stride) = [target, weight, ...] (datasets/satellite_depth.py); use_weights = 0 is ds_noweights (main.py:137).
+// Block b writes its share of the value to loss_parts[b].
+__global__ void __launch_bounds__(256) depth_loss_kernel(const float* __restrict__ depth, const float* __restrict__ depths, int stride,
+                                                        int use_weights, long n, float lam, float* __restrict__ loss_parts,
+                                                        float* __restrict__ g_depth) {
+  __shared__ float part[4];
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  float contrib = 0.f;
+  if (r < n) {
+    const float diff = depth[r] - depths[r * stride];
+    const float w = use_weights ? depths[r * stride + 1] : 1.f;
+    const float inv_n = 1.0f / (float)n;
+    contrib = lam * w * diff * diff * inv_n;
+    g_depth[r] = 2.0f * lam * w * diff * inv_n;
+  }
+  contrib = wave_sum_f(contrib);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = contrib;
+  __syncthreads();
+  if (threadIdx.x == 0) loss_parts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
 // ---- fused per-ray training kernel: compositing forward -> SatNerf loss -> compositing backward ---------------------------
 // One wave per ray (lane = sample, S <= 64).  Replaces models/satnerf.py:52-70 + metrics.py:21-25,56-73 + their autograd in ONE
 // launch: the wave already holds alpha, T, w for the whole ray, so the loss gradient (which needs the ray sums beta_r, rgb_r) and
@@ -221,6 +243,16 @@ extern "C" int sr_satnerf_loss(const float* rgb, const float* weights, const flo
   hipLaunchKernelGGL(satnerf_loss_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rgb, weights, beta, target,
                      (long)n_rays, n_samples, beta_min, grad_scale, loss_parts, g_rgb, g_weights, g_beta);
   return check_launch("satnerf_loss_kernel");
+}
+
+extern "C" int sr_depth_loss(const float* depth, const float* depths, int depths_stride, int use_weights, int64_t n_rays, float lambda_ds,
+                             float* loss_parts, float* g_depth, void* stream) {
+  if (n_rays <= 0) return 0;
+  SR_REQUIRE(depth && depths && loss_parts && g_depth, "sr_depth_loss: null pointer");
+  SR_REQUIRE(depths_stride >= (use_weights ? 2 : 1), "sr_depth_loss: depths_stride=%d too small", depths_stride);
+  hipLaunchKernelGGL(depth_loss_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, depth, depths, depths_stride,
+                     use_weights, (long)n_rays, lambda_ds / 3.0f, loss_parts, g_depth);
+  return check_launch("depth_loss_kernel");
 }
 
 extern "C" int sr_render_loss(const float* z_vals, const float* sigma, const float* noise, float noise_std, const float* albedo,

@@ -385,6 +385,16 @@ def pack_all(flat, idx, scale, hi, lo, f32_idx, f32_scale, f32_out, tick=None):
               _p(_chk(f32_idx, "f32_idx", torch.int32)), _p(_chk(f32_scale, "f32_scale")), f32_idx.numel(), _p(f32_out), _p(tick), _stream())
 
 
+def depth_loss(depth, depths, lambda_ds, use_weights=True):
+    """metrics.DepthLoss (coarse) value parts + gradient w.r.t. the rendered depth: (loss_parts, g_depth (N,))."""
+    depths, stride = _rows(depths, "depths", 2 if use_weights else 1)
+    n = depth.shape[0]
+    parts = torch.empty((n + 255) // 256, dtype=torch.float32, device=depth.device)
+    g = torch.empty(n, dtype=torch.float32, device=depth.device)
+    _lib.call("sr_depth_loss", _p(_chk(depth, "depth")), _p(depths), stride, int(use_weights), n, float(lambda_ds), _p(parts), _p(g), _stream())
+    return parts, g
+
+
 def ray_setup(rays, u, n_samples, w1, b1, w2, b2, seed=0, step_counter=None):
     """Fused sr_ray_sample_fwd + sr_sky_fwd: returns (z (N,S), sky (N,3)).  ``u`` = (N,S) uniform jitter, or None to draw it inside
     the kernel (Philox keyed by ``seed``, stepping with the 1-float device tensor ``step_counter``)."""

@@ -209,13 +209,9 @@ class Trainer:
         albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, 3:6], rays[:, 8:11], z, emb.weight.data, ts, n * s, s, feat, tau, mode,
                                                      hi, lo, l0, acts=acts)
         weights, transp, depth, _ = ops.composite(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky)
-        lam = float(args.ds_lambda) / 3.0
-        diff = depth - depths[:, 0]
-        w_diff = diff if getattr(args, "ds_noweights", False) else depths[:, 1] * diff
-        loss = lam * torch.mean(w_diff * diff)
-        g_depth = (2.0 * lam / n) * w_diff
+        loss, g_depth = ops.depth_loss(depth, depths, float(args.ds_lambda), use_weights=not getattr(args, "ds_noweights", False))
         d_sigma, _, _, _ = ops.composite_bwd(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky, weights, transp,
-                                             None, g_depth.contiguous(), None, None)
+                                             None, g_depth, None, None)
         dpre, _ = ops.satnerf_mlp_bwd(feat, tau, n * s, bstream, acts, albedo, sigma, sun_v, beta, None, d_sigma, None, None, want_dt=False)
         ops.satnerf_wgrad(feat, tau, n * s, dpre, acts, maps["blocks"], maps["gidx"], maps["gscale"], model.flat_grads(), accumulate=True)
         return loss
