@@ -62,3 +62,31 @@ class DepthBank(RayBank):
         if depths.dim() != 2 or depths.shape[1] != 2:
             raise ValueError("depths must be (N, 2) = [target depth, weight]")
         super().__init__(rays, torch.cat([depths.float(), torch.zeros_like(depths[:, :1], dtype=torch.float32)], 1), ts, batch_size, **kw)
+
+
+def sun_direction(sun_elevation_deg, sun_azimuth_deg):
+    """Unit sun vector of one image (``SatelliteDataset.get_sun_dirs``, datasets/satellite.py:232-244)."""
+    import math
+
+    el, az = math.radians(float(sun_elevation_deg)), math.radians(float(sun_azimuth_deg))
+    return torch.tensor([math.sin(az) * math.cos(el), math.cos(az) * math.cos(el), math.sin(el)], dtype=torch.float32)
+
+
+def rays_from_cache(cached_rays, center, scene_range, sun_elevation_deg, sun_azimuth_deg, device=None):
+    """The (HW, 11) fp32 ray block of one image from the reference's ``<cache_dir>/<img_id>.data`` file (``torch.save`` of the
+    (HW, 8) ECEF rays ``get_rays`` produced; datasets/satellite.py:185-196): scene normalisation of origin / near / far
+    (``normalize_rays``, :218-227) and the per-image sun direction appended (:199-211).  ``cached_rays`` = a path or the
+    loaded tensor; arithmetic in the cache's own dtype before the final cast, like the reference.  Host-side data plumbing
+    for ``RayBank``: the RPC localisation that writes the cache is not rebuilt."""
+    rays = torch.load(cached_rays) if isinstance(cached_rays, (str, bytes)) or hasattr(cached_rays, "__fspath__") else cached_rays
+    if rays.dim() != 2 or rays.shape[1] != 8:
+        raise ValueError(f"cached rays must be (HW, 8), got {tuple(rays.shape)}")
+    rays = rays.clone()
+    for c in range(3):
+        rays[:, c] -= center[c]
+        rays[:, c] /= scene_range
+    rays[:, 6] /= scene_range
+    rays[:, 7] /= scene_range
+    sun = sun_direction(sun_elevation_deg, sun_azimuth_deg).to(rays.dtype).expand(rays.shape[0], 3)
+    out = torch.hstack([rays, sun]).type(torch.float32)
+    return out if device is None else out.to(device)

@@ -83,3 +83,29 @@ def test_lightning_style_checkpoint_loads_by_reference_key_layout(tmp_path):
     assert models["coarse"].flat_params().numel() == 662537  # still one flat buffer after load
     with pytest.raises(FileNotFoundError):
         checkpoint.load_nerf(run, str(tmp_path / "logs"), str(tmp_path / "ckpts"), 9, device="cpu")
+
+
+def test_rays_from_reference_cache_format(tmp_path):
+    """data.rays_from_cache: the reference's <img_id>.data cache (torch.save of (HW,8) ECEF rays) -> normalised (HW,11) rays with
+    the sun direction, as SatelliteDataset.load_data assembles them (datasets/satellite.py:185-227,232-244)."""
+    import math
+
+    from satnerf_amd.data import rays_from_cache, sun_direction
+
+    g = torch.Generator().manual_seed(5)
+    center, rng = [794000.0, -5455000.0, 3200000.0], 431.7
+    o = torch.tensor(center, dtype=torch.float64) + (torch.rand(50, 3, generator=g, dtype=torch.float64) - 0.5) * 2 * rng
+    d = torch.nn.functional.normalize(torch.randn(50, 3, generator=g, dtype=torch.float64), dim=1)
+    ecef = torch.cat([o, d, torch.zeros(50, 1, dtype=torch.float64), 300 + 50 * torch.rand(50, 1, generator=g, dtype=torch.float64)], 1)
+    path = tmp_path / "JAX_068_001_RGB.data"
+    torch.save(ecef, path)
+    rays = rays_from_cache(str(path), center, rng, 47.5, 153.2)
+    assert rays.shape == (50, 11) and rays.dtype == torch.float32
+    assert torch.allclose(rays[:, 0:3].double(), (o - torch.tensor(center, dtype=torch.float64)) / rng, atol=1e-6)
+    assert torch.allclose(rays[:, 3:6].double(), d, atol=1e-7) and torch.allclose(rays[:, 7].double(), ecef[:, 7] / rng, atol=1e-6)
+    el, az = math.radians(47.5), math.radians(153.2)
+    want = torch.tensor([math.sin(az) * math.cos(el), math.cos(az) * math.cos(el), math.sin(el)])
+    assert torch.allclose(rays[:, 8:11], want.expand(50, 3), atol=1e-7) and abs(sun_direction(47.5, 153.2).norm().item() - 1) < 1e-6
+    assert torch.equal(torch.load(path), ecef)  # the cache itself is not modified
+    with pytest.raises(ValueError):
+        rays_from_cache(torch.zeros(4, 11), center, rng, 1, 2)
