@@ -439,3 +439,52 @@ def test_in_kernel_jitter_is_uniform_reproducible_and_steps():
     c1 = torch.corrcoef(torch.stack([uu[:, :-1].flatten(), uu[:, 1:].flatten()]))[0, 1].abs().item()
     c2 = torch.corrcoef(torch.stack([uu[:-1].flatten(), uu[1:].flatten()]))[0, 1].abs().item()
     assert c1 < 2e-2 and c2 < 2e-2
+
+
+def test_coarse_plus_fine_gradients_and_training():
+    """BASELINE configs[2] shape (coarse + fine with importance sampling) through autograd over the fused kernels: both models'
+    gradients against autograd through the oracle on the same draws; the trainer's step lowers the loss."""
+    from satnerf_amd import rendering
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    args = O.default_args(n_importance=32, mlp_mode="bf16x3")
+    pc, pf = O.procedural_satnerf_params(256, 4, seed=91), O.procedural_satnerf_params(256, 4, seed=92)
+    embw = O.procedural_uniform((30, 4), 1.0, 93)
+    models = {}
+    for typ, prm in (("coarse", pc), ("fine", pf)):
+        m = load_model(args)
+        m.load_state_dict(prm)
+        models[typ] = m.to(DEV)
+    emb = torch.nn.Embedding(30, 4)
+    emb.load_state_dict({"weight": embw})
+    models["t"] = emb.to(DEV)
+    n = 40
+    rays, ts = O.synthetic_rays(n, seed=94)
+    g = torch.Generator().manual_seed(95)
+    draws = [torch.rand(n, 64, generator=g), torch.randn(n, 64, generator=g), torch.rand(n, 32, generator=g), torch.randn(n, 96, generator=g)]
+    target = torch.rand(n, 3, generator=g)
+    loss_of = lambda r, t: sum(((r[f"rgb_{k}"] - t) ** 2).mean() + (r[f"weights_{k}"].unsqueeze(-1) * r[f"beta_{k}"]).sum() * 1e-2  # noqa: E731
+                               for k in ("coarse", "fine"))
+    po = {t: {k: v.clone().requires_grad_(True) for k, v in prm.items()} for t, prm in (("coarse", pc), ("fine", pf))}
+    eo = embw.clone().requires_grad_(True)
+    lo = loss_of(O.render_rays({"coarse": po["coarse"], "fine": po["fine"], "t": eo}, O.default_args(n_importance=32), rays, ts, O.ReplayRng(draws)), target)
+    lo.backward()
+    with rendering.replay_rng([d.to(DEV) for d in draws]):
+        res = rendering.render_rays(models, args, rays.to(DEV), ts.to(DEV))
+    assert res["weights_fine"].shape == (n, 96)
+    lh = loss_of(res, target.to(DEV))
+    lh.backward()
+    assert abs(lh.item() - lo.item()) < 1e-4 * abs(lo.item())
+    for typ in ("coarse", "fine"):
+        sd = dict(models[typ].named_parameters())
+        errs = {k: maxnorm_rel(sd[k].grad.cpu(), po[typ][k].grad) for k in po[typ]}
+        worst = max(errs, key=errs.get)
+        print(typ, "worst", worst, f"{errs[worst]:.1e}")
+        assert errs[worst] < GRAD_TOL, errs
+    assert maxnorm_rel(models["t"].weight.grad.cpu(), eo.grad) < GRAD_TOL
+    targs = O.default_args(n_importance=32, mlp_mode="bf16")
+    tr = Trainer(models, targs)
+    assert not tr.direct and tr.state.params.numel() == 2 * 662537 + 120
+    losses = [tr.step(rays.to(DEV), ts.to(DEV), target.to(DEV)).item() for _ in range(10)]
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
