@@ -131,6 +131,11 @@ int sr_embedding_bwd(const float* d_t, const int64_t* ts, int64_t n_rays, int n_
 /* sr_depth_loss: metrics.DepthLoss for the coarse model (metrics.py:75-92; main.py:134-141): value = sum(loss_parts[0 ..
  * ceil(N/256))) = lambda_ds/3 * mean(w * (depth - target)^2), g_depth (N) its gradient; depths (N, stride) = [target, weight, ...],
  * use_weights = 0 is --ds_noweights. */
+/* sr_sc_loss: the solar-correction terms of SNerfLoss / SatNerfLoss (metrics.py:27-34) for the pass rendered along the sun
+ * direction (rendering.py:102-108): compositing of that pass (z_vals, sigma[, noise]) -> value = sum(loss_parts[0 .. ceil(N/4))) =
+ * lambda_sc/3 * (mean_r sum_j (T_j - sun_j)^2 + mean_r (1 - sum_j w_j sun_j)), d_sun_v (N,S) its gradient (T, w detached). */
+int sr_sc_loss(const float* z_vals, const float* sigma, const float* noise, float noise_std, const float* sun_v, int64_t n_rays,
+               int n_samples, float lambda_sc, float* loss_parts, float* d_sun_v, void* stream);
 int sr_depth_loss(const float* depth, const float* depths, int depths_stride, int use_weights, int64_t n_rays, float lambda_ds,
                   float* loss_parts, float* g_depth, void* stream);
 int sr_ray_setup(const float* rays, int ray_stride, const float* u, int64_t n_rays, int n_samples, int hidden, const float* w1,

@@ -245,6 +245,65 @@ extern "C" int sr_satnerf_loss(const float* rgb, const float* weights, const flo
   return check_launch("satnerf_loss_kernel");
 }
 
+// ---- solar correction (metrics.py:27-34; rendering.py:102-108): the second pass renders the same depths along the SUN direction;
+// term2 = sum_j (T_j - sun_j)^2, term3 = 1 - sum_j w_j sun_j with T, w of that pass DETACHED -- only sun_sc carries a gradient.
+// One wave per ray: compositing forward of the pass (alpha, T, w) -> the two terms -> d loss / d sun_j, nothing else written.
+__global__ void __launch_bounds__(256) sc_loss_kernel(const float* __restrict__ z, const float* __restrict__ sigma,
+                                                     const float* __restrict__ noise, float noise_std, const float* __restrict__ sun_v,
+                                                     long n_rays, int S, float lam, float* __restrict__ loss_parts,
+                                                     float* __restrict__ d_sun) {
+  __shared__ float part[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long r = (long)blockIdx.x * 4 + wv;
+  const bool ray_on = r < n_rays;
+  const float inv_n = 1.0f / (float)n_rays;
+  float carry = 1.f, t2 = 0.f, t3 = 0.f;
+  for (int j0 = 0; j0 < S && ray_on; j0 += 64) {
+    const int j = j0 + lane;
+    const bool on = j < S;
+    const long i = r * S + (on ? j : S - 1);
+    float alpha = 0.f, sv = 0.f;
+    if (on) {
+#pragma clang fp contract(off)
+      const float zj = z[i];
+      const float delta = j < S - 1 ? z[i + 1] - zj : 1e10f;
+      float sg = sigma[i];
+      if (noise) sg = sg + noise[i] * noise_std;
+      alpha = 1.0f - expf(-delta * (sg > 0.f ? sg : 0.f));
+      sv = sun_v[i];
+    }
+    float f;
+    {
+#pragma clang fp contract(off)
+      f = on ? (1.0f - alpha) + 1e-10f : 1.f;
+    }
+    const float incl = wave_scan_mul_f(f, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.f;
+    const float T = carry * excl;
+    carry = carry * __shfl(incl, 63, 64);
+    if (on) {
+      const float w = alpha * T, e = T - sv;
+      t2 += e * e, t3 += w * sv;
+      d_sun[i] = lam * inv_n * (-2.0f * e - w);
+    }
+  }
+  t2 = wave_sum_f(t2), t3 = wave_sum_f(t3);
+  if (lane == 0) part[wv] = ray_on ? lam * inv_n * (t2 + 1.0f - t3) : 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0) loss_parts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+extern "C" int sr_sc_loss(const float* z_vals, const float* sigma, const float* noise, float noise_std, const float* sun_v, int64_t n_rays,
+                          int n_samples, float lambda_sc, float* loss_parts, float* d_sun_v, void* stream) {
+  if (n_rays <= 0) return 0;
+  SR_REQUIRE(z_vals && sigma && sun_v && loss_parts && d_sun_v, "sr_sc_loss: null pointer");
+  SR_REQUIRE(n_samples >= 1, "sr_sc_loss: n_samples must be >= 1");
+  hipLaunchKernelGGL(sc_loss_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z_vals, sigma, noise, noise_std, sun_v,
+                     (long)n_rays, n_samples, lambda_sc / 3.0f, loss_parts, d_sun_v);
+  return check_launch("sc_loss_kernel");
+}
+
 extern "C" int sr_depth_loss(const float* depth, const float* depths, int depths_stride, int use_weights, int64_t n_rays, float lambda_ds,
                              float* loss_parts, float* g_depth, void* stream) {
   if (n_rays <= 0) return 0;

@@ -385,6 +385,16 @@ def pack_all(flat, idx, scale, hi, lo, f32_idx, f32_scale, f32_out, tick=None):
               _p(_chk(f32_idx, "f32_idx", torch.int32)), _p(_chk(f32_scale, "f32_scale")), f32_idx.numel(), _p(f32_out), _p(tick), _stream())
 
 
+def sc_loss(z, sigma, noise, noise_std, sun_v, lambda_sc):
+    """Solar-correction terms of the pass along the sun direction: (loss_parts, d_sun_v (N,S))."""
+    n, s = z.shape
+    parts = torch.empty((n + 3) // 4, dtype=torch.float32, device=z.device)
+    d_sun = torch.empty(n, s, dtype=torch.float32, device=z.device)
+    _lib.call("sr_sc_loss", _p(_chk(z, "z")), _p(_chk(sigma, "sigma")), _p(_chk(noise, "noise", allow_none=True)), float(noise_std),
+              _p(_chk(sun_v, "sun_v")), n, s, float(lambda_sc), _p(parts), _p(d_sun), _stream())
+    return parts, d_sun
+
+
 def depth_loss(depth, depths, lambda_ds, use_weights=True):
     """metrics.DepthLoss (coarse) value parts + gradient w.r.t. the rendered depth: (loss_parts, g_depth (N,))."""
     depths, stride = _rows(depths, "depths", 2 if use_weights else 1)

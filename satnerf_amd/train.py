@@ -114,7 +114,7 @@ class Trainer:
     passed, the depth-supervision batch (main.py:134-141, metrics.DepthLoss) -- both backward passes accumulate into the same
     flat gradient buffer before the single all-reduce + Adam update.
 
-    Fast path (default loss, no solar correction, no fine model): the step calls the HIP kernels directly -- no autograd
+    Fast path (default loss, no fine model; solar correction and depth supervision included): the step calls the HIP kernels directly -- no autograd
     graph, fused loss+gradient kernel, fused Adam over the flat buffer -- and, when ``noise_std == 0``, replays the whole
     forward+backward from ONE hipGraph (the step is ~25 launches of 5-350 us; eager launch gaps would dominate).
     Anything else goes through ``render_rays`` + autograd + the same flat buffers.
@@ -134,8 +134,8 @@ class Trainer:
         self._seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
         self._adam_in_graph = False
         self.loss_fn = loss_fn
-        self.direct = (loss_fn is None and p.is_cuda and getattr(args, "sc_lambda", 0.0) == 0 and args.n_importance == 0
-                       and args.model == "sat-nerf" and getattr(models["coarse"], "fused", False))
+        self.direct = (loss_fn is None and p.is_cuda and args.n_importance == 0 and args.model == "sat-nerf"
+                       and getattr(models["coarse"], "fused", False))
         self.use_graph = use_graph and self.direct
         self._graph, self._static = None, None
         self.last_rgb = None
@@ -182,10 +182,33 @@ class Trainer:
         ops.grad_tail(partial, plan, maps["gidx"], maps["gscale"], model.flat_grads(), rays[:, 8:11], sk[0].weight.data, sk[0].bias.data,
                       sk[2].weight.data, sky, d_sky, sk[0].weight.grad, sk[0].bias.grad, sk[2].weight.grad, sk[2].bias.grad, d_t, ts, n, s, tau,
                       emb.weight.grad)
+        if float(getattr(args, "sc_lambda", 0.0)) > 0:
+            loss = torch.cat([loss.view(-1), self._sc_pass(rays, ts, z, noise_std).view(-1)])
         if depth is not None:
             loss = torch.cat([loss.view(-1), self._depth_pass(*depth, noise_std * 0.9).view(-1)])  # main.py:132 decays the noise first
         if self.world == 1 and self._adam_in_graph:  # no all-reduce to wait for: the update rides in the same graph
             ops.adam_step_graph(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.adam_state, lr=self.lr, zero_grad=True)
+        return loss
+
+    def _sc_pass(self, rays, ts, z, noise_std):
+        """Solar correction (rendering.py:102-108, metrics.py:27-34): the SAME depths along the sun direction; transparency and
+        weights of that pass are detached, so only sun visibility receives a gradient."""
+        from . import ops
+        from .rendering import _mode_of
+
+        model, emb, args = self.models["coarse"], self.models["t"], self.args
+        n, s = z.shape
+        mode = _mode_of(args)
+        feat, tau = model.feat, model.t_embedding_dims
+        hi, lo, l0 = model.packed(mode)
+        bstream, maps = model.packed_backward()
+        nz = torch.randn(n, s, device=rays.device) if noise_std != 0 else None
+        acts = ops.acts_workspace(n * s, feat, rays.device)
+        albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, 8:11], rays[:, 8:11], z, emb.weight.data, ts, n * s, s, feat, tau, mode,
+                                                     hi, lo, l0, acts=acts)
+        loss, d_sun = ops.sc_loss(z, sigma.view(n, s), nz, noise_std, sun_v.view(n, s), float(args.sc_lambda))
+        dpre, _ = ops.satnerf_mlp_bwd(feat, tau, n * s, bstream, acts, albedo, sigma, sun_v, beta, None, None, d_sun, None, want_dt=False)
+        ops.satnerf_wgrad(feat, tau, n * s, dpre, acts, maps["blocks"], maps["gidx"], maps["gscale"], model.flat_grads(), accumulate=True)
         return loss
 
     def _depth_pass(self, rays, ts, depths, noise_std):

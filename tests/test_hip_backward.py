@@ -488,3 +488,57 @@ def test_coarse_plus_fine_gradients_and_training():
     assert not tr.direct and tr.state.params.numel() == 2 * 662537 + 120
     losses = [tr.step(rays.to(DEV), ts.to(DEV), target.to(DEV)).item() for _ in range(10)]
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
+
+
+def test_direct_step_with_solar_correction_matches_autograd_path():
+    """sc_lambda > 0 on the kernel-direct path (second pass along the sun direction + sr_sc_loss) == render_rays under autograd +
+    the torch SatNerfLoss with solar correction, same jitter; and the captured step trains."""
+    from satnerf_amd import rendering
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer, satnerf_loss
+
+    args = O.default_args(mlp_mode="bf16x3", sc_lambda=0.1)
+    params = O.procedural_satnerf_params(256, 4, seed=101)
+    m = load_model(args)
+    m.load_state_dict(params)
+    emb = torch.nn.Embedding(30, 4)
+    emb.load_state_dict({"weight": O.procedural_uniform((30, 4), 1.0, 102)})
+    models = {"coarse": m.to(DEV), "t": emb.to(DEV)}
+    rays, ts = O.synthetic_rays(160, seed=103)
+    rays, ts = rays.to(DEV), ts.to(DEV)
+    target = torch.rand(160, 3, generator=torch.Generator().manual_seed(104)).to(DEV)
+    tr = Trainer(models, args, use_graph=False)
+    assert tr.direct
+    torch.manual_seed(11)
+    parts = tr._forward_backward(rays, ts, target)
+    g_direct = tr.state.grads.clone()
+    tr.state.zero_grad()
+    torch.manual_seed(11)
+    u = torch.rand(160, 64, device=DEV)
+    with rendering.replay_rng([u, torch.zeros_like(u), torch.zeros_like(u)]):
+        res = rendering.render_rays(models, args, rays, ts)
+    la = satnerf_loss(res, target, lambda_sc=0.1)
+    la.backward()
+    assert abs(parts.sum().item() - la.item()) < 1e-4 * abs(la.item()), (parts.sum().item(), la.item())
+    assert maxnorm_rel(g_direct.cpu(), tr.state.grads.cpu()) < 1e-4
+    tr.state.zero_grad()
+    # S = 128 (two 64-lane segments in sr_sc_loss) against the same torch formulation
+    args128 = O.default_args(mlp_mode="bf16x3", sc_lambda=0.1, n_samples=128)
+    tr128 = Trainer(models, args128, use_graph=False)
+    torch.manual_seed(12)
+    p128 = tr128._forward_backward(rays[:48], ts[:48], target[:48])
+    g128 = tr128.state.grads.clone()
+    tr128.state.zero_grad()
+    torch.manual_seed(12)
+    u = torch.rand(48, 128, device=DEV)
+    with rendering.replay_rng([u, torch.zeros_like(u), torch.zeros_like(u)]):
+        res = rendering.render_rays(models, args128, rays[:48], ts[:48])
+    la = satnerf_loss(res, target[:48], lambda_sc=0.1)
+    la.backward()
+    assert abs(p128.sum().item() - la.item()) < 1e-4 * abs(la.item())
+    assert maxnorm_rel(g128.cpu(), tr128.state.grads.cpu()) < 1e-4
+    tr128.state.zero_grad()
+    # captured steps
+    trg = Trainer(models, O.default_args(mlp_mode="bf16", sc_lambda=0.1))
+    losses = [trg.step(rays, ts, target).item() for _ in range(20)]
+    assert trg._graph is not None and all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
