@@ -114,7 +114,7 @@ def main():
 
     from satnerf_amd import ops, rendering
     from satnerf_amd.models import load_model
-    from oracle import satnerf_oracle as O  # synthetic-ray recipe only
+    from satnerf_amd.data import default_args, synthetic_rays  # SURVEY.md 8d recipe; oracle/ is only used by cpu_baseline()
 
     try:
         from satnerf_amd import train as train_mod
@@ -124,7 +124,7 @@ def main():
     if phase == "train" and train_mod is None:
         raise SystemExit("training phase not built")
 
-    args = O.default_args(n_samples=a.samples, mlp_mode=a.mode)
+    args = default_args(n_samples=a.samples, mlp_mode=a.mode)
     torch.manual_seed(0)  # identical init on every rank
     model = load_model(args).to(dev)
     emb = torch.nn.Embedding(args.t_embbeding_vocab, args.t_embbeding_tau).to(dev)
@@ -133,7 +133,7 @@ def main():
     from satnerf_amd.data import RayBank
 
     n_bank = max(1 << 20, a.rays * 16 * world)  # 1 M rays (47 MB): an epoch is ~1000 steps, as with a real scene
-    bank_rays, bank_ts = O.synthetic_rays(n_bank, seed=20240628)
+    bank_rays, bank_ts = synthetic_rays(n_bank, seed=20240628)
     bank_rgb = torch.rand(n_bank, 3, generator=torch.Generator().manual_seed(7))
     bank = RayBank(bank_rays.to(dev), bank_rgb.to(dev), bank_ts.to(dev), a.rays, seed=11, rank=rank, world_size=world)
     torch.manual_seed(1234 + rank)  # per-rank sampling jitter

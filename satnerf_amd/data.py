@@ -90,3 +90,31 @@ def rays_from_cache(cached_rays, center, scene_range, sun_elevation_deg, sun_azi
     sun = sun_direction(sun_elevation_deg, sun_azimuth_deg).to(rays.dtype).expand(rays.shape[0], 3)
     out = torch.hstack([rays, sun]).type(torch.float32)
     return out if device is None else out.to(device)
+
+
+def synthetic_rays(n_rays, seed=20240628, n_images=19, far_lo=0.5, far_hi=1.0):
+    """Synthetic sat-nerf ray batch for benchmarks (no dataset ships offline): origins U[-1,1]^3, unit directions, near = 0
+    (datasets/satellite.py:60), far U[far_lo, far_hi] (scene-normalised, :225-226), one sun direction per synthetic image id
+    from random (azimuth, elevation in [30, 80] deg) as in ``get_sun_dirs`` (:239-241), ts ~ randint(n_images).
+    Returns (rays (N,11) fp32 on the CPU, ts (N,) int64)."""
+    import math
+
+    g = torch.Generator().manual_seed(seed)
+    o = torch.rand(n_rays, 3, generator=g) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=1)
+    far = far_lo + (far_hi - far_lo) * torch.rand(n_rays, 1, generator=g)
+    az = torch.rand(n_images, generator=g) * 2 * math.pi
+    el = math.radians(30) + torch.rand(n_images, generator=g) * math.radians(50)
+    sun = torch.stack([torch.sin(az) * torch.cos(el), torch.cos(az) * torch.cos(el), torch.sin(el)], 1)
+    ts = torch.randint(0, n_images, (n_rays,), generator=g)
+    return torch.cat([o, d, torch.zeros(n_rays, 1), far, sun[ts]], 1).float(), ts
+
+
+def default_args(**kw):
+    """The ``args`` attributes the hot path reads, with the BASELINE configs[1] values (opt.py defaults except fc_units=256)."""
+    from types import SimpleNamespace
+
+    a = dict(model="sat-nerf", n_samples=64, n_importance=0, chunk=5120, noise_std=0.0, sc_lambda=0.0, ds_lambda=0.0, fc_layers=8,
+             fc_units=256, t_embbeding_tau=4, t_embbeding_vocab=30)
+    a.update(kw)
+    return SimpleNamespace(**a)

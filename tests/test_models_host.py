@@ -109,3 +109,16 @@ def test_rays_from_reference_cache_format(tmp_path):
     assert torch.equal(torch.load(path), ecef)  # the cache itself is not modified
     with pytest.raises(ValueError):
         rays_from_cache(torch.zeros(4, 11), center, rng, 1, 2)
+
+
+def test_package_synthetic_rays_follow_the_survey_recipe():
+    """satnerf_amd.data.synthetic_rays / default_args (what bench.py's GPU legs use) equal the oracle's recipe."""
+    from satnerf_amd import data
+
+    for n, seed in ((257, 20240628), (64, 3)):
+        r1, t1 = data.synthetic_rays(n, seed=seed)
+        r2, t2 = O.synthetic_rays(n, seed=seed)
+        assert torch.equal(t1, t2) and torch.allclose(r1, r2, atol=1e-7) and r1.dtype == torch.float32
+        assert torch.allclose(r1[:, 3:6].norm(dim=1), torch.ones(n), atol=1e-6) and (r1[:, 6] == 0).all()
+    a, b = data.default_args(n_samples=50), O.default_args(n_samples=50)
+    assert all(getattr(a, k) == v for k, v in vars(b).items())

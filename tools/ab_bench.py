@@ -1,14 +1,14 @@
 """Time the bf16 fused-MLP kernel for one library build (SATRENDER_LIB); prints one line.  Used for A/B of variants."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import satnerf_oracle as O
+from satnerf_amd import data as O  # synthetic rays / default args (the oracle is test infrastructure)
 from satnerf_amd import ops
 from satnerf_amd.models import load_model
 dev = 'cuda:0'
 mode = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
 n_rays = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 args = O.default_args()
-m = load_model(args); m.load_state_dict(O.procedural_satnerf_params(256, 4, seed=1)); m = m.to(dev)
+m = load_model(args).to(dev)
 emb = torch.nn.Embedding(30, 4).to(dev)
 rays, ts = O.synthetic_rays(n_rays); rays = rays.to(dev); ts = ts.to(dev)
 hi, lo, l0 = m.packed(mode)

@@ -2,7 +2,7 @@
 import sys, time, os
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import satnerf_oracle as O
+from satnerf_amd import data as O  # synthetic rays / default args (the oracle is test infrastructure)
 from satnerf_amd import rendering
 from satnerf_amd.models import load_model
 dev = "cuda:0"

@@ -1,6 +1,6 @@
 import sys, time, torch
 sys.path.insert(0, "/root/repo")
-from oracle import satnerf_oracle as O
+from satnerf_amd import data as O  # synthetic rays / default args (the oracle is test infrastructure)
 from satnerf_amd.models import load_model
 from satnerf_amd.train import Trainer
 dev = "cuda:0"

@@ -1,11 +1,11 @@
 import time, torch, sys
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import satnerf_oracle as O
+from satnerf_amd import data as O  # synthetic rays / default args (the oracle is test infrastructure)
 from satnerf_amd import rendering, ops
 from satnerf_amd.models import load_model
 dev='cuda:0'
 args=O.default_args()
-m=load_model(args); m.load_state_dict(O.procedural_satnerf_params(256,4,seed=1)); m=m.to(dev)
+m=load_model(args).to(dev)
 emb=torch.nn.Embedding(30,4).to(dev)
 rays,ts=O.synthetic_rays(1024); rays=rays.to(dev); ts=ts.to(dev)
 for mode in ('bf16','bf16x3'):
