@@ -29,6 +29,12 @@ extern "C" {
 #define SR_MODE_BF16 1   /* single-pass bf16 MFMA, fp32 accumulate -- throughput mode            */
 #define SR_MODE_BF16X3 3 /* hi*hi + lo*hi + hi*lo split on the same MFMA pipe -- parity mode (~2e-6) */
 
+/* formats of the training workspaces the forward / dX / weight-gradient kernels exchange through HBM:
+ * 16 = unorm16 phase / bf16 (the parity mode's backward), 8 = one byte per value (PHASE8 / micro-scaled int8): half the
+ * bytes of a training step, used by the throughput mode */
+#define SR_FMT16 16
+#define SR_FMT8 8
+
 int sr_version(void);
 const char* sr_last_error(void);
 
@@ -38,8 +44,9 @@ const char* sr_last_error(void);
  * (satnerf_amd/packing.py) must produce for a given network shape; -1 on an unsupported shape. */
 int64_t sr_fwd_stream_elems(int feat, int tau);  /* bf16 elements of the forward stream (per hi/lo plane) */
 int64_t sr_bwd_stream_elems(int feat, int tau);  /* bf16 elements of the transposed (dX) stream          */
-int64_t sr_act_elems_per_tile(int feat);         /* bf16 elements saved per 32-point tile in training     */
-int64_t sr_dpre_elems_per_tile(int feat);        /* bf16 elements of pre-activation gradients per tile    */
+/* training workspaces, per 32-point tile, in 16-bit elements, for a workspace format `fmt` (below) */
+int64_t sr_act_elems_per_tile(int feat, int fmt);   /* activations saved by the forward pass          */
+int64_t sr_dpre_elems_per_tile(int feat, int fmt);  /* pre-activation gradients written by the dX pass */
 
 /* ---- weight packing:  replaces nothing in the reference (its weights feed addmm directly) ---------
  * out_hi[i] = bf16_rne(src[idx[i]] * scale[i]);  out_lo[i] = bf16_rne(src[idx[i]]*scale[i] - out_hi[i])
@@ -79,7 +86,8 @@ int sr_sky_fwd(const float* sun, int sun_stride, int64_t n, int hidden, const fl
  * outputs (any may be NULL): albedo (P,3), sigma (P), sun_v (P), beta (P)   [models/satnerf.py:45-49]
  * stream_hi/lo: packed forward stream from sr_pack_stream (lo required iff mode == SR_MODE_BF16X3)
  * l0: (feat,4) fp32 rows [w_x, w_y, w_z, b] of fc_net.0, each multiplied by 30/(2*pi), in slot order
- * acts: NULL, or training workspace of sr_act_elems_per_tile(feat) * ceil(P/32) bf16 elements. */
+ * acts: NULL, or training workspace of sr_act_elems_per_tile(feat, act_fmt) * ceil(P/32) 16-bit elements, written in the
+ * format act_fmt (SR_FMT8 needs mode == SR_MODE_BF16; act_fmt is ignored when acts == NULL). */
 typedef struct sr_mlp_inputs {
   const float* org;
   int org_stride;
@@ -96,13 +104,13 @@ typedef struct sr_mlp_inputs {
 
 int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, int mode, const uint16_t* stream_hi,
                        const uint16_t* stream_lo, const float* l0, float* albedo, float* sigma, float* sun_v,
-                       float* beta, uint16_t* acts, void* stream);
+                       float* beta, uint16_t* acts, int act_fmt, void* stream);
 
 /* ---- backward of the fused MLP: replaces autograd through SatNeRF.forward (models/satnerf.py:156-208) ------------
  * sr_satnerf_mlp_bwd: data-gradient chain.  Inputs: the forward's saved `acts`, its four outputs and the gradients of
  * those outputs (g_* may be NULL = 0); bwd_stream = packed transposed weights (sr_pack_stream with
- * packing.backward_maps).  Outputs: dpre (sr_dpre_elems_per_tile(feat) * ceil(P/32) bf16) and d_t (P,tau) fp32, the
- * gradient w.r.t. each point's embedding vector (NULL to skip).
+ * packing.backward_maps).  Outputs: dpre (sr_dpre_elems_per_tile(feat, fmt) * ceil(P/32) 16-bit elements) and d_t (P,tau)
+ * fp32, the gradient w.r.t. each point's embedding vector (NULL to skip).  `fmt` = format of BOTH workspaces.
  * sr_satnerf_wgrad: weight-gradient GEMMs dpre x acts over all points.  `blocks` (n_blocks x 12 int32, device) lists the job
  * blocks (rf0 nr0 rf1 nr1 | cf0 nc0 cf1 nc1 | col_kind n_slices first_slice -: up to two ranges of dpre row fragments and of
  * activation column fragments, <= 16 each; packing.backward_maps); every block is cut into n_slices contiguous ranges of
@@ -112,10 +120,17 @@ int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, int mode, con
  * most n_wg workgroups (n_wg <= 0: the current device's CU count); *n_slices = total slices. */
 int sr_satnerf_mlp_bwd(int feat, int tau, int64_t n_points, const uint16_t* bwd_stream, const uint16_t* acts,
                        const float* albedo, const float* sigma, const float* sun_v, const float* beta, const float* g_albedo,
-                       const float* g_sigma, const float* g_sun_v, const float* g_beta, uint16_t* dpre, float* d_t, void* stream);
+                       const float* g_sigma, const float* g_sun_v, const float* g_beta, uint16_t* dpre, float* d_t, int fmt,
+                       void* stream);
 int sr_wgrad_plan(int32_t* blocks, int n_blocks, int64_t n_points, int n_wg, int* n_slices);
 int sr_satnerf_wgrad(int feat, int tau, int64_t n_points, const uint16_t* dpre, const uint16_t* acts, const int32_t* blocks,
                      int n_blocks, int n_slices, float* partial, void* stream);
+/* the same contraction from SR_FMT8 workspaces: every wave fetches one 1-KiB double fragment per tile and expands it in LDS
+ * (PHASE8 -> bf16 sin, MX8 -> bf16 value); `loads` (n_blocks x sr_wgrad8_load_ints() int32, device; packing.wgrad8_loads) says
+ * which unit of which workspace each wave of a block fetches and where it goes; `blocks` is the same planned table. */
+int sr_satnerf_wgrad8(int feat, int tau, int64_t n_points, const uint16_t* dpre, const uint16_t* acts, const int32_t* blocks,
+                      const int32_t* loads, int n_blocks, int n_slices, float* partial, void* stream);
+int sr_wgrad8_load_ints(void);
 
 /* parameter gradients of the sky head (atomicAdd into g_*; zero them first) and of the embedding table
  * g_emb[ts[r]] += sum_j d_t[r*S + j] (nn.Embedding backward, rendering.py:100) */

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("SATRENDER_LIB") or os.path.join(_HERE, "csrc", "libsa
 
 MODE_BF16 = 1
 MODE_BF16X3 = 3
+FMT16, FMT8 = 16, 8  # training workspace formats (include/satrender.h)
 
 _vp, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 
@@ -35,9 +36,9 @@ SIGNATURES = {
     "sr_last_error": (C.c_char_p, []),
     "sr_fwd_stream_elems": (_i64, [_i, _i]),
     "sr_bwd_stream_elems": (_i64, [_i, _i]),
-    "sr_act_elems_per_tile": (_i64, [_i]),
+    "sr_act_elems_per_tile": (_i64, [_i, _i]),
     "sr_pack_stream": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
-    "sr_dpre_elems_per_tile": (_i64, [_i]),
+    "sr_dpre_elems_per_tile": (_i64, [_i, _i]),
     "sr_unpack_grads": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _vp]),
     "sr_composite_image": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp]),
     "sr_latlonalt_from_depth": (_i, [_vp, _i, _vp, _i64, _vp, _d, _vp, _vp, _vp, _vp]),
@@ -47,8 +48,10 @@ SIGNATURES = {
     "sr_positional_map": (_i, [_vp, _i, _i, _i64, _i, _vp, _vp]),
     "sr_points_along": (_i, [_vp, _i, _i, _vp, _i64, _i, _vp, _vp]),
     "sr_wgrad_plan": (_i, [_vp, _i, _i64, _i, _vp]),
-    "sr_satnerf_mlp_bwd": (_i, [_i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sr_satnerf_mlp_bwd": (_i, [_i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sr_satnerf_wgrad": (_i, [_i, _i, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "sr_satnerf_wgrad8": (_i, [_i, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "sr_wgrad8_load_ints": (_i, []),
     "sr_sky_bwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sr_embedding_bwd": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "sr_ray_setup": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -66,7 +69,7 @@ SIGNATURES = {
     "sr_gather_scale_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "sr_ray_sample_fwd": (_i, [_vp, _i, _vp, _i64, _i, _vp, _vp]),
     "sr_sky_fwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "sr_satnerf_mlp_fwd": (_i, [C.POINTER(MlpInputs), _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sr_satnerf_mlp_fwd": (_i, [C.POINTER(MlpInputs), _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sr_composite_fwd": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sr_composite_bwd": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp, _vp]),

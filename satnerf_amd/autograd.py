@@ -27,16 +27,19 @@ class _InferenceFn(torch.autograd.Function):
         feat, tau = model.feat, model.t_embedding_dims
         hi, lo, l0 = model.packed(mode)
         emb = emb_module.weight.data
-        acts = ops.acts_workspace(n * s, feat, rays.device)
+        from .train import _fmt_of
+
+        fmt = _fmt_of(args)
+        acts = ops.acts_workspace(n * s, feat, rays.device, fmt)
         albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, dir_cols[0]:dir_cols[1]], rays[:, 8:11], z, emb, ts, n * s, s, feat, tau,
-                                                     mode, hi, lo, l0, acts=acts)
+                                                     mode, hi, lo, l0, acts=acts, fmt=fmt)
         sk = model.sky_color
         sky = ops.sky(rays[:, 8:11], sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data)
         noise_std = float(args.noise_std)
         use_noise = noise_std != 0
         weights, transparency, depth, rgb = ops.composite(z, sigma.view(n, s), noise if use_noise else None, noise_std, albedo.view(n, s, 3),
                                                          sun_v.view(n, s), sky)
-        ctx.model, ctx.emb_module, ctx.noise_std, ctx.shape = model, emb_module, noise_std, (n, s)
+        ctx.model, ctx.emb_module, ctx.noise_std, ctx.shape, ctx.fmt = model, emb_module, noise_std, (n, s), fmt
         ctx.save_for_backward(rays, z, ts, noise if use_noise else None, acts, albedo, sigma, sun_v, beta, sky, weights, transparency)
         return rgb, depth, weights, transparency, albedo.view(n, s, 3), sun_v.view(n, s, 1), sky, beta.view(n, s, 1)
 
@@ -58,9 +61,10 @@ class _InferenceFn(torch.autograd.Function):
         g_beta_pt = None if g_beta is None else g_beta.reshape(n * s).contiguous().float()
         bstream, maps = model.packed_backward()
         dpre, d_t = ops.satnerf_mlp_bwd(feat, tau, n * s, bstream, acts, albedo, sigma, sun_v, beta, d_albedo.contiguous(), d_sigma, d_sun.contiguous(),
-                                        g_beta_pt)
+                                        g_beta_pt, fmt=ctx.fmt)
         grad_flat = model.flat_grads()
-        ops.satnerf_wgrad(feat, tau, n * s, dpre, acts, maps["blocks"], maps["gidx"], maps["gscale"], grad_flat, accumulate=True)
+        ops.satnerf_wgrad(feat, tau, n * s, dpre, acts, maps["blocks"], maps["gidx"], maps["gscale"], grad_flat, accumulate=True, fmt=ctx.fmt,
+                          loads=maps["loads8"])
         sk = model.sky_color
         ops.sky_bwd(rays[:, 8:11], sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sky, d_sky.contiguous(), sk[0].weight.grad, sk[0].bias.grad,
                     sk[2].weight.grad, sk[2].bias.grad)

@@ -4,15 +4,15 @@
 #include "mlp_params.h"
 
 namespace sr {
-int launch_fwd_p1a1(const FwdParams&, bool, hipStream_t);
-int launch_fwd_p1a2(const FwdParams&, bool, hipStream_t);
-int launch_fwd_p3a1(const FwdParams&, bool, hipStream_t);
-int launch_fwd_p3a2(const FwdParams&, bool, hipStream_t);
+int launch_fwd_p1a1(const FwdParams&, int, hipStream_t);
+int launch_fwd_p1a2(const FwdParams&, int, hipStream_t);
+int launch_fwd_p3a1(const FwdParams&, int, hipStream_t);
+int launch_fwd_p3a2(const FwdParams&, int, hipStream_t);
 }  // namespace sr
 using namespace sr;
 extern "C" int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, int mode, const uint16_t* stream_hi,
                                   const uint16_t* stream_lo, const float* l0, float* albedo, float* sigma, float* sun_v,
-                                  float* beta, uint16_t* acts, void* stream) {
+                                  float* beta, uint16_t* acts, int act_fmt, void* stream) {
   SR_REQUIRE(in != nullptr, "sr_satnerf_mlp_fwd: null inputs");
   SR_REQUIRE(feat == kFeat, "sr_satnerf_mlp_fwd: feat=%d unsupported (this build handles %d)", feat, kFeat);
   SR_REQUIRE(tau >= 1 && tau <= 24, "sr_satnerf_mlp_fwd: tau=%d unsupported (1..24)", tau);
@@ -20,6 +20,7 @@ extern "C" int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, in
   SR_REQUIRE(stream_hi && l0 && in->org && in->sun && in->temb, "sr_satnerf_mlp_fwd: null pointer argument");
   SR_REQUIRE(mode != SR_MODE_BF16X3 || stream_lo, "sr_satnerf_mlp_fwd: BF16X3 needs the lo plane");
   SR_REQUIRE(in->n_samples >= 1, "sr_satnerf_mlp_fwd: n_samples must be >= 1");
+  SR_REQUIRE(acts == nullptr || act_fmt == SR_FMT16 || act_fmt == SR_FMT8, "sr_satnerf_mlp_fwd: act_fmt must be 16 or 8 (got %d)", act_fmt);
   if (in->n_points <= 0) return 0;
   FwdParams p;
   p.in = *in;
@@ -30,7 +31,7 @@ extern "C" int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, in
   p.acts = (uint4*)acts;
   p.tau = tau;
   hipStream_t st = (hipStream_t)stream;
-  const bool save = acts != nullptr;
+  const int save = acts != nullptr ? act_fmt : 0;
   const int auxs = aux_steps(tau);
   if (mode == SR_MODE_BF16) return auxs == 1 ? launch_fwd_p1a1(p, save, st) : launch_fwd_p1a2(p, save, st);
   return auxs == 1 ? launch_fwd_p3a1(p, save, st) : launch_fwd_p3a2(p, save, st);
@@ -41,7 +42,7 @@ extern "C" int64_t sr_fwd_stream_elems(int feat, int tau) {
   return (aux_steps(tau) == 1 ? FwdStream<1>::total_pieces() : FwdStream<2>::total_pieces()) * 512;
 }
 
-extern "C" int64_t sr_act_elems_per_tile(int feat) {
-  if (feat != kFeat) return -1;
-  return (int64_t)act_ksteps(2) * 64 * 8;  // sized for the larger aux layout
+extern "C" int64_t sr_act_elems_per_tile(int feat, int fmt) {
+  if (feat != kFeat || (fmt != SR_FMT16 && fmt != SR_FMT8)) return -1;
+  return (int64_t)(fmt == SR_FMT8 ? act8_units(2) : act_ksteps(2)) * 64 * 8;  // sized for the larger aux layout
 }

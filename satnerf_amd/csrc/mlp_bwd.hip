@@ -10,8 +10,12 @@
 // sin stages: the forward saved the pre-activation PHASE (unorm16 revolutions); d pre = d out * cos(2 pi phase) (for
 // fc_net.0 the factor w0 = 30 is applied to its weight gradient by the gather scale, packing.backward_maps).
 // Arithmetic: single-pass bf16 MFMA with fp32 accumulation (mixed-precision backward) in both numeric modes.
+// Workspace format (template FMT, mlp_layout.h): SR_FMT16 reads unorm16 phases and writes bf16 gradients; SR_FMT8 (the
+// throughput mode) reads PHASE8 double fragments and writes the gradients as MX8 (codec8.h) -- the gradient that continues down
+// the chain stays bf16 in registers either way, only the copy the weight-gradient kernel reads is 8-bit.
 #include "mlp_device.h"
 #include "mlp_params.h"
+#include "codec8.h"
 
 namespace sr {
 
@@ -38,16 +42,55 @@ __device__ __forceinline__ float phase_cos(uint32_t w, int half) {
   return __builtin_amdgcn_cosf((float)u * (1.0f / 65535.0f));  // v_cos_f32 takes revolutions
 }
 
-// 16 accumulator values (fragments 2T, 2T+1 of the stage's input vector) -> [x cos(phase)] -> two bf16 fragments
-template <bool COS>
-__device__ __forceinline__ void bpack(const f32x16& acc, const uint4& p0, const uint4& p1, uint4& o0, uint4& o1) {
+// phases of one output tile's 16 values per lane: SR_FMT16 two unorm16 fragments, SR_FMT8 one PHASE8 double fragment
+template <int FMT>
+struct Phase {
+  uint4 p0, p1;
+  __device__ __forceinline__ void load(const uint4* acts_tile, int auxs, int frag) {  // frag = logical fragment of value 0 (even)
+    if constexpr (FMT == SR_FMT8) p0 = ws_load(acts_tile + (auxs + (frag >> 1)) * 64);
+    else p0 = ws_load(acts_tile + (auxs + frag) * 64), p1 = ws_load(acts_tile + (auxs + frag + 1) * 64);
+  }
+  __device__ __forceinline__ float cos(int g) const {
+    if constexpr (FMT == SR_FMT8) {
+      const uint32_t pw[4] = {p0.x, p0.y, p0.z, p0.w};
+      return __builtin_amdgcn_cosf(phase8_rev(pw[g >> 2], g & 3));
+    } else {
+      const uint32_t pw[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+      return phase_cos(pw[g >> 1], g & 1);
+    }
+  }
+};
+
+// 16 accumulator values (fragments 2T, 2T+1 of the stage's input vector) -> [x cos(phase)] -> two bf16 fragments (the next
+// stage's B operand), stored to the dpre workspace at logical fragment `frag` in the format FMT; returns the MX8 scale byte.
+constexpr int dp8_unit(int frag) { return frag < kDpSigma ? frag >> 1 : (frag - 1) >> 1; }  // mlp_layout.h: d_sigma_pre sits between
+template <bool COS, int FMT>
+__device__ __forceinline__ uint32_t bpack(const f32x16& acc, const Phase<FMT>& ph, uint4& o0, uint4& o1, uint4* dpre_tile, int frag) {
   float v[16];
-  const uint32_t pw[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
 #pragma unroll
-  for (int g = 0; g < 16; ++g) v[g] = COS ? acc[g] * phase_cos(pw[g >> 1], g & 1) : acc[g];
+  for (int g = 0; g < 16; ++g) v[g] = COS ? acc[g] * ph.cos(g) : acc[g];
   o0 = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
   o1 = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15]));
+  if constexpr (FMT == SR_FMT8) {
+    const uint32_t e = mx8_exponent(v);
+    ws_store(dpre_tile + dp8_unit(frag) * 64, mx8_encode(v, e));
+    return e;
+  } else {
+    ws_store(dpre_tile + frag * 64, o0);
+    ws_store(dpre_tile + (frag + 1) * 64, o1);
+    return 0u;
+  }
 }
+// scale bytes of a group's tiles (SR_FMT8): byte (group & 1) * 8 + t of the lane's 16 B in unit kD8Scale + (group >> 1)
+template <int FMT, int NT>
+__device__ __forceinline__ void store_scales(uint4* dpre_tile, int group, const uint32_t (&eb)[2]) {
+  if constexpr (FMT == SR_FMT8) {
+    char* p = reinterpret_cast<char*>(dpre_tile + (kD8Scale + (group >> 1)) * 64) + (group & 1) * 8;
+    if constexpr (NT > 4) *reinterpret_cast<uint2*>(p) = make_uint2(eb[0], eb[1]);
+    else *reinterpret_cast<uint32_t*>(p) = eb[0];
+  }
+}
+constexpr int dp8_group(int frag) { return frag < kDpFeats ? frag / 16 : frag < kDpSigma ? 8 : 9 + (frag - kDpRgbh) / kHS; }
 
 // one output tile: acc = sum_i A(piece P0+i of the slot) x in[i]
 template <int KIN>
@@ -61,27 +104,29 @@ __device__ __forceinline__ f32x16 btile(const char* slot, int p0, const uint4 (&
   return acc;
 }
 
-// generic transposed stage: NCHUNK chunks of TPC tiles, each KIN pieces; tile t -> out[O0+2t], out[O0+2t+1], stored to dst
-template <int KIN, int TPC, int NCHUNK, int G0, bool COS, int NOUT, int O0 = 0>
+// generic transposed stage: NCHUNK chunks of TPC tiles, each KIN pieces; tile t -> out[2t], out[2t+1], stored to the dpre
+// workspace from logical fragment DF0; AF0 = logical activation fragment of the stage's phases (COS stages)
+template <int FMT, int KIN, int TPC, int NCHUNK, int G0, bool COS, int NOUT, int AF0, int DF0>
 __device__ __forceinline__ void bstage(const uint4 (&in)[KIN], uint4 (&out)[NOUT], char* ring, const char* stream, int wave, int lane,
-                                       const uint4* phase, uint4* dst) {
+                                       const uint4* acts_tile, int auxs, uint4* dpre_tile) {
+  uint32_t eb[2] = {0u, 0u};
   static_for<NCHUNK>([&](auto cc) {
     constexpr int c = decltype(cc)::value, g = G0 + c;
     static_assert(BS::np(g) == TPC * KIN, "backward stream geometry mismatch");
     bchunk_enter<g>(ring, stream, wave, lane);
     const char* slot = ring + (g % kNSLOT) * kBSlot;
     static_for<TPC>([&](auto tc) {
-      constexpr int tt = decltype(tc)::value, t = c * TPC + tt, o = O0 + 2 * t;
-      uint4 p0 = {}, p1 = {};
-      if constexpr (COS) p0 = ws_load(phase + (2 * t) * 64), p1 = ws_load(phase + (2 * t + 1) * 64);
+      constexpr int tt = decltype(tc)::value, t = c * TPC + tt, o = 2 * t;
+      Phase<FMT> ph = {};
+      if constexpr (COS) ph.load(acts_tile, auxs, AF0 + 2 * t);
       const f32x16 acc = btile<KIN>(slot, tt * KIN, in, lane);
-      bpack<COS>(acc, p0, p1, out[o], out[o + 1]);
-      ws_store(dst + (2 * t) * 64, out[o]);
-      ws_store(dst + (2 * t + 1) * 64, out[o + 1]);
+      eb[t >> 2] |= bpack<COS, FMT>(acc, ph, out[o], out[o + 1], dpre_tile, DF0 + 2 * t) << (8 * (t & 3));
     });
   });
+  store_scales<FMT, TPC * NCHUNK>(dpre_tile, dp8_group(DF0), eb);
 }
 
+template <int FMT>
 __global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;
@@ -89,7 +134,8 @@ __global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, pl = lane & 31;
   const char* stream = prm.stream;
-  const int A = prm.auxs, AK = act_ksteps(prm.auxs);
+  const int A = prm.auxs, AK = FMT == SR_FMT8 ? act8_units(prm.auxs) : act_ksteps(prm.auxs);
+  constexpr int DK = FMT == SR_FMT8 ? kD8Units : kDpFrags;  // workspace units per tile
 
 #pragma unroll
   for (int g = 0; g < kD; ++g) {
@@ -105,8 +151,8 @@ __global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
 #endif
   const long pt = tile * 32 + pl;
   const bool valid = pt < prm.n_points;
-  const uint4* acts = prm.acts + tile * AK * 64 + lane;   // + fragment * 64
-  uint4* dpre = prm.dpre + tile * kDpFrags * 64 + lane;   // + fragment * 64
+  const uint4* acts = prm.acts + tile * AK * 64 + lane;   // + unit * 64
+  uint4* dpre = prm.dpre + tile * DK * 64 + lane;         // + unit * 64
 
   // ---- gradients of the head pre-activations (rows 0..2 albedo logits, 3 sun logit, 4 beta; sigma separately) ----------
   uint4 dhead[1], dsig;
@@ -132,8 +178,8 @@ __global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
     }
     dhead[0] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
     dsig = make_uint4(pack_bf16x2(sg, 0.f), 0u, 0u, 0u);
-    dpre[kDpHead * 64] = dhead[0];
-    dpre[kDpSigma * 64] = dsig;
+    dpre[(FMT == SR_FMT8 ? kD8Head : kDpHead) * 64] = dhead[0];
+    dpre[(FMT == SR_FMT8 ? kD8Sigma : kDpSigma) * 64] = dsig;
   }
 
   // ---- bH: d_head -> d rgb-hidden | d sun-hidden-3 | d beta-hidden (12 tiles x 1 piece, one chunk) --------------------
@@ -141,27 +187,30 @@ __global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
   {
     bchunk_enter<BS::G_H>(ring, stream, wave, lane);
     const char* slot = ring + (BS::G_H % kNSLOT) * kBSlot;
+    uint32_t eb[3][2] = {};
     static_for<3 * kMTH>([&](auto tc) {
       constexpr int T = decltype(tc)::value, part = T / kMTH, t = T % kMTH;
       constexpr int act0 = part == 0 ? kActRgbh : (part == 1 ? kActS3 : kActE1);
       constexpr int dp0 = part == 0 ? kDpRgbh : (part == 1 ? kDpS3 : kDpE1);
-      const uint4 p0 = ws_load(acts + (A + act0 + 2 * t) * 64), p1 = ws_load(acts + (A + act0 + 2 * t + 1) * 64);
+      Phase<FMT> ph;
+      ph.load(acts, A, act0 + 2 * t);
       const f32x16 acc = btile<1>(slot, T, dhead, lane);
       uint4 o0, o1;
-      bpack<true>(acc, p0, p1, o0, o1);
+      eb[part][0] |= bpack<true, FMT>(acc, ph, o0, o1, dpre, dp0 + 2 * t) << (8 * t);
       if constexpr (part == 0) d_rgbh[2 * t] = o0, d_rgbh[2 * t + 1] = o1;
       else if constexpr (part == 1) d_s3[2 * t] = o0, d_s3[2 * t + 1] = o1;
       else d_e1[2 * t] = o0, d_e1[2 * t + 1] = o1;
-      ws_store(dpre + (dp0 + 2 * t) * 64, o0);
-      ws_store(dpre + (dp0 + 2 * t + 1) * 64, o1);
     });
+    store_scales<FMT, kMTH>(dpre, dp8_group(kDpRgbh), eb[0]);
+    store_scales<FMT, kMTH>(dpre, dp8_group(kDpS3), eb[1]);
+    store_scales<FMT, kMTH>(dpre, dp8_group(kDpE1), eb[2]);
   }
   // ---- sun chain: bS3 (d s3 -> d s2), bS2 (d s2 -> d s1) -------------------------------------------------------------
   uint4 d_g2[3 * kHS];  // [d rgbh | d s1 | d e1] : the input of bG2
   {
     uint4 d_s2[kHS], d_s1[kHS];
-    bstage<kHS, 2, 2, BS::G_S3, true, kHS>(d_s3, d_s2, ring, stream, wave, lane, acts + (A + kActS2) * 64, dpre + kDpS2 * 64);
-    bstage<kHS, 2, 2, BS::G_S2, true, kHS>(d_s2, d_s1, ring, stream, wave, lane, acts + (A + kActS1) * 64, dpre + kDpS1 * 64);
+    bstage<FMT, kHS, 2, 2, BS::G_S3, true, kHS, kActS2, kDpS2>(d_s3, d_s2, ring, stream, wave, lane, acts, A, dpre);
+    bstage<FMT, kHS, 2, 2, BS::G_S2, true, kHS, kActS1, kDpS1>(d_s2, d_s1, ring, stream, wave, lane, acts, A, dpre);
 #pragma unroll
     for (int i = 0; i < kHS; ++i) d_g2[i] = d_rgbh[i], d_g2[kHS + i] = d_s1[i], d_g2[2 * kHS + i] = d_e1[i];
   }
@@ -169,7 +218,7 @@ __global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
   uint4 d_g1[kKS + 1];  // [d feats (16) | d sigma_pre (1)] : the input of bG1
   {
     uint4 d_feats[kKS];
-    bstage<3 * kHS, 1, kMT, BS::G_G2, false, kKS>(d_g2, d_feats, ring, stream, wave, lane, nullptr, dpre + kDpFeats * 64);
+    bstage<FMT, 3 * kHS, 1, kMT, BS::G_G2, false, kKS, 0, kDpFeats>(d_g2, d_feats, ring, stream, wave, lane, acts, A, dpre);
     bchunk_enter<BS::G_DT>(ring, stream, wave, lane);
     const f32x16 acc = btile<kHS>(ring + (BS::G_DT % kNSLOT) * kBSlot, 0, d_e1, lane);
     if (valid && prm.d_t) {
@@ -185,29 +234,28 @@ __global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
   }
   // ---- bG1: -> d a7, x cos(phase a7) = d pre_7 ----------------------------------------------------------------------
   uint4 cur[kKS], nxt[kKS];
-  bstage<kKS + 1, 1, kMT, BS::G_G1, true, kKS>(d_g1, cur, ring, stream, wave, lane, acts + (A + kActA0 + 7 * kKS) * 64,
-                                               dpre + (kDpL + 7 * kKS) * 64);
+  bstage<FMT, kKS + 1, 1, kMT, BS::G_G1, true, kKS, kActA0 + 7 * kKS, kDpL + 7 * kKS>(d_g1, cur, ring, stream, wave, lane, acts, A, dpre);
   // ---- bL7 .. bL2 (runtime loop), bL1 (peeled: its chunks are the tail of the stream) --------------------------------
   constexpr long offL = BS::offset_pieces(BS::G_L);
 #pragma unroll 1
   for (int l = 7; l >= 2; --l) {
     const long cbase = (long)(7 - l) * kMT;
-    const uint4* ph = acts + (A + kActA0 + (l - 1) * kKS) * 64;
-    uint4* dst = dpre + (kDpL + (l - 1) * kKS) * 64;
+    const int lfrag = (l - 1) * kKS;  // logical fragment of a_{l-1} / d_pre_{l-1}
+    uint32_t eb[2] = {0u, 0u};
     static_for<kMT>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
       wait_then_barrier<(kD - 1) * min_loads<1>(kKS)>();
       issue_chunk<1, kKS>(stream, nullptr, (offL + (cbase + t + kD) * kKS) * 1024L, ring + ((BS::G_L + t + kD) % kNSLOT) * kBSlot, wave, lane);
-      const uint4 p0 = ws_load(ph + (2 * t) * 64), p1 = ws_load(ph + (2 * t + 1) * 64);
+      Phase<FMT> ph;
+      ph.load(acts, A, kActA0 + lfrag + 2 * t);
       const f32x16 acc = btile<kKS>(ring + ((BS::G_L + t) % kNSLOT) * kBSlot, 0, cur, lane);
-      bpack<true>(acc, p0, p1, nxt[2 * t], nxt[2 * t + 1]);
-      ws_store(dst + (2 * t) * 64, nxt[2 * t]);
-      ws_store(dst + (2 * t + 1) * 64, nxt[2 * t + 1]);
+      eb[t >> 2] |= bpack<true, FMT>(acc, ph, nxt[2 * t], nxt[2 * t + 1], dpre, kDpL + lfrag + 2 * t) << (8 * (t & 3));
     });
+    store_scales<FMT, kMT>(dpre, l - 1, eb);
 #pragma unroll
     for (int i = 0; i < kKS; ++i) cur[i] = nxt[i];
   }
-  bstage<kKS, 1, kMT, BS::G_L + 6 * kMT, true, kKS>(cur, nxt, ring, stream, wave, lane, acts + (A + kActA0) * 64, dpre + kDpL * 64);
+  bstage<FMT, kKS, 1, kMT, BS::G_L + 6 * kMT, true, kKS, kActA0, kDpL>(cur, nxt, ring, stream, wave, lane, acts, A, dpre);
 }
 
 }  // namespace sr
@@ -216,9 +264,10 @@ using namespace sr;
 
 extern "C" int sr_satnerf_mlp_bwd(int feat, int tau, int64_t n_points, const uint16_t* bwd_stream, const uint16_t* acts, const float* albedo,
                                   const float* sigma, const float* sun_v, const float* beta, const float* g_albedo, const float* g_sigma,
-                                  const float* g_sun_v, const float* g_beta, uint16_t* dpre, float* d_t, void* stream) {
+                                  const float* g_sun_v, const float* g_beta, uint16_t* dpre, float* d_t, int fmt, void* stream) {
   SR_REQUIRE(feat == kFeat, "sr_satnerf_mlp_bwd: feat=%d unsupported (this build handles %d)", feat, kFeat);
   SR_REQUIRE(tau >= 1 && tau <= 24, "sr_satnerf_mlp_bwd: tau=%d unsupported (1..24)", tau);
+  SR_REQUIRE(fmt == SR_FMT16 || fmt == SR_FMT8, "sr_satnerf_mlp_bwd: workspace format must be 16 or 8 (got %d)", fmt);
   SR_REQUIRE(bwd_stream && acts && dpre && albedo && sigma && sun_v && beta, "sr_satnerf_mlp_bwd: null pointer argument");
   if (n_points <= 0) return 0;
   BwdParams p;
@@ -230,14 +279,16 @@ extern "C" int sr_satnerf_mlp_bwd(int feat, int tau, int64_t n_points, const uin
   const size_t lds = (size_t)kNSLOT * kBSlot;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)satnerf_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)satnerf_bwd_kernel<SR_FMT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)satnerf_bwd_kernel<SR_FMT8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
       return 1;
     }
     attr_set = true;
   }
   const long tiles = (n_points + 31) / 32;
-  hipLaunchKernelGGL(satnerf_bwd_kernel, dim3((unsigned)((tiles + 7) / 8)), dim3(512), lds, (hipStream_t)stream, p);
+  if (fmt == SR_FMT8) hipLaunchKernelGGL(satnerf_bwd_kernel<SR_FMT8>, dim3((unsigned)((tiles + 7) / 8)), dim3(512), lds, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(satnerf_bwd_kernel<SR_FMT16>, dim3((unsigned)((tiles + 7) / 8)), dim3(512), lds, (hipStream_t)stream, p);
   return check_launch("satnerf_bwd_kernel");
 }
 
@@ -246,7 +297,7 @@ extern "C" int64_t sr_bwd_stream_elems(int feat, int tau) {
   return BwdStream::total_pieces() * 512;
 }
 
-extern "C" int64_t sr_dpre_elems_per_tile(int feat) {
-  if (feat != kFeat) return -1;
-  return (int64_t)kDpFrags * 64 * 8;
+extern "C" int64_t sr_dpre_elems_per_tile(int feat, int fmt) {
+  if (feat != kFeat || (fmt != SR_FMT16 && fmt != SR_FMT8)) return -1;
+  return (int64_t)(fmt == SR_FMT8 ? kD8Units : kDpFrags) * 64 * 8;
 }

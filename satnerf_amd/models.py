@@ -201,6 +201,7 @@ class SatNeRF(_FlatParamModule):
         if ent is None or ent["idx"].device != flat.device:
             m = packing.backward_maps(self.feat, self.t_embedding_dims)
             ent = {k: torch.from_numpy(m[k]).to(flat.device) for k in ("idx", "scale", "blocks", "gidx", "gscale")}
+            ent["loads8"] = torch.from_numpy(packing.wgrad8_loads(self.feat, self.t_embedding_dims)).to(flat.device)
             self._pack_cache["bmaps"] = ent
         cached = self._pack_cache.get("bstream")
         version = self.weights_version()

@@ -108,8 +108,9 @@ def sky(sun, w1, b1, w2, b2):
     return out
 
 
-def satnerf_mlp(org, direction, sun, z, temb, ts, n_points, n_samples, feat, tau, mode, stream_hi, stream_lo, l0, acts=None):
-    """Fused MLP over n_points sample points; returns (albedo (P,3), sigma (P), sun_v (P), beta (P))."""
+def satnerf_mlp(org, direction, sun, z, temb, ts, n_points, n_samples, feat, tau, mode, stream_hi, stream_lo, l0, acts=None, fmt=16):
+    """Fused MLP over n_points sample points; returns (albedo (P,3), sigma (P), sun_v (P), beta (P)).  ``acts`` = training
+    workspace (``acts_workspace(..., fmt)``) the activations are saved to in format ``fmt`` (16 | 8)."""
     org, so = _rows(org, "org", 3)
     sun, ss = _rows(sun, "sun", 3)
     sd = 0
@@ -130,7 +131,7 @@ def satnerf_mlp(org, direction, sun, z, temb, ts, n_points, n_samples, feat, tau
     if ev:
         ev[0].record()
     _lib.call("sr_satnerf_mlp_fwd", C.byref(inp), feat, tau, MODES[mode], _p(stream_hi), _p(stream_lo), _p(_chk(l0, "l0")), _p(albedo), _p(sigma),
-              _p(sun_v), _p(beta), _p(acts), _stream())
+              _p(sun_v), _p(beta), _p(acts), int(fmt), _stream())
     if ev:
         ev[1].record()
     return albedo, sigma, sun_v, beta
@@ -285,15 +286,22 @@ def sample_pdf_merge(z_coarse, weights_coarse, u, eps=1e-5):
 
 
 # ------------------------------------------------------------------------------------------------ backward
-def acts_workspace(n_points, feat, device):
-    per_tile = _lib.lib().sr_act_elems_per_tile(feat)
+def default_fmt(mode):
+    """Workspace format of a numeric mode: the throughput mode trains on 8-bit saved state, the parity mode on 16-bit."""
+    return 8 if mode == "bf16" else 16
+
+
+def acts_workspace(n_points, feat, device, fmt=16):
+    per_tile = _lib.lib().sr_act_elems_per_tile(feat, int(fmt))
+    if per_tile <= 0:
+        raise ValueError(f"unsupported workspace (feat={feat}, fmt={fmt})")
     return torch.empty(((n_points + 31) // 32) * per_tile, dtype=torch.int16, device=device)
 
 
-def satnerf_mlp_bwd(feat, tau, n_points, bwd_stream, acts, albedo, sigma, sun_v, beta, g_albedo, g_sigma, g_sun_v, g_beta, want_dt=True):
-    """dX chain: returns (dpre workspace, d_t (P,tau) or None)."""
+def satnerf_mlp_bwd(feat, tau, n_points, bwd_stream, acts, albedo, sigma, sun_v, beta, g_albedo, g_sigma, g_sun_v, g_beta, want_dt=True, fmt=16):
+    """dX chain: returns (dpre workspace, d_t (P,tau) or None); ``fmt`` = format of ``acts`` and of the returned workspace."""
     dev = albedo.device
-    per_tile = _lib.lib().sr_dpre_elems_per_tile(feat)
+    per_tile = _lib.lib().sr_dpre_elems_per_tile(feat, int(fmt))
     dpre = torch.empty(((n_points + 31) // 32) * per_tile, dtype=torch.int16, device=dev)
     d_t = torch.empty(n_points, tau, dtype=torch.float32, device=dev) if want_dt else None
     opt = lambda t, nm: _p(_chk(t, nm, allow_none=True))  # noqa: E731
@@ -302,7 +310,7 @@ def satnerf_mlp_bwd(feat, tau, n_points, bwd_stream, acts, albedo, sigma, sun_v,
         ev[0].record()
     _lib.call("sr_satnerf_mlp_bwd", feat, tau, n_points, _p(bwd_stream), _p(acts), _p(_chk(albedo, "albedo")), _p(_chk(sigma, "sigma")),
               _p(_chk(sun_v, "sun_v")), _p(_chk(beta, "beta")), opt(g_albedo, "g_albedo"), opt(g_sigma, "g_sigma"), opt(g_sun_v, "g_sun_v"),
-              opt(g_beta, "g_beta"), _p(dpre), _p(d_t), _stream())
+              opt(g_beta, "g_beta"), _p(dpre), _p(d_t), int(fmt), _stream())
     if ev:
         ev[1].record()
     return dpre, d_t
@@ -329,23 +337,28 @@ def wgrad_plan(blocks, n_points, n_wg=0):
     return ent[0], ent[1]
 
 
-def wgrad_partials(feat, tau, n_points, dpre, acts, blocks):
-    """Weight-gradient GEMMs only: returns (fp32 split-K slices, planned job table); reduce with grad_tail / unpack_grads."""
+def wgrad_partials(feat, tau, n_points, dpre, acts, blocks, fmt=16, loads=None):
+    """Weight-gradient GEMMs only: returns (fp32 split-K slices, planned job table); reduce with grad_tail / unpack_grads.
+    ``fmt`` = format of both workspaces; the 8-bit kernel also needs the per-block load table ``loads`` (packing.wgrad8_loads)."""
     plan, n_slices = wgrad_plan(blocks, n_points)
     block_floats = 256 * 256 + 256 * 32  # csrc/mlp_layout.h kWgBlockFloats
     partial = torch.empty(n_slices * block_floats, dtype=torch.float32, device=dpre.device)
     ev = kernel_timer.span("wgrad") if kernel_timer is not None else None
     if ev:
         ev[0].record()
-    _lib.call("sr_satnerf_wgrad", feat, tau, n_points, _p(dpre), _p(acts), _p(plan), plan.shape[0], n_slices, _p(partial), _stream())
+    if int(fmt) == 8:
+        _lib.call("sr_satnerf_wgrad8", feat, tau, n_points, _p(dpre), _p(acts), _p(plan), _p(_chk(loads, "loads", torch.int32)), plan.shape[0], n_slices,
+                  _p(partial), _stream())
+    else:
+        _lib.call("sr_satnerf_wgrad", feat, tau, n_points, _p(dpre), _p(acts), _p(plan), plan.shape[0], n_slices, _p(partial), _stream())
     if ev:
         ev[1].record()
     return partial, plan
 
 
-def satnerf_wgrad(feat, tau, n_points, dpre, acts, blocks, gidx, gscale, grad_flat, accumulate=True):
+def satnerf_wgrad(feat, tau, n_points, dpre, acts, blocks, gidx, gscale, grad_flat, accumulate=True, fmt=16, loads=None):
     """Weight-gradient GEMMs + split-K reduction + scatter into the flat gradient buffer."""
-    partial, plan = wgrad_partials(feat, tau, n_points, dpre, acts, blocks)
+    partial, plan = wgrad_partials(feat, tau, n_points, dpre, acts, blocks, fmt, loads)
     _lib.call("sr_unpack_grads", _p(partial), _p(_chk(gidx, "gidx", torch.int32)), _p(_chk(gscale, "gscale")), gidx.numel(), _p(plan),
               _p(_chk(grad_flat, "grad_flat")), int(accumulate), _stream())
 

@@ -390,3 +390,80 @@ def backward_maps(feat=256, tau=4):
     put("beta_from_xyz.2.bias", jobs["H"], inv16[[4]], "aux", AUXC.AUX_ONE)
     return dict(idx=idx, scale=scale, blocks=tab.table(), block_rows=tab.rows, block_cols=tab.cols, gidx=gidx.astype(np.int32), gscale=gscale,
                 n_params=n_params, auxs=auxs, offsets=offsets)
+
+
+# ------------------------------------------------------------------------------------------------ 8-bit workspaces
+# csrc/mlp_layout.h (SR_FMT8): logical 16-bit fragment f of a workspace -> (unit, codec[, scale unit, scale byte]).
+SRC_DPRE, SRC_ACTS = 1, 2
+RAW16, PHASE8, MX8 = 0, 1, 2
+WG8_LOAD_INTS = 20
+D8_SIGMA, D8_HEAD, D8_SCALE, D8_UNITS, A8_SCALE = 92, 93, 94, 101, 92
+_DP_SIGMA, _DP_RGBH, _DP_HEAD = 144, 145, 185
+
+
+def act8_units(auxs):
+    return auxs + 93
+
+
+def dpre8_source(f):
+    """Logical dpre fragment -> dict(unit, codec, half[, scale_unit, scale_byte]) in the 8-bit layout."""
+    if f == _DP_SIGMA:
+        return dict(unit=D8_SIGMA, codec=RAW16, half=0)
+    if f == _DP_HEAD:
+        return dict(unit=D8_HEAD, codec=RAW16, half=0)
+    u = f >> 1 if f < _DP_SIGMA else (f - 1) >> 1
+    half = f & 1 if f < _DP_SIGMA else (f - 1) & 1
+    if u < 72:
+        g, k = u // 8, u % 8           # trunk layers 0..7, d_feats = 8
+    else:
+        g, k = 9 + (u - 72) // 4, (u - 72) % 4
+    return dict(unit=u, codec=MX8, half=half, scale_unit=D8_SCALE + (g >> 1), scale_byte=(g & 1) * 8 + k)
+
+
+def act8_source(f, auxs):
+    """Logical activation fragment (aux offset included, as in the job table) -> its 8-bit source."""
+    a = f - auxs
+    assert a >= 0, "aux fragments are fetched by the kernel itself"
+    if 128 <= a < 144:  # feats: identity stage -> MX8
+        return dict(unit=auxs + (a >> 1), codec=MX8, half=a & 1, scale_unit=auxs + A8_SCALE, scale_byte=(a - 128) >> 1)
+    return dict(unit=auxs + (a >> 1), codec=PHASE8, half=a & 1)
+
+
+@functools.lru_cache(maxsize=8)
+def wgrad8_loads(feat=256, tau=4):
+    """Load table of csrc/wgrad8.hip for the job blocks of ``backward_maps``: int32 [n_blocks, 20].
+
+    Per block: ints 0..15 = the primary load of wave w (0 = none; bits 0-1 source, 2-3 codec, 4-11 unit, 12-17 operand
+    fragment, 18-19 scale area, 20-23 scale byte), ints 16..18 = the scale unit fetched into scale area 0..2 (0 = none)."""
+    bm = backward_maps(feat, tau)
+    auxs = bm["auxs"]
+    out = np.zeros((len(bm["block_rows"]), WG8_LOAD_INTS), np.int32)
+    for b, (rows, cols) in enumerate(zip(bm["block_rows"], bm["block_cols"])):
+        loads, areas = [], []
+
+        def area_of(src, unit):
+            if (src, unit) not in areas:
+                areas.append((src, unit))
+            return areas.index((src, unit))
+
+        for base, frags, src, lookup in ((0, rows, SRC_DPRE, dpre8_source), (16, cols, SRC_ACTS, lambda f: act8_source(f, auxs))):
+            pos = 0
+            while pos < len(frags):
+                d = lookup(frags[pos])
+                desc = src | (d["codec"] << 2) | (d["unit"] << 4) | ((base + pos) << 12)
+                if d["codec"] == RAW16:
+                    pos += 1
+                else:
+                    assert d["half"] == 0 and pos + 1 < len(frags) and frags[pos + 1] == frags[pos] + 1, (b, frags, pos)
+                    if d["codec"] == MX8:
+                        desc |= (area_of(src, d["scale_unit"]) << 18) | (d["scale_byte"] << 20)
+                    pos += 2
+                loads.append(desc)
+        assert len(loads) <= 16 and len(areas) <= 3, (b, len(loads), len(areas))
+        # waves 0, 1 also fetch the aux fragments and waves 2..4 the scale units: hand the primaries to the others first
+        order = list(range(5, 16)) + [4, 3, 2, 1, 0]
+        for w, desc in zip(order, loads):
+            out[b, w] = desc
+        for k, (src, unit) in enumerate(areas):
+            out[b, 16 + k] = src | (unit << 4)
+    return out

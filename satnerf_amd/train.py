@@ -16,6 +16,21 @@ import torch
 import torch.distributed as dist
 
 
+def _fmt_of(args):
+    """Format of the saved training state (include/satrender.h SR_FMT*): ``args.bwd_fmt`` (16 | 8) when given, else the
+    numeric mode's default -- 8-bit for the throughput mode ``bf16``, 16-bit for the parity mode ``bf16x3``."""
+    from . import ops
+    from .rendering import _mode_of
+
+    fmt = getattr(args, "bwd_fmt", None)
+    fmt = ops.default_fmt(_mode_of(args)) if fmt is None else int(fmt)
+    if fmt not in (8, 16):
+        raise ValueError(f"bwd_fmt must be 8 or 16, got {fmt}")
+    if fmt == 8 and _mode_of(args) != "bf16":
+        raise ValueError("the 8-bit workspace format belongs to mlp_mode='bf16'")
+    return fmt
+
+
 def satnerf_loss(res, target, lambda_sc=0.0, beta_min=0.05):
     """``metrics.SatNerfLoss`` for the coarse model (metrics.py:21-34,56-73)."""
     beta = torch.sum(res["weights_coarse"].unsqueeze(-1) * res["beta_coarse"], -2) + beta_min
@@ -165,9 +180,10 @@ class Trainer:
         nz = torch.randn(n, s, device=rays.device) if noise_std != 0 else None
         z, sky = ops.ray_setup(rays, u, s, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data, seed=self._seed,
                                step_counter=self.adam_state)
-        acts = ops.acts_workspace(n * s, feat, rays.device)
+        fmt = _fmt_of(args)
+        acts = ops.acts_workspace(n * s, feat, rays.device, fmt)
         albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, 3:6], rays[:, 8:11], z, emb.weight.data, ts, n * s, s, feat, tau, mode,
-                                                     hi, lo, l0, acts=acts)
+                                                     hi, lo, l0, acts=acts, fmt=fmt)
         if s <= 64:  # one launch: compositing forward -> loss -> compositing backward
             loss, self.last_rgb, d_sigma, d_albedo, d_sun, g_beta, d_sky = ops.render_loss(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3),
                                                                                            sun_v.view(n, s), beta.view(n, s), sky, rgbs)
@@ -177,8 +193,8 @@ class Trainer:
             d_sigma, d_albedo, d_sun, d_sky = ops.composite_bwd(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky,
                                                                weights, transp, g_rgb, None, g_w, None)
             self.last_rgb = rgb
-        dpre, d_t = ops.satnerf_mlp_bwd(feat, tau, n * s, bstream, acts, albedo, sigma, sun_v, beta, d_albedo, d_sigma, d_sun, g_beta.view(-1))
-        partial, plan = ops.wgrad_partials(feat, tau, n * s, dpre, acts, maps["blocks"])
+        dpre, d_t = ops.satnerf_mlp_bwd(feat, tau, n * s, bstream, acts, albedo, sigma, sun_v, beta, d_albedo, d_sigma, d_sun, g_beta.view(-1), fmt=fmt)
+        partial, plan = ops.wgrad_partials(feat, tau, n * s, dpre, acts, maps["blocks"], fmt, maps["loads8"])
         ops.grad_tail(partial, plan, maps["gidx"], maps["gscale"], model.flat_grads(), rays[:, 8:11], sk[0].weight.data, sk[0].bias.data,
                       sk[2].weight.data, sky, d_sky, sk[0].weight.grad, sk[0].bias.grad, sk[2].weight.grad, sk[2].bias.grad, d_t, ts, n, s, tau,
                       emb.weight.grad)
@@ -203,12 +219,14 @@ class Trainer:
         hi, lo, l0 = model.packed(mode)
         bstream, maps = model.packed_backward()
         nz = torch.randn(n, s, device=rays.device) if noise_std != 0 else None
-        acts = ops.acts_workspace(n * s, feat, rays.device)
+        fmt = _fmt_of(args)
+        acts = ops.acts_workspace(n * s, feat, rays.device, fmt)
         albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, 8:11], rays[:, 8:11], z, emb.weight.data, ts, n * s, s, feat, tau, mode,
-                                                     hi, lo, l0, acts=acts)
+                                                     hi, lo, l0, acts=acts, fmt=fmt)
         loss, d_sun = ops.sc_loss(z, sigma.view(n, s), nz, noise_std, sun_v.view(n, s), float(args.sc_lambda))
-        dpre, _ = ops.satnerf_mlp_bwd(feat, tau, n * s, bstream, acts, albedo, sigma, sun_v, beta, None, None, d_sun, None, want_dt=False)
-        ops.satnerf_wgrad(feat, tau, n * s, dpre, acts, maps["blocks"], maps["gidx"], maps["gscale"], model.flat_grads(), accumulate=True)
+        dpre, _ = ops.satnerf_mlp_bwd(feat, tau, n * s, bstream, acts, albedo, sigma, sun_v, beta, None, None, d_sun, None, want_dt=False, fmt=fmt)
+        ops.satnerf_wgrad(feat, tau, n * s, dpre, acts, maps["blocks"], maps["gidx"], maps["gscale"], model.flat_grads(), accumulate=True, fmt=fmt,
+                          loads=maps["loads8"])
         return loss
 
     def _depth_pass(self, rays, ts, depths, noise_std):
@@ -228,15 +246,17 @@ class Trainer:
         nz = torch.randn(n, s, device=rays.device) if noise_std != 0 else None
         z, sky = ops.ray_setup(rays, u, s, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data, seed=self._seed + 1,
                                step_counter=self.adam_state)
-        acts = ops.acts_workspace(n * s, feat, rays.device)
+        fmt = _fmt_of(args)
+        acts = ops.acts_workspace(n * s, feat, rays.device, fmt)
         albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, 3:6], rays[:, 8:11], z, emb.weight.data, ts, n * s, s, feat, tau, mode,
-                                                     hi, lo, l0, acts=acts)
+                                                     hi, lo, l0, acts=acts, fmt=fmt)
         weights, transp, depth, _ = ops.composite(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky)
         loss, g_depth = ops.depth_loss(depth, depths, float(args.ds_lambda), use_weights=not getattr(args, "ds_noweights", False))
         d_sigma, _, _, _ = ops.composite_bwd(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky, weights, transp,
                                              None, g_depth, None, None)
-        dpre, _ = ops.satnerf_mlp_bwd(feat, tau, n * s, bstream, acts, albedo, sigma, sun_v, beta, None, d_sigma, None, None, want_dt=False)
-        ops.satnerf_wgrad(feat, tau, n * s, dpre, acts, maps["blocks"], maps["gidx"], maps["gscale"], model.flat_grads(), accumulate=True)
+        dpre, _ = ops.satnerf_mlp_bwd(feat, tau, n * s, bstream, acts, albedo, sigma, sun_v, beta, None, d_sigma, None, None, want_dt=False, fmt=fmt)
+        ops.satnerf_wgrad(feat, tau, n * s, dpre, acts, maps["blocks"], maps["gidx"], maps["gscale"], model.flat_grads(), accumulate=True, fmt=fmt,
+                          loads=maps["loads8"])
         return loss
 
     def _capture(self, inputs):

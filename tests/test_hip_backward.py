@@ -54,10 +54,11 @@ def _run_backward(models, args, rays, ts, draws, loss_of):
     return loss, res
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
-def test_gradients_match_reference_golden(mode):
+@pytest.mark.parametrize("mode,fmt", [("bf16x3", 16), ("bf16", 16), ("bf16", 8)])
+def test_gradients_match_reference_golden(mode, fmt):
+    """fmt = format of the saved training state: 16-bit (parity mode's default) or the throughput mode's 8-bit workspaces."""
     g = load_golden("backward")
-    args = O.default_args(mlp_mode=mode)
+    args = O.default_args(mlp_mode=mode, bwd_fmt=fmt)
     models = build_models(args)
     models["coarse"].train()
     loss, _ = _run_backward(models, args, g["rays"], g["ts"], golden_draws(g),
@@ -69,7 +70,7 @@ def test_gradients_match_reference_golden(mode):
         if k.startswith("grad_") and k != "grad_embedding":
             errs[k[5:]] = maxnorm_rel(sd[k[5:]].grad.cpu(), v)
     errs["embedding"] = maxnorm_rel(models["t"].weight.grad.cpu(), g["grad_embedding"])
-    print(mode, {k: f"{e:.1e}" for k, e in errs.items()})
+    print(mode, fmt, {k: f"{e:.1e}" for k, e in errs.items()})
     assert len(errs) == 14
     assert max(errs.values()) < GRAD_TOL, errs
     # every p.grad is a view of ONE flat buffer
