@@ -50,6 +50,10 @@ struct Phase {
     if constexpr (FMT == SR_FMT8) p0 = ws_load(acts_tile + (auxs + (frag >> 1)) * 64);
     else p0 = ws_load(acts_tile + (auxs + frag) * 64), p1 = ws_load(acts_tile + (auxs + frag + 1) * 64);
   }
+  __device__ __forceinline__ void from_lds(const char* slot, int lane) {  // staged by stage_phase()
+    p0 = *reinterpret_cast<const uint4*>(slot + lane * 16);
+    if constexpr (FMT != SR_FMT8) p1 = *reinterpret_cast<const uint4*>(slot + 1024 + lane * 16);
+  }
   __device__ __forceinline__ float cos(int g) const {
     if constexpr (FMT == SR_FMT8) {
       const uint32_t pw[4] = {p0.x, p0.y, p0.z, p0.w};
@@ -102,6 +106,47 @@ __device__ __forceinline__ f32x16 btile(const char* slot, int p0, const uint4 (&
     acc = mfma(a, in[i], acc);
   }
   return acc;
+}
+
+// ---- trunk schedule ---------------------------------------------------------------------------------------------------------
+// In the trunk (7 layers x 8 output tiles, two thirds of the kernel) every vector-memory LOAD of a wave is an LDS-DMA issued
+// through inline asm -- the weight chunks into the shared ring, the tile's saved phases into a wave-private staging ring -- so
+// the compiler never sees a load it would have to wait for (left to hipcc, each tile's phase load became an s_waitcnt vmcnt(0)
+// that also drained the weight prefetch and the workspace stores: 62 % of the wave cycles were spent parked, PMC r02a).  The
+// waits are ours and EXACT: vmcnt retires in order on gfx9, the instruction stream of a wave is fixed, so the number of
+// vector-memory instructions issued after the one being waited for is a compile-time constant of the position in the layer.
+// Per layer (NP = phase DMAs per tile, NS = workspace stores per tile, ND = weight DMAs per group of 2 chunks):
+//   tile t:   [t even: wait A(t), s_barrier, ND weight DMAs for chunks t+2, t+3]  NP phase DMAs for tile t+2  MFMAs(t)
+//             [t > 0: wait B(t-1), epilogue(t-1) = cos, pack, encode, NS stores]
+//   end:      wait B(7), epilogue(7), scale store (NSS)
+template <int NP, int NS, int NSS>
+struct TrunkSched {
+  static constexpr int ND = 2 * (kKS / 8);  // 2 chunks x 16 pieces / 8 waves
+  static constexpr int tile_len(int t) { return (t % 2 == 0 ? ND : 0) + NP + (t > 0 ? NS : 0); }
+  static constexpr int tile_start(int t) {
+    int p = 0;
+    for (int k = 0; k < t; ++k) p += tile_len(k);
+    return p;
+  }
+  static constexpr int period() { return tile_start(kMT) + NS + NSS; }
+  static constexpr int after_d(int t) { return tile_start(t) + ND; }                          // just after the weight DMAs of tile t (even)
+  static constexpr int after_p(int t) { return tile_start(t) + (t % 2 == 0 ? ND : 0) + NP; }  // just after the phase DMAs issued in tile t
+  static constexpr int at_store(int t) { return t < kMT - 1 ? after_p(t + 1) : tile_start(kMT); }  // where epilogue(t)'s wait sits
+  // instructions issued after the phase DMAs of tile t (issued in tile t-2; in the previous layer -- or the prologue -- for t < 2)
+  static constexpr int wait_b(int t) {
+    if (t >= 2) return at_store(t) - after_p(t - 2);
+    const int steady = at_store(t) - (after_p(t + kMT - 2) - period());
+    const int first = t == 0 ? NP + at_store(0) : at_store(1);  // first layer: phases of tiles 0, 1 are staged by the prologue
+    return steady < first ? steady : first;
+  }
+  // instructions issued after the weight DMAs of tile t's group (issued at the entry of tile t-2)
+  static constexpr int wait_a(int t) { return t >= 2 ? tile_start(t) - after_d(t - 2) : tile_start(0) - (after_d(kMT - 2) - period()); }
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // generic transposed stage: NCHUNK chunks of TPC tiles, each KIN pieces; tile t -> out[2t], out[2t+1], stored to the dpre
@@ -235,27 +280,54 @@ __global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
   // ---- bG1: -> d a7, x cos(phase a7) = d pre_7 ----------------------------------------------------------------------
   uint4 cur[kKS], nxt[kKS];
   bstage<FMT, kKS + 1, 1, kMT, BS::G_G1, true, kKS, kActA0 + 7 * kKS, kDpL + 7 * kKS>(d_g1, cur, ring, stream, wave, lane, acts, A, dpre);
-  // ---- bL7 .. bL2 (runtime loop), bL1 (peeled: its chunks are the tail of the stream) --------------------------------
+  // ---- bL7 .. bL1: d pre_l -> d a_{l-1}, x cos(phase a_{l-1}) = d pre_{l-1}; scheduled by TrunkSched (above) -------------------
   constexpr long offL = BS::offset_pieces(BS::G_L);
+  constexpr int NPH = FMT == SR_FMT8 ? 1 : 2;  // phase units per tile
+  using TS = TrunkSched<NPH, NPH, FMT == SR_FMT8 ? 1 : 0>;
+  char* stage = smem + kNSLOT * kBSlot + wave * (4 * NPH * 1024);  // this wave's phase staging ring: 4 tiles
+  const uint32_t stage_addr = __builtin_amdgcn_readfirstlane(lds_addr_of(stage));
+  auto stage_phase = [&](int slot, int frag) {  // frag = logical activation fragment of the tile's first value
+    const char* src = reinterpret_cast<const char*>(acts + (A + (FMT == SR_FMT8 ? frag >> 1 : frag)) * 64);
+#pragma unroll
+    for (int k = 0; k < NPH; ++k) glds16(src + k * 1024, stage_addr + (slot * NPH + k) * 1024);
+  };
+  // G1's chunk protocol already requested the first trunk chunks; drain everything once and start from a known queue
+  wait_then_barrier<0>();
+  stage_phase(0, kActA0 + 6 * kKS), stage_phase(1, kActA0 + 6 * kKS + 2);
 #pragma unroll 1
-  for (int l = 7; l >= 2; --l) {
+  for (int l = 7; l >= 1; --l) {
     const long cbase = (long)(7 - l) * kMT;
-    const int lfrag = (l - 1) * kKS;  // logical fragment of a_{l-1} / d_pre_{l-1}
+    const int lfrag = (l - 1) * kKS;                    // logical fragment of a_{l-1} / d_pre_{l-1}
+    const int nfrag = l >= 2 ? lfrag - kKS : lfrag;     // ... of the next layer (the last layer re-stages its own: uniform counts)
+    f32x16 acc[2];
     uint32_t eb[2] = {0u, 0u};
+    auto epilogue = [&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      wait_vmcnt<TS::wait_b(t)>();
+      Phase<FMT> ph;
+      ph.from_lds(stage + (t & 3) * NPH * 1024, lane);
+      eb[t >> 2] |= bpack<true, FMT>(acc[t & 1], ph, nxt[2 * t], nxt[2 * t + 1], dpre, kDpL + lfrag + 2 * t) << (8 * (t & 3));
+    };
     static_for<kMT>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
-      wait_then_barrier<(kD - 1) * min_loads<1>(kKS)>();
-      issue_chunk<1, kKS>(stream, nullptr, (offL + (cbase + t + kD) * kKS) * 1024L, ring + ((BS::G_L + t + kD) % kNSLOT) * kBSlot, wave, lane);
-      Phase<FMT> ph;
-      ph.load(acts, A, kActA0 + lfrag + 2 * t);
-      const f32x16 acc = btile<kKS>(ring + ((BS::G_L + t) % kNSLOT) * kBSlot, 0, cur, lane);
-      eb[t >> 2] |= bpack<true, FMT>(acc, ph, nxt[2 * t], nxt[2 * t + 1], dpre, kDpL + lfrag + 2 * t) << (8 * (t & 3));
+      if constexpr (t % 2 == 0) {
+        wait_then_barrier<TS::wait_a(t)>();
+#pragma unroll
+        for (int k = 2; k < 4; ++k) {  // chunks t+2, t+3 (clamped at the end of the stream: same instruction count every layer)
+          long c = cbase + t + k;
+          c = c < kTrunkLayers * kMT ? c : kTrunkLayers * kMT - 1;
+          issue_chunk<1, kKS>(stream, nullptr, (offL + c * kKS) * 1024L, ring + ((BS::G_L + t + k) % kNSLOT) * kBSlot, wave, lane);
+        }
+      }
+      stage_phase((t + 2) & 3, kActA0 + (t + 2 < kMT ? lfrag : nfrag) + 2 * ((t + 2) % kMT));
+      acc[t & 1] = btile<kKS>(ring + ((BS::G_L + t) % kNSLOT) * kBSlot, 0, cur, lane);
+      if constexpr (t > 0) epilogue(std::integral_constant<int, t - 1>{});
     });
+    epilogue(std::integral_constant<int, kMT - 1>{});
     store_scales<FMT, kMT>(dpre, l - 1, eb);
 #pragma unroll
     for (int i = 0; i < kKS; ++i) cur[i] = nxt[i];
   }
-  bstage<FMT, kKS, 1, kMT, BS::G_L + 6 * kMT, true, kKS, kActA0, kDpL>(cur, nxt, ring, stream, wave, lane, acts, A, dpre);
 }
 
 }  // namespace sr
@@ -276,7 +348,7 @@ extern "C" int sr_satnerf_mlp_bwd(int feat, int tau, int64_t n_points, const uin
   p.acts = (const uint4*)acts, p.dpre = (uint4*)dpre, p.d_t = d_t;
   p.stream = (const char*)bwd_stream;
   p.n_points = n_points, p.tau = tau, p.auxs = aux_steps(tau);
-  const size_t lds = (size_t)kNSLOT * kBSlot;
+  const size_t lds = (size_t)kNSLOT * kBSlot + 8 * 4 * (fmt == SR_FMT8 ? 1 : 2) * 1024;  // weight ring + per-wave phase staging
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)satnerf_bwd_kernel<SR_FMT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||

@@ -1,0 +1,19 @@
+"""Per-kernel HIP-event timings of one eager training step (bench.py's roofline leg) for one library build (SATRENDER_LIB)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from satnerf_amd import ops, data
+from satnerf_amd.models import load_model
+from satnerf_amd.train import Trainer
+dev = "cuda:0"
+args = data.default_args(mlp_mode=os.environ.get("AB_MODE", "bf16"))
+if os.environ.get("AB_FMT"): args.bwd_fmt = int(os.environ["AB_FMT"])
+torch.manual_seed(0)
+models = {"coarse": load_model(args).to(dev), "t": torch.nn.Embedding(30, 4).to(dev)}
+tr = Trainer(models, args, use_graph=False)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+rays, ts = data.synthetic_rays(n); rays, ts = rays.to(dev), ts.to(dev); tgt = torch.rand(n, 3, device=dev)
+for _ in range(10): tr.step(rays, ts, tgt)
+timer = ops.KernelTimer(); ops.kernel_timer = timer
+for _ in range(30): tr.step(rays, ts, tgt)
+torch.cuda.synchronize()
+print(os.path.basename(os.environ.get("SATRENDER_LIB", "default")), {k: round(timer.mean_ms(k) * 1e3, 1) for k in ("mlp_fwd", "mlp_bwd", "wgrad")})
