@@ -24,23 +24,6 @@ __device__ __forceinline__ uint4 phase8_encode(const V& x) {  // x[0..15]
 __device__ __forceinline__ float ubyte_f32(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }  // v_cvt_f32_ubyte<k>
 __device__ __forceinline__ float phase8_rev(uint32_t w, int k) { return ubyte_f32(w, k) * (1.0f / 256.0f); }
 
-// ---- SIN8 -------------------------------------------------------------------------------------------------------------
-// v in [-1, 1] -> u = 128 + floor(v * 32767 / 256) via v_cvt_pknorm_i16_f32 (two values per instruction), the high bytes of four
-// snorm16 gathered by one v_perm and flipped to offset binary by one v_xor: ~0.8 VALU per value.  Decode: (u - 127.5) / 127.996.
-template <class V>
-__device__ __forceinline__ uint4 sin8_encode(const V& v) {  // v[0..15]
-  uint32_t w[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const uint32_t lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_i16(v[4 * q], v[4 * q + 1]));
-    const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_i16(v[4 * q + 2], v[4 * q + 3]));
-    w[q] = __builtin_amdgcn_perm(hi, lo, 0x07050301u) ^ 0x80808080u;  // [lo.b1, lo.b3, hi.b1, hi.b3]
-  }
-  return make_uint4(w[0], w[1], w[2], w[3]);
-}
-constexpr float kSin8Scale = 256.0f / 32767.0f, kSin8Bias = -127.5f * (256.0f / 32767.0f);
-__device__ __forceinline__ float sin8_value(uint32_t w, int k) { return __builtin_fmaf(ubyte_f32(w, k), kSin8Scale, kSin8Bias); }
-
 // ---- MX8 --------------------------------------------------------------------------------------------------------------
 // E = biased exponent of max|v| * (1 + 2^-7) (so that max|v| / 2^(E-133) <= 127.008 rounds to <= 127), clamped to >= 6.
 template <class V>

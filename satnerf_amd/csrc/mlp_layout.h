@@ -90,20 +90,14 @@ constexpr int kDpL = 0, kDpFeats = 8 * kKS, kDpSigma = kDpFeats + kKS, kDpRgbh =
 // (2.08 GB per 1024x64 step at 16 bits), so the throughput mode stores one byte per value.  Unit = 1 KiB =
 // 64 lanes x 16 B; a "double fragment" (DF) holds, for lane (p, h), the 16 values of one 32-row output tile = B fragments
 // 2t and 2t+1 of the 16-bit layout (logical fragment f lives in half f & 1 of DF f >> 1).  Two codecs:
-//   PHASE8: sin stages, u = round(frac(pre-activation in revolutions) * 256) mod 256 (cos recovered to +-pi/256 rad): read by the
-//           dX kernel only;
-//   SIN8  : the same stages' OUTPUT as offset-binary int8, u = 128 + floor(127.996 sin) (decoded (u - 127.5) / 127.996, +-0.004):
-//           read by the weight-gradient kernel only -- its operand then costs a convert and an fma per value instead of a v_sin
-//           (16 cycles), which had made that kernel VALU-bound (profiles/r02_ab_variants.txt);
+//   PHASE8: sin stages, u = round(frac(pre-activation in revolutions) * 256) mod 256 (sin and cos recovered to +-pi/256 rad);
 //   MX8   : identity stages and pre-activation gradients, offset-binary int8 with ONE shared power-of-two scale per lane per DF
 //           (16 values): v = (u - 128) * 2^(E - 133), E = biased exponent of 1.0079 * max|v| -- the micro-scaled int8 of the
 //           OCP MX formats with the block laid along a point's features (what a lane holds) instead of along K.
 // activations (per 32-point tile):  aux (auxs bf16 fragments) | a0..a7 (8 DF each, PHASE8) | feats (8 DF, MX8) |
-//   rgbh s1 e1 s2 s3 (4 DF each, PHASE8) | feats scale unit (lane's 16 B: byte t = E of feats DF t) |
-//   SIN8 twins of the PHASE8 units: a0..a7 (64 DF) | rgbh s1 e1 s2 s3 (20 DF)
-constexpr int kA8Trunk = 0, kA8Feats = 64, kA8Rgbh = 72, kA8S1 = 76, kA8E1 = 80, kA8S2 = 84, kA8S3 = 88, kA8Scale = 92, kA8Sin = 93;  // + auxs
-constexpr int act8_sin_unit(int frag) { return kA8Sin + (frag < kActFeats ? frag >> 1 : (frag - kActRgbh + kActFeats) >> 1); }  // logical fragment -> SIN8 unit
-constexpr int act8_units(int auxs) { return auxs + 93 + 84; }
+//   rgbh s1 e1 s2 s3 (4 DF each, PHASE8) | feats scale unit (lane's 16 B: byte t = E of feats DF t)
+constexpr int kA8Trunk = 0, kA8Feats = 64, kA8Rgbh = 72, kA8S1 = 76, kA8E1 = 80, kA8S2 = 84, kA8S3 = 88, kA8Scale = 92;  // + auxs
+constexpr int act8_units(int auxs) { return auxs + 93; }
 // pre-activation gradients:  d_pre_0..7 (8 DF each) | d_feats (8) | d_rgbh d_s1 d_e1 d_s2 d_s3 (4 each) -- all MX8 -- |
 //   d_sigma_pre, d_head (one bf16 fragment each) | 7 scale units: group g = 0..7 trunk layer, 8 feats, 9 rgbh, 10 s1, 11 e1,
 //   12 s2, 13 s3 keeps byte (g & 1) * 8 + t of the lane's 16 B in unit kD8Scale + (g >> 1)

@@ -395,18 +395,14 @@ def backward_maps(feat=256, tau=4):
 # ------------------------------------------------------------------------------------------------ 8-bit workspaces
 # csrc/mlp_layout.h (SR_FMT8): logical 16-bit fragment f of a workspace -> (unit, codec[, scale unit, scale byte]).
 SRC_DPRE, SRC_ACTS = 1, 2
-RAW16, SIN8, MX8 = 0, 1, 2  # codecs the weight-gradient kernel decodes (PHASE8 units are read by the dX kernel only)
-WG8_DUMP_FRAG = 34          # operand fragment nobody multiplies: target of the dummy loads that pad short blocks
+RAW16, PHASE8, MX8 = 0, 1, 2
 WG8_LOAD_INTS = 20
 D8_SIGMA, D8_HEAD, D8_SCALE, D8_UNITS, A8_SCALE = 92, 93, 94, 101, 92
 _DP_SIGMA, _DP_RGBH, _DP_HEAD = 144, 145, 185
 
 
-A8_SIN = 93  # first SIN8 unit (+ auxs): twins of the PHASE8 units a0..a7 (64) and rgbh s1 e1 s2 s3 (20)
-
-
 def act8_units(auxs):
-    return auxs + 93 + 84
+    return auxs + 93
 
 
 def dpre8_source(f):
@@ -430,17 +426,15 @@ def act8_source(f, auxs):
     assert a >= 0, "aux fragments are fetched by the kernel itself"
     if 128 <= a < 144:  # feats: identity stage -> MX8
         return dict(unit=auxs + (a >> 1), codec=MX8, half=a & 1, scale_unit=auxs + A8_SCALE, scale_byte=(a - 128) >> 1)
-    twin = a >> 1 if a < 128 else 64 + ((a - 144) >> 1)  # csrc/mlp_layout.h act8_sin_unit
-    return dict(unit=auxs + A8_SIN + twin, codec=SIN8, half=a & 1)
+    return dict(unit=auxs + (a >> 1), codec=PHASE8, half=a & 1)
 
 
 @functools.lru_cache(maxsize=8)
 def wgrad8_loads(feat=256, tau=4):
     """Load table of csrc/wgrad8.hip for the job blocks of ``backward_maps``: int32 [n_blocks, 20].
 
-    Per block: ints 0..7 = row loads, 8..15 = column loads (bits 0-1 source, 2-3 codec, 4-11 unit, 12-17 operand fragment,
-    18-19 scale area, 20-23 scale byte), ints 16..18 = the scale unit fetched into scale area 0..2 (0 = none), int 19 = the
-    codec of the column loads."""
+    Per block: ints 0..15 = the primary load of wave w (0 = none; bits 0-1 source, 2-3 codec, 4-11 unit, 12-17 operand
+    fragment, 18-19 scale area, 20-23 scale byte), ints 16..18 = the scale unit fetched into scale area 0..2 (0 = none)."""
     bm = backward_maps(feat, tau)
     auxs = bm["auxs"]
     out = np.zeros((len(bm["block_rows"]), WG8_LOAD_INTS), np.int32)
@@ -465,25 +459,11 @@ def wgrad8_loads(feat=256, tau=4):
                         desc |= (area_of(src, d["scale_unit"]) << 18) | (d["scale_byte"] << 20)
                     pos += 2
                 loads.append(desc)
-        assert len(areas) <= 3, (b, len(areas))
-        # ints 0..7 = row loads, 8..15 = column loads: wave w of the 8-wave workgroup fetches and decodes row load w and column
-        # load w.  Every block is padded to 8 + 8 loads with dummies that decode into the dump fragment (the kernel's iteration is
-        # branch-free); int 19 = the codec of the column loads (one per block).
-        row_loads = [d for d in loads if ((d >> 12) & 63) < 16]
-        col_loads = [d for d in loads if ((d >> 12) & 63) >= 16]
-        assert len(row_loads) <= 8 and len(col_loads) <= 8, (b, len(row_loads), len(col_loads))
-        assert all(((d >> 2) & 3) in (MX8, RAW16) for d in row_loads)
-        col_codecs = {(d >> 2) & 3 for d in col_loads}
-        assert len(col_codecs) == 1 and RAW16 not in col_codecs, (b, col_codecs)
-        col_codec = col_codecs.pop()
-        dummy_row = SRC_DPRE | (MX8 << 2) | (0 << 4) | (WG8_DUMP_FRAG << 12)
-        dummy_col = SRC_ACTS | (col_codec << 2) | ((auxs + (A8_SIN if col_codec == SIN8 else 64)) << 4) | (WG8_DUMP_FRAG << 12)
-        # waves 0, 1 also fetch the aux fragments and waves 2..4 the scale units: real loads go to the other waves first
-        order = [5, 6, 7, 4, 3, 2, 1, 0]
-        for k, w in enumerate(order):
-            out[b, w] = row_loads[k] if k < len(row_loads) else dummy_row
-            out[b, 8 + w] = col_loads[k] if k < len(col_loads) else dummy_col
+        assert len(loads) <= 16 and len(areas) <= 3, (b, len(loads), len(areas))
+        # waves 0, 1 also fetch the aux fragments and waves 2..4 the scale units: hand the primaries to the others first
+        order = list(range(5, 16)) + [4, 3, 2, 1, 0]
+        for w, desc in zip(order, loads):
+            out[b, w] = desc
         for k, (src, unit) in enumerate(areas):
             out[b, 16 + k] = src | (unit << 4)
-        out[b, 19] = col_codec
     return out

@@ -45,7 +45,7 @@ def test_version_and_stream_geometry(handle):
     assert handle.sr_fwd_stream_elems(512, 4) == -1
     assert handle.sr_fwd_stream_elems(256, 25) == -1
     assert handle.sr_act_elems_per_tile(256, 16) == 186 * 512 and handle.sr_dpre_elems_per_tile(256, 16) == 186 * 512
-    assert handle.sr_act_elems_per_tile(256, 8) == 179 * 512 and handle.sr_dpre_elems_per_tile(256, 8) == 101 * 512  # the 8-bit workspaces
+    assert handle.sr_act_elems_per_tile(256, 8) == 95 * 512 and handle.sr_dpre_elems_per_tile(256, 8) == 101 * 512  # the 8-bit workspaces
     assert handle.sr_act_elems_per_tile(256, 4) == -1 and handle.sr_wgrad8_load_ints() == packing.WG8_LOAD_INTS
 
 
