@@ -163,10 +163,14 @@ int sr_ray_setup_rng(const float* rays, int ray_stride, uint64_t seed, const flo
                      void* stream);
 int sr_render_loss(const float* z_vals, const float* sigma, const float* noise, float noise_std, const float* albedo,
                    const float* sun_v, const float* beta, const float* sky, const float* target, int64_t n_rays, int n_samples,
-                   float beta_min, float* loss_parts, float* rgb, float* d_sigma, float* d_albedo, float* d_sun_v, float* g_beta,
-                   float* d_sky, void* stream);
+                   float beta_min, const float* sched, float* loss_parts, float* rgb, float* d_sigma, float* d_albedo, float* d_sun_v,
+                   float* g_beta, float* d_sky, void* stream);
 
-/* sr_grad_tail = sr_unpack_grads + sr_sky_bwd + sr_embedding_bwd as three block ranges of one launch (training fast path);
+/* `sched` (NULL = none) is the DEVICE-side schedule block of a captured training step, 4 floats the host updates between graph
+ * replays: [0] 1-based optimizer step (ticked by sr_pack_all), [1] learning rate (sr_adam_step_graph with lr < 0 reads it:
+ * StepLR(gamma 0.9) per epoch, main.py:86-94 / train_utils.py:41-57), [2] != 0 while the SNerfLoss warm-up lasts (the colour loss
+ * is then the plain MSE of metrics.SNerfLoss, main.py:128-131 -- no beta term, no beta gradient), [3] reserved.
+ * sr_grad_tail = sr_unpack_grads + sr_sky_bwd + sr_embedding_bwd as three block ranges of one launch (training fast path);
  * sr_adam_step_graph = sr_adam_step with the 1-based step count read from the device (state[0], advanced by sr_pack_all's
  * `tick` earlier in the same step) so the launch can be replayed from a hipGraph. */
 int sr_grad_tail(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, const int32_t* blocks,
@@ -227,8 +231,8 @@ int sr_latlonalt_from_depth(const float* rays, int ray_stride, const float* dept
  * sr_adam_step: torch.optim.Adam update (main.py:84) over a flat buffer; `step` is the 1-based step count; grads are
  * multiplied by grad_scale first and zeroed afterwards when zero_grad != 0. */
 int sr_satnerf_loss(const float* rgb, const float* weights, const float* beta, const float* target, int64_t n_rays,
-                    int n_samples, float beta_min, float grad_scale, float* loss_parts, float* g_rgb, float* g_weights,
-                    float* g_beta, void* stream);
+                    int n_samples, float beta_min, float grad_scale, const float* sched, float* loss_parts, float* g_rgb,
+                    float* g_weights, float* g_beta, void* stream);
 /* batch gather from a GPU-resident ray bank: rows idx[0..n) of rays (.,11), rgbs (.,3), ts (.) -> contiguous batch tensors
  * (replaces DataLoader collate + host-to-device copy, main.py:96-110) */
 int sr_gather_batch(const float* rays, const float* rgbs, const int64_t* ts, const int64_t* idx, int64_t n, float* out_rays,

@@ -6,6 +6,10 @@
 
 namespace sr {
 
+// device-side schedule block of the captured training step (4 floats, satnerf_amd.train.Trainer.sched): [0] 1-based optimizer
+// step (ticked by sr_pack_all), [1] learning rate, [2] != 0 while the SNerfLoss warm-up epochs last, [3] reserved
+enum { kSchedStep = 0, kSchedLr = 1, kSchedWarm = 2 };
+
 __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
@@ -19,9 +23,11 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // value is sum(loss_parts) and only logging reads it); g_* are the gradients w.r.t. rgb (N,3), weights (N,S), beta (N,S).
 __global__ void __launch_bounds__(256) satnerf_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ weights,
                                                           const float* __restrict__ beta, const float* __restrict__ target, long n_rays, int S,
-                                                          float beta_min, float grad_scale, float* __restrict__ loss_parts,
-                                                          float* __restrict__ g_rgb, float* __restrict__ g_weights, float* __restrict__ g_beta) {
+                                                          float beta_min, float grad_scale, const float* __restrict__ sched,
+                                                          float* __restrict__ loss_parts, float* __restrict__ g_rgb,
+                                                          float* __restrict__ g_weights, float* __restrict__ g_beta) {
   __shared__ float part[4];
+  const bool warm = sched != nullptr && sched[kSchedWarm] != 0.f;  // SNerfLoss epochs (main.py:128-131): plain MSE, no beta
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long r = (long)blockIdx.x * 4 + wv;
   if (lane == 0) part[wv] = 0.f;
@@ -34,10 +40,10 @@ __global__ void __launch_bounds__(256) satnerf_loss_kernel(const float* __restri
   float d0 = 0.f, d1 = 0.f, d2 = 0.f;
   if (on) d0 = rgb[r * 3] - target[r * 3], d1 = rgb[r * 3 + 1] - target[r * 3 + 1], d2 = rgb[r * 3 + 2] - target[r * 3 + 2];
   const float sq = d0 * d0 + d1 * d1 + d2 * d2;
-  const float ib2 = 1.0f / (b * b);
+  const float ib2 = warm ? 2.0f : 1.0f / (b * b);  // MSE = the same expression with beta^2 = 1/2 and no log term
   if (lane == 0 && on) {
-    float contrib = sq * ib2 * (0.5f / 3.0f) * inv_n + 0.5f * logf(b) * inv_n;
-    if (r == 0) contrib += 1.5f;
+    float contrib = sq * ib2 * (0.5f / 3.0f) * inv_n + (warm ? 0.f : 0.5f * logf(b) * inv_n);
+    if (r == 0 && !warm) contrib += 1.5f;
     part[wv] = contrib;
     const float k = ib2 * (1.0f / 3.0f) * inv_n * grad_scale;
     g_rgb[r * 3] = d0 * k, g_rgb[r * 3 + 1] = d1 * k, g_rgb[r * 3 + 2] = d2 * k;
@@ -46,7 +52,7 @@ __global__ void __launch_bounds__(256) satnerf_loss_kernel(const float* __restri
   if (threadIdx.x == 0) loss_parts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
   if (!on) return;
   // d loss / d beta_r = -sq / (3 N beta^3) + 1 / (2 N beta)
-  const float db = (-sq * ib2 / b * (1.0f / 3.0f) + 0.5f / b) * inv_n * grad_scale;
+  const float db = warm ? 0.f : (-sq * ib2 / b * (1.0f / 3.0f) + 0.5f / b) * inv_n * grad_scale;
   for (int j = lane; j < S; j += 64) {
     g_weights[r * S + j] = db * beta[r * S + j];
     g_beta[r * S + j] = db * weights[r * S + j];
@@ -101,10 +107,11 @@ __global__ void __launch_bounds__(256) render_loss_kernel(const float* __restric
                                                          const float* __restrict__ noise, float noise_std, const float* __restrict__ albedo,
                                                          const float* __restrict__ sun_v, const float* __restrict__ beta,
                                                          const float* __restrict__ sky, const float* __restrict__ target, long n_rays, int S,
-                                                         float beta_min, float* __restrict__ loss_parts, float* __restrict__ rgb_out,
-                                                         float* __restrict__ d_sigma, float* __restrict__ d_albedo, float* __restrict__ d_sun,
-                                                         float* __restrict__ g_beta, float* __restrict__ d_sky) {
+                                                         float beta_min, const float* __restrict__ sched, float* __restrict__ loss_parts,
+                                                         float* __restrict__ rgb_out, float* __restrict__ d_sigma, float* __restrict__ d_albedo,
+                                                         float* __restrict__ d_sun, float* __restrict__ g_beta, float* __restrict__ d_sky) {
   __shared__ float part[4];
+  const bool warm = sched != nullptr && sched[kSchedWarm] != 0.f;  // SNerfLoss epochs (main.py:128-131): plain MSE, no beta
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long r = (long)blockIdx.x * 4 + wv;
   if (lane == 0) part[wv] = 0.f;
@@ -144,10 +151,10 @@ __global__ void __launch_bounds__(256) render_loss_kernel(const float* __restric
   float e0 = 0.f, e1 = 0.f, e2 = 0.f;
   if (ray_on) e0 = r0 - target[r * 3], e1 = r1 - target[r * 3 + 1], e2 = r2 - target[r * 3 + 2];
   const float sq = e0 * e0 + e1 * e1 + e2 * e2;
-  const float ib2 = 1.0f / (b * b);
+  const float ib2 = warm ? 2.0f : 1.0f / (b * b);  // metrics.SNerfLoss colour term = the same expression with beta^2 = 1/2, no log term
   if (lane == 0 && ray_on) {
-    float contrib = sq * ib2 * (0.5f / 3.0f) * inv_n + 0.5f * logf(b) * inv_n;
-    if (r == 0) contrib += 1.5f;
+    float contrib = sq * ib2 * (0.5f / 3.0f) * inv_n + (warm ? 0.f : 0.5f * logf(b) * inv_n);
+    if (r == 0 && !warm) contrib += 1.5f;
     part[wv] = contrib;
     if (rgb_out) rgb_out[r * 3] = r0, rgb_out[r * 3 + 1] = r1, rgb_out[r * 3 + 2] = r2;
   }
@@ -158,7 +165,7 @@ __global__ void __launch_bounds__(256) render_loss_kernel(const float* __restric
   const float gr0 = (c0 >= 0.f && c0 <= 1.f) ? e0 * kk : 0.f;  // torch.clamp passes the gradient where min <= x <= max
   const float gr1 = (c1 >= 0.f && c1 <= 1.f) ? e1 * kk : 0.f;
   const float gr2 = (c2 >= 0.f && c2 <= 1.f) ? e2 * kk : 0.f;
-  const float db = (-sq * ib2 / b * (1.0f / 3.0f) + 0.5f / b) * inv_n;  // d loss / d beta_r
+  const float db = warm ? 0.f : (-sq * ib2 / b * (1.0f / 3.0f) + 0.5f / b) * inv_n;  // d loss / d beta_r
   // backward through compositing: G_j = dL/dw_j
   const float G = db * bj + gr0 * a0 * i0 + gr1 * a1 * i1 + gr2 * a2 * i2;
   const float tail = on ? G * w : 0.f;
@@ -217,10 +224,11 @@ __global__ void __launch_bounds__(256) adam_graph_kernel(float* __restrict__ p, 
                                                         float grad_scale, const float* __restrict__ state, int zero_grad) {
   __shared__ float bc[2];
   if (threadIdx.x == 0) {
-    const float t = state[0];
+    const float t = state[kSchedStep];
     bc[0] = 1.0f - powf(b1, t), bc[1] = 1.0f - powf(b2, t);
   }
   __syncthreads();
+  if (lr < 0.f) lr = state[kSchedLr];  // the scheduler's current rate (StepLR per epoch, main.py:86-94) under graph replay
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float gi = g[i] * grad_scale;
@@ -236,12 +244,12 @@ __global__ void __launch_bounds__(256) adam_graph_kernel(float* __restrict__ p, 
 using namespace sr;
 
 extern "C" int sr_satnerf_loss(const float* rgb, const float* weights, const float* beta, const float* target, int64_t n_rays, int n_samples,
-                               float beta_min, float grad_scale, float* loss_parts, float* g_rgb, float* g_weights, float* g_beta,
-                               void* stream) {
+                               float beta_min, float grad_scale, const float* sched, float* loss_parts, float* g_rgb, float* g_weights,
+                               float* g_beta, void* stream) {
   SR_REQUIRE(rgb && weights && beta && target && loss_parts && g_rgb && g_weights && g_beta, "sr_satnerf_loss: null pointer");
   if (n_rays <= 0) return 0;
   hipLaunchKernelGGL(satnerf_loss_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rgb, weights, beta, target,
-                     (long)n_rays, n_samples, beta_min, grad_scale, loss_parts, g_rgb, g_weights, g_beta);
+                     (long)n_rays, n_samples, beta_min, grad_scale, sched, loss_parts, g_rgb, g_weights, g_beta);
   return check_launch("satnerf_loss_kernel");
 }
 
@@ -316,15 +324,15 @@ extern "C" int sr_depth_loss(const float* depth, const float* depths, int depths
 
 extern "C" int sr_render_loss(const float* z_vals, const float* sigma, const float* noise, float noise_std, const float* albedo,
                               const float* sun_v, const float* beta, const float* sky, const float* target, int64_t n_rays, int n_samples,
-                              float beta_min, float* loss_parts, float* rgb, float* d_sigma, float* d_albedo, float* d_sun_v, float* g_beta,
-                              float* d_sky, void* stream) {
+                              float beta_min, const float* sched, float* loss_parts, float* rgb, float* d_sigma, float* d_albedo,
+                              float* d_sun_v, float* g_beta, float* d_sky, void* stream) {
   SR_REQUIRE(z_vals && sigma && albedo && sun_v && beta && sky && target && loss_parts && d_sigma && d_albedo && d_sun_v && g_beta && d_sky,
              "sr_render_loss: null pointer");
   SR_REQUIRE(n_samples >= 1 && n_samples <= 64, "sr_render_loss: n_samples=%d unsupported (1..64); use the separate kernels", n_samples);
   if (n_rays <= 0) return 0;
   hipLaunchKernelGGL(render_loss_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z_vals, sigma, noise, noise_std,
-                     albedo, sun_v, beta, sky, target, (long)n_rays, n_samples, beta_min, loss_parts, rgb, d_sigma, d_albedo, d_sun_v, g_beta,
-                     d_sky);
+                     albedo, sun_v, beta, sky, target, (long)n_rays, n_samples, beta_min, sched, loss_parts, rgb, d_sigma, d_albedo, d_sun_v,
+                     g_beta, d_sky);
   return check_launch("render_loss_kernel");
 }
 

@@ -373,7 +373,7 @@ def embedding_bwd(d_t, ts, n_rays, n_samples, tau, g_emb):
     _lib.call("sr_embedding_bwd", _p(_chk(d_t, "d_t")), _p(_chk(ts, "ts", torch.int64)), n_rays, n_samples, tau, _p(_chk(g_emb, "g_emb")), _stream())
 
 
-def satnerf_loss(rgb, weights, beta, target, beta_min=0.05, grad_scale=1.0):
+def satnerf_loss(rgb, weights, beta, target, beta_min=0.05, grad_scale=1.0, sched=None):
     """Fused SatNerfLoss forward + gradient: returns (loss partial sums (ceil(N/4),) -- the loss is their sum --, g_rgb (N,3),
     g_weights (N,S), g_beta (N,S))."""
     n, s = weights.shape
@@ -383,7 +383,7 @@ def satnerf_loss(rgb, weights, beta, target, beta_min=0.05, grad_scale=1.0):
     g_w = torch.empty(n, s, dtype=torch.float32, device=dev)
     g_b = torch.empty(n, s, dtype=torch.float32, device=dev)
     _lib.call("sr_satnerf_loss", _p(_chk(rgb, "rgb")), _p(_chk(weights, "weights")), _p(_chk(beta, "beta")), _p(_chk(target, "target")), n, s,
-              float(beta_min), float(grad_scale), _p(loss), _p(g_rgb), _p(g_w), _p(g_b), _stream())
+              float(beta_min), float(grad_scale), _p(_chk(sched, "sched", allow_none=True)), _p(loss), _p(g_rgb), _p(g_w), _p(g_b), _stream())
     return loss, g_rgb, g_w, g_b
 
 
@@ -434,7 +434,7 @@ def ray_setup(rays, u, n_samples, w1, b1, w2, b2, seed=0, step_counter=None):
     return z, sky_rgb
 
 
-def render_loss(z, sigma, noise, noise_std, albedo, sun_v, beta, sky_rgb, target, beta_min=0.05):
+def render_loss(z, sigma, noise, noise_std, albedo, sun_v, beta, sky_rgb, target, beta_min=0.05, sched=None):
     """Fused compositing forward + SatNerf loss + compositing backward (S <= 64).
     Returns (loss partial sums, rgb (N,3), d_sigma (N,S), d_albedo (N,S,3), d_sun (N,S), g_beta (N,S), d_sky (N,3))."""
     n, s = z.shape
@@ -443,7 +443,8 @@ def render_loss(z, sigma, noise, noise_std, albedo, sun_v, beta, sky_rgb, target
     loss, rgb, d_sigma, d_albedo, d_sun, g_beta, d_sky = e((n + 3) // 4), e(n, 3), e(n, s), e(n, s, 3), e(n, s), e(n, s), e(n, 3)
     _lib.call("sr_render_loss", _p(_chk(z, "z")), _p(_chk(sigma, "sigma")), _p(_chk(noise, "noise", allow_none=True)), float(noise_std),
               _p(_chk(albedo, "albedo")), _p(_chk(sun_v, "sun_v")), _p(_chk(beta, "beta")), _p(_chk(sky_rgb, "sky")), _p(_chk(target, "target")), n, s,
-              float(beta_min), _p(loss), _p(rgb), _p(d_sigma), _p(d_albedo), _p(d_sun), _p(g_beta), _p(d_sky), _stream())
+              float(beta_min), _p(_chk(sched, "sched", allow_none=True)), _p(loss), _p(rgb), _p(d_sigma), _p(d_albedo), _p(d_sun), _p(g_beta), _p(d_sky),
+              _stream())
     return loss, rgb, d_sigma, d_albedo, d_sun, g_beta, d_sky
 
 

@@ -43,6 +43,18 @@ def satnerf_loss(res, target, lambda_sc=0.0, beta_min=0.05):
     return loss
 
 
+def snerf_loss(res, target, lambda_sc=0.0):
+    """``metrics.SNerfLoss`` for the coarse model (metrics.py:36-54): plain MSE + the solar-correction terms; what a sat-nerf
+    run trains with during its first two epochs (main.py:128-131)."""
+    loss = torch.mean((res["rgb_coarse"] - target) ** 2)
+    if lambda_sc > 0:
+        sun_sc = res["sun_sc_coarse"].squeeze(-1)
+        term2 = torch.sum(torch.square(res["transparency_sc_coarse"].detach() - sun_sc), -1)
+        term3 = 1 - torch.sum(res["weights_sc_coarse"].detach() * sun_sc, -1)
+        loss = loss + lambda_sc / 3.0 * torch.mean(term2) + lambda_sc / 3.0 * torch.mean(term3)
+    return loss
+
+
 def nerf_loss(res, target):
     """``metrics.NerfLoss`` (metrics.py:8-19): MSE of the coarse [+ fine] colour."""
     loss = torch.mean((res["rgb_coarse"] - target) ** 2)
@@ -135,16 +147,29 @@ class Trainer:
     Anything else goes through ``render_rays`` + autograd + the same flat buffers.
     """
 
-    def __init__(self, models, args, world_size=1, lr=5e-4, loss_fn=None, use_graph=True):
+    def __init__(self, models, args, world_size=1, lr=5e-4, loss_fn=None, use_graph=True, steps_per_epoch=None, lr_gamma=0.9,
+                 warmup_epochs=2):
+        """``steps_per_epoch`` (= len(dataset) // batch_size, train_utils.py:14-15) switches the reference's schedule on:
+        StepLR(step_size=1, gamma=``lr_gamma``) per epoch (main.py:86-94, train_utils.py:41-57) and ``metrics.SNerfLoss`` instead
+        of ``SatNerfLoss`` while epoch < ``warmup_epochs`` (main.py:128-131 hard-codes 2).  None = constant rate, SatNerfLoss
+        from the first step (what bench.py measures)."""
         self.models, self.args, self.world, self.lr = models, args, world_size, lr
+        self.lr0, self.lr_gamma, self.steps_per_epoch, self.warmup_epochs = lr, lr_gamma, steps_per_epoch, warmup_epochs
+        if args.model == "sat-nerf" and args.n_importance > 0 and loss_fn is None:
+            # metrics.py:22 multiplies weights_fine (N,S+I,1) with beta_coarse (N,S,1): the reference cannot train this combination
+            # either (SURVEY.md section 4); training only the coarse model while eval renders the fine one would be silently wrong
+            raise NotImplementedError("sat-nerf with n_importance > 0 has no trainable reference loss (metrics.py:22 shape error): pass loss_fn")
         mods = [models["coarse"]] + ([models["fine"]] if "fine" in models else []) + ([models["t"]] if "t" in models else [])
         self.state = FlatState(mods)
         p = self.state.params
         self.exp_avg, self.exp_avg_sq = torch.zeros_like(p), torch.zeros_like(p)
         self.n_steps = 0
-        # device-side step counter, ticked by the step's first launch: the in-graph Adam's step count and the step of the
-        # in-kernel jitter RNG of captured steps
-        self.adam_state = torch.zeros(1, dtype=torch.float32, device=p.device)
+        # device-side schedule block (include/satrender.h `sched`): [0] step counter, ticked by the step's first launch (the in-graph
+        # Adam's step count and the step of the in-kernel jitter RNG of captured steps), [1] learning rate, [2] SNerfLoss warm-up flag
+        self.adam_state = torch.zeros(4, dtype=torch.float32, device=p.device)
+        self.sched = self.adam_state
+        self._sched_host = None
+        self._apply_schedule()
         self._kernel_rng = False
         self._seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
         self._adam_in_graph = False
@@ -186,10 +211,11 @@ class Trainer:
                                                      hi, lo, l0, acts=acts, fmt=fmt)
         if s <= 64:  # one launch: compositing forward -> loss -> compositing backward
             loss, self.last_rgb, d_sigma, d_albedo, d_sun, g_beta, d_sky = ops.render_loss(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3),
-                                                                                           sun_v.view(n, s), beta.view(n, s), sky, rgbs)
+                                                                                           sun_v.view(n, s), beta.view(n, s), sky, rgbs,
+                                                                                           sched=self.sched)
         else:
             weights, transp, _, rgb = ops.composite(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky)
-            loss, g_rgb, g_w, g_beta = ops.satnerf_loss(rgb, weights, beta.view(n, s), rgbs)
+            loss, g_rgb, g_w, g_beta = ops.satnerf_loss(rgb, weights, beta.view(n, s), rgbs, sched=self.sched)
             d_sigma, d_albedo, d_sun, d_sky = ops.composite_bwd(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky,
                                                                weights, transp, g_rgb, None, g_w, None)
             self.last_rgb = rgb
@@ -203,7 +229,8 @@ class Trainer:
         if depth is not None:
             loss = torch.cat([loss.view(-1), self._depth_pass(*depth, noise_std * 0.9).view(-1)])  # main.py:132 decays the noise first
         if self.world == 1 and self._adam_in_graph:  # no all-reduce to wait for: the update rides in the same graph
-            ops.adam_step_graph(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.adam_state, lr=self.lr, zero_grad=True)
+            # lr < 0: the kernel reads the current rate from sched[1], so a scheduler can change it under graph replay
+            ops.adam_step_graph(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.adam_state, lr=-1.0, zero_grad=True)
         return loss
 
     def _sc_pass(self, rays, ts, z, noise_std):
@@ -259,6 +286,39 @@ class Trainer:
                           loads=maps["loads8"])
         return loss
 
+    # ---- schedule (main.py:86-94,128-131) ------------------------------------------------------------------------------------
+    def current_epoch(self):
+        """``NeRF_pl.get_current_epoch`` (train_utils.py:14-15) of the step about to run: main.py:121 counts the step first
+        (``self.train_steps += 1``), so step k (0-based) sees epoch (k + 1) // steps_per_epoch."""
+        return 0 if not self.steps_per_epoch else (self.n_steps + 1) // int(self.steps_per_epoch)
+
+    def warming_up(self):
+        """True while the reference trains with SNerfLoss (main.py:128: sat-nerf, epoch < 2)."""
+        return bool(self.steps_per_epoch) and self.args.model == "sat-nerf" and self.current_epoch() < self.warmup_epochs
+
+    def _apply_schedule(self):
+        """Write [lr, warm-up flag] of the step about to run into the device-side schedule block when they changed (once per epoch)."""
+        if self.steps_per_epoch:
+            self.lr = self.lr0 * self.lr_gamma ** self.current_epoch()  # StepLR(step_size=1, gamma)
+        host = (float(self.lr), 1.0 if self.warming_up() else 0.0)
+        if host != self._sched_host:
+            self.adam_state[1:3].copy_(torch.tensor(host, dtype=torch.float32))
+            self._sched_host = host
+
+    def set_lr(self, lr):
+        self.lr0 = self.lr = float(lr)
+        self._apply_schedule()
+
+    def save_ckpt(self, path):
+        """A checkpoint ``eval_satnerf.load_nerf`` / ``checkpoint.load_ckpt`` can read: Lightning's ``state_dict`` key prefixes
+        (main.py:51-58: nerf_coarse. / nerf_fine. / embedding_t.) plus the optimizer moments and the step count."""
+        sd = {}
+        for prefix, key in (("nerf_coarse.", "coarse"), ("nerf_fine.", "fine"), ("embedding_t.", "t")):
+            if key in self.models:
+                sd.update({prefix + k: v.detach().cpu().clone() for k, v in self.models[key].state_dict().items()})
+        torch.save({"state_dict": sd, "global_step": self.n_steps, "epoch": self.current_epoch(),
+                    "optimizer": {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "lr": self.lr, "step": self.n_steps}}, path)
+
     def _capture(self, inputs):
         self._static = tuple(t.clone() for t in inputs)
         self._adam_in_graph = self.world == 1
@@ -274,7 +334,8 @@ class Trainer:
         torch.cuda.synchronize()
         self.state.zero_grad()
         if self._adam_in_graph:  # the warm-up passes stepped the optimizer: roll them back
-            self.state.params.copy_(snapshot[0]), self.exp_avg.copy_(snapshot[1]), self.exp_avg_sq.copy_(snapshot[2]), self.adam_state.copy_(snapshot[3])
+            self.state.params.copy_(snapshot[0]), self.exp_avg.copy_(snapshot[1]), self.exp_avg_sq.copy_(snapshot[2])
+        self.adam_state.copy_(snapshot[3])  # ... and ticked the step counter (the jitter RNG's step) in every configuration
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._static_loss = run()
@@ -297,6 +358,7 @@ class Trainer:
 
         if depth is not None and not float(getattr(self.args, "ds_lambda", 0.0)) > 0:
             raise ValueError("a depth batch was passed but args.ds_lambda is not > 0 (main.py:51)")
+        self._apply_schedule()
         if self.direct:
             inputs = (rays, ts, rgbs) + (tuple(depth) if depth is not None else ())
             if self.use_graph and float(self.args.noise_std) == 0.0:
@@ -322,8 +384,14 @@ class Trainer:
             from .rendering import render_rays
 
             res = render_rays(self.models, self.args, rays, ts)
-            loss_fn = self.loss_fn or (nerf_loss if self.args.model == "nerf" else
-                                       lambda r, t: satnerf_loss(r, t, getattr(self.args, "sc_lambda", 0.0)))  # metrics.load_loss
+            if self.loss_fn is not None:
+                loss_fn = self.loss_fn
+            elif self.args.model == "nerf":
+                loss_fn = nerf_loss
+            elif self.warming_up():  # metrics.SNerfLoss for the first epochs (main.py:128-131)
+                loss_fn = lambda r, t: snerf_loss(r, t, getattr(self.args, "sc_lambda", 0.0))  # noqa: E731
+            else:
+                loss_fn = lambda r, t: satnerf_loss(r, t, getattr(self.args, "sc_lambda", 0.0))  # noqa: E731  metrics.load_loss
             loss = loss_fn(res, rgbs)
             if depth is not None:
                 d_rays, d_ts, d_depths = depth

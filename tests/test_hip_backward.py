@@ -485,10 +485,14 @@ def test_coarse_plus_fine_gradients_and_training():
         assert errs[worst] < GRAD_TOL, errs
     assert maxnorm_rel(models["t"].weight.grad.cpu(), eo.grad) < GRAD_TOL
     targs = O.default_args(n_importance=32, mlp_mode="bf16")
-    tr = Trainer(models, targs)
+    with pytest.raises(NotImplementedError):  # the reference's SatNerfLoss cannot train sat-nerf + fine (metrics.py:22): no silent coarse-only loss
+        Trainer(models, targs)
+    tr = Trainer(models, targs, loss_fn=loss_of)
     assert not tr.direct and tr.state.params.numel() == 2 * 662537 + 120
+    fine0 = models["fine"].flat_params().detach().clone()
     losses = [tr.step(rays.to(DEV), ts.to(DEV), target.to(DEV)).item() for _ in range(10)]
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
+    assert (models["fine"].flat_params().detach() - fine0).abs().max().item() > 0  # the fine model is trained too
 
 
 def test_direct_step_with_solar_correction_matches_autograd_path():

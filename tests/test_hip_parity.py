@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import satnerf_oracle as O
-from tests.helpers import golden_cfg, golden_draws, load_golden, maxnorm_rel
+from tests.helpers import make_models, golden_cfg, golden_draws, load_golden, maxnorm_rel
 
 pytestmark = pytest.mark.gpu
 
@@ -221,6 +221,20 @@ def test_large_batch_properties_full_size():
         b = rendering.render_rays(models, args, rays[500:].to(DEV), ts[500:].to(DEV))
     for k in ("rgb_coarse", "depth_coarse", "weights_coarse"):
         assert torch.equal(full[k], torch.cat([a[k], b[k]], 0)), k
+    # sampled oracle comparison at the headline size: 48 rays spread over the batch, same draws, parity mode <= 1e-4
+    pick = torch.arange(0, 1024, 21)[:48]
+    mo = make_models(args)
+    want = O.render_rays(mo, args, rays[pick], ts[pick], O.ReplayRng([u[pick].cpu(), nz[pick].cpu()]))
+    errs = {k: maxnorm_rel(full[k][pick.to(DEV)].cpu(), want[k]) for k in ("rgb_coarse", "depth_coarse", "weights_coarse", "beta_coarse", "sun_coarse")}
+    print("bf16x3 @1024x64", {k: f"{e:.1e}" for k, e in errs.items()})
+    assert max(errs.values()) < 1e-4, errs
+    # the throughput arithmetic (single-pass bf16) on the same batch: reported, and bounded at the level bf16 operands allow
+    fast = O.default_args(mlp_mode="bf16")
+    with torch.no_grad(), rendering.replay_rng([u, nz]):
+        fres = rendering.render_rays(build_models(fast), fast, rays.to(DEV), ts.to(DEV))
+    ferrs = {k: maxnorm_rel(fres[k][pick.to(DEV)].cpu(), want[k]) for k in ("rgb_coarse", "depth_coarse", "weights_coarse")}
+    print("bf16   @1024x64", {k: f"{e:.1e}" for k, e in ferrs.items()})
+    assert max(ferrs.values()) < 2e-2, ferrs
 
 
 def test_width_512_golden_through_the_layer_path():

@@ -1,0 +1,259 @@
+"""Training-step semantics of the HIP path (main.py:81-154): the fused Adam against torch.optim.Adam, the reference's schedule
+(StepLR per epoch, SNerfLoss warm-up) under graph replay, depth supervision at BASELINE configs[3] size, and the data-parallel
+Trainer.step with two ranks on one GPU."""
+import os
+import socket
+
+import pytest
+import torch
+
+from oracle import satnerf_oracle as O
+from tests.helpers import load_golden, golden_draws, make_models, maxnorm_rel
+from tests.test_hip_parity import DEV, build_models
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_fused_adam_matches_torch_adam(graph):
+    """sr_adam_step / sr_adam_step_graph == torch.optim.Adam(lr, betas (0.9, 0.999), eps 1e-8) on identical gradients over 12 steps,
+    including a learning-rate change midway (the graph variant reads step and rate from the device-side schedule block)."""
+    from satnerf_amd import ops
+
+    n = 662537 + 120
+    g = torch.Generator().manual_seed(3)
+    p0 = (torch.rand(n, generator=g) - 0.5) * 0.3
+    ref_p = torch.nn.Parameter(p0.clone().double())  # fp64 reference of the same recurrence
+    ref32 = torch.nn.Parameter(p0.clone().to(DEV))   # torch's own fp32 GPU Adam
+    opt64 = torch.optim.Adam([ref_p], lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0)
+    opt32 = torch.optim.Adam([ref32], lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0)
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    sched = torch.zeros(4, device=DEV)
+    lr = 5e-4
+    for step in range(1, 13):
+        if step == 7:  # StepLR(gamma=0.9) at an epoch boundary
+            lr *= 0.9
+            for o in (opt64, opt32):
+                o.param_groups[0]["lr"] = lr
+        grad = torch.randn(n, generator=g) * (10.0 ** torch.randint(-6, 1, (n,), generator=g).float())  # gradients over 6 decades
+        ref_p.grad, ref32.grad = grad.double(), grad.to(DEV)
+        opt64.step(), opt32.step()
+        gdev = (grad * 2.0).to(DEV)  # the kernel undoes this with grad_scale = 0.5 (the 1 / world_size of the data-parallel step)
+        if graph:
+            sched[0] = float(step)
+            sched[1] = lr
+            ops.adam_step_graph(p, gdev, m, v, sched, lr=-1.0, grad_scale=0.5, zero_grad=True)
+        else:
+            ops.adam_step(p, gdev, m, v, step, lr=lr, grad_scale=0.5, zero_grad=True)
+        assert float(gdev.abs().max()) == 0.0  # zero_grad
+    err64 = maxnorm_rel(p.cpu(), ref_p.detach())
+    err32 = maxnorm_rel(p.cpu(), ref32.detach().cpu())
+    upd = maxnorm_rel((p.cpu() - p0), (ref_p.detach() - p0.double()))  # on the update itself, not hidden behind the parameter's magnitude
+    print(f"adam graph={graph}: vs fp64 {err64:.1e}, vs torch fp32 {err32:.1e}, update {upd:.1e}")
+    assert err64 < 1e-6 and err32 < 1e-6 and upd < 1e-4  # (fp32 parameter storage: 12 roundings of |p| ~ 0.15 against updates of ~6e-3)
+
+
+def test_schedule_lr_decay_and_snerf_warmup_under_graph_replay():
+    """steps_per_epoch switches on StepLR(0.9)/epoch and the SNerfLoss warm-up (main.py:86-94,128-131).  The captured step must
+    follow both without re-capture: loss values equal the torch formulations on the trainer's own rendering, the parameter
+    update of a step scales with the scheduled rate."""
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    torch.manual_seed(0)
+    args = O.default_args(mlp_mode="bf16")
+    model = load_model(args).to(DEV)
+    emb = torch.nn.Embedding(30, 4).to(DEV)
+    tr = Trainer({"coarse": model, "t": emb}, args, steps_per_epoch=3, warmup_epochs=2)
+    rays, ts = O.synthetic_rays(256, seed=3)
+    rays, ts = rays.to(DEV), ts.to(DEV)
+    target = (torch.rand(256, 3, generator=torch.Generator().manual_seed(4)) * 0.2 + 0.4).to(DEV)
+    seen = []
+    for k in range(9):
+        before = tr.state.params.clone()
+        loss = tr.step(rays, ts, target).item()
+        epoch = (k + 1) // 3
+        assert tr._graph is not None  # one capture serves every epoch
+        assert abs(tr.lr - 5e-4 * 0.9 ** epoch) < 1e-12
+        assert float(tr.sched[1]) == pytest.approx(5e-4 * 0.9 ** epoch, rel=1e-6) and float(tr.sched[2]) == (1.0 if epoch < 2 else 0.0)
+        rgb = tr.last_rgb
+        mse = torch.mean((rgb - target) ** 2).item()
+        if epoch < 2:  # metrics.SNerfLoss (lambda_sc = 0): plain MSE
+            assert loss == pytest.approx(mse, rel=1e-4), (k, loss, mse)
+        else:          # metrics.SatNerfLoss: > the MSE (log-beta term + 3/2)
+            assert loss > 1.0 > mse
+        step_size = (tr.state.params - before).abs().max().item()
+        seen.append((epoch, step_size))
+    # Adam's first updates are ~lr per coordinate: the largest update of an epoch's first step tracks the decayed rate
+    assert seen[0][1] == pytest.approx(5e-4, rel=0.05)
+    assert all(s <= 5e-4 * 0.9 ** e * 1.2 for e, s in seen)
+
+
+def test_snerf_warmup_loss_matches_reference_golden_and_autograd_path():
+    """(i) the torch SNerfLoss formulation on the reference's own batched results == the stored metrics.SNerfLoss value;
+    (ii) the kernel-direct step in warm-up mode == render_rays under autograd + that formulation (value and gradients)."""
+    from satnerf_amd import rendering
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer, snerf_loss
+
+    g = load_golden("batched_losses")
+    args = O.default_args(chunk=100, sc_lambda=0.05, mlp_mode="bf16x3")
+    models = build_models(args)
+    draws = [x.to(DEV) for x in golden_draws(g)]
+    rays, ts = g["rays"].to(DEV), g["ts"].to(DEV)
+    with torch.no_grad(), rendering.replay_rng(draws):
+        outs = [rendering.render_rays(models, args, rays[i:i + 100], ts[i:i + 100]) for i in range(0, 250, 100)]
+    res = {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+    l_sn = snerf_loss(res, g["target"].to(DEV), lambda_sc=0.05)
+    assert abs(l_sn.item() - float(g["loss_snerf"])) < 1e-4 * abs(float(g["loss_snerf"]))
+
+    args = O.default_args(mlp_mode="bf16x3", sc_lambda=0.1)
+    params = O.procedural_satnerf_params(256, 4, seed=111)
+    m = load_model(args)
+    m.load_state_dict(params)
+    emb = torch.nn.Embedding(30, 4)
+    emb.load_state_dict({"weight": O.procedural_uniform((30, 4), 1.0, 112)})
+    models = {"coarse": m.to(DEV), "t": emb.to(DEV)}
+    rays, ts = O.synthetic_rays(160, seed=113)
+    rays, ts = rays.to(DEV), ts.to(DEV)
+    target = torch.rand(160, 3, generator=torch.Generator().manual_seed(114)).to(DEV)
+    tr = Trainer(models, args, use_graph=False, steps_per_epoch=1000)  # epoch 0: warm-up
+    assert tr.direct and tr.warming_up()
+    torch.manual_seed(11)
+    parts = tr._forward_backward(rays, ts, target)
+    g_direct = tr.state.grads.clone()
+    tr.state.zero_grad()
+    torch.manual_seed(11)
+    u = torch.rand(160, 64, device=DEV)
+    with rendering.replay_rng([u, torch.zeros_like(u), torch.zeros_like(u)]):
+        res = rendering.render_rays(models, args, rays, ts)
+    loss = snerf_loss(res, target, 0.1)
+    loss.backward()
+    assert abs(parts.sum().item() - loss.item()) < 1e-4 * abs(loss.item())
+    assert maxnorm_rel(g_direct.cpu(), tr.state.grads.cpu()) < 1e-4
+    # no gradient reaches the uncertainty head while the warm-up lasts
+    sd = dict(models["coarse"].named_parameters())
+    assert float(sd["beta_from_xyz.2.weight"].grad.abs().max()) == 0.0
+
+
+def test_depth_supervision_at_config4_size():
+    """BASELINE configs[3]: 4096 colour + 4096 depth rays per step (main.py:134-141, metrics.DepthLoss).  Properties at full
+    size + 32 sampled depth rays against the oracle; the step trains."""
+    from satnerf_amd import rendering
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    torch.manual_seed(0)
+    args = O.default_args(mlp_mode="bf16x3", ds_lambda=1000.0)
+    model = load_model(args)
+    params = O.procedural_satnerf_params(256, 4, seed=121)
+    model.load_state_dict(params)
+    embw = O.procedural_uniform((30, 4), 1.0, 122)
+    emb = torch.nn.Embedding(30, 4)
+    emb.load_state_dict({"weight": embw})
+    models = {"coarse": model.to(DEV), "t": emb.to(DEV)}
+    n = 4096
+    rays, ts = O.synthetic_rays(n, seed=123)
+    d_rays, d_ts = O.synthetic_rays(n, seed=124)
+    gen = torch.Generator().manual_seed(125)
+    target = torch.rand(n, 3, generator=gen)
+    depths = torch.stack([torch.rand(n, generator=gen) * 0.5 + 0.2, torch.rand(n, generator=gen) + 0.5], 1)  # [target depth, weight]
+    # depth rendering of the depth batch vs the oracle on 32 sampled rays (same draws)
+    u, nz = torch.rand(n, 64, device=DEV), torch.zeros(n, 64, device=DEV)
+    with torch.no_grad(), rendering.replay_rng([u, nz]):
+        res = rendering.render_rays(models, args, d_rays.to(DEV), d_ts.to(DEV))
+    assert res["depth_coarse"].shape == (n,) and torch.isfinite(res["depth_coarse"]).all()
+    assert (res["depth_coarse"] >= 0).all() and (res["depth_coarse"] <= d_rays[:, 7].max().item() + 1e-4).all()  # within [near, far]
+    pick = torch.arange(0, n, 128)[:32]
+    want = O.render_rays({"coarse": params, "t": embw}, args, d_rays[pick], d_ts[pick], O.ReplayRng([u[pick].cpu(), nz[pick].cpu()]))
+    assert maxnorm_rel(res["depth_coarse"][pick.to(DEV)].cpu(), want["depth_coarse"]) < 1e-4
+    lam = 1000.0 / 3.0
+    l_ref = lam * torch.mean(depths[pick, 1] * (want["depth_coarse"] - depths[pick, 0]) ** 2)
+    l_hip = lam * torch.mean(depths[pick, 1].to(DEV) * (res["depth_coarse"][pick.to(DEV)] - depths[pick, 0].to(DEV)) ** 2)
+    assert abs(l_hip.item() - l_ref.item()) < 1e-3 * abs(l_ref.item())
+    # the full-size step: colour + depth batches, one flat gradient, loss parts = [colour, depth]
+    targs = O.default_args(mlp_mode="bf16", ds_lambda=1000.0)
+    tr = Trainer(models, targs)
+    dev = lambda *t: tuple(x.to(DEV) for x in t)  # noqa: E731
+    losses = [tr.step(*dev(rays, ts, target), depth=dev(d_rays, d_ts, depths)).item() for _ in range(8)]
+    assert tr.direct and tr._graph is not None
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
+
+
+def _rank_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share the one GPU: gloo stages through the host
+    torch.manual_seed(0)  # identical init on every rank
+    args = O.default_args(mlp_mode="bf16", bwd_fmt=16)
+    models = {"coarse": load_model(args).to("cuda:0"), "t": torch.nn.Embedding(30, 4).to("cuda:0")}
+    tr = Trainer(models, args, world_size=world)
+    rays, ts = O.synthetic_rays(128 * world, seed=31)
+    target = torch.rand(128 * world, 3, generator=torch.Generator().manual_seed(32))
+    sl = slice(128 * rank, 128 * (rank + 1))
+    torch.manual_seed(100 + rank)  # per-rank sampling jitter
+    losses = [tr.step(rays[sl].cuda(), ts[sl].cuda(), target[sl].cuda()).item() for _ in range(3)]
+    torch.save({"params": tr.state.params.cpu(), "losses": losses, "graphed": tr._graph is not None}, out_path.format(rank))
+    dist.destroy_process_group()
+
+
+def test_two_rank_trainer_step_on_one_gpu(tmp_path):
+    """Trainer.step with world_size 2 (the path bench.py runs at N > 1: captured forward/backward per rank, all-reduce of the flat
+    gradient, Adam with grad_scale 1/2): replicas bit-identical after 3 steps, and equal to ONE process that accumulates the two
+    ranks' batches into the flat gradient and steps with grad_scale 1/2."""
+    import torch.multiprocessing as mp
+
+    from satnerf_amd import ops
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    port, out = _free_port(), str(tmp_path / "rank{}.pt")
+    mp.spawn(_rank_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out.format(0)), torch.load(out.format(1))
+    assert r0["graphed"] and r1["graphed"]
+    assert torch.equal(r0["params"], r1["params"])  # replicas stay bit-identical
+    # single-process twin: same init, same per-rank draws (the captured step draws its jitter in-kernel from the seed and the
+    # step counter), rank batches accumulated into one gradient, one Adam step with grad_scale = 1/2
+    torch.manual_seed(0)
+    args = O.default_args(mlp_mode="bf16", bwd_fmt=16)
+    models = {"coarse": load_model(args).to(DEV), "t": torch.nn.Embedding(30, 4).to(DEV)}
+    rays, ts = O.synthetic_rays(256, seed=31)
+    target = torch.rand(256, 3, generator=torch.Generator().manual_seed(32))
+    tr = Trainer(models, args, world_size=2, use_graph=False)  # (constructed under the same torch seed as the ranks: same jitter key)
+    tr._kernel_rng = True  # what the captured rank steps use
+    for step in range(3):
+        for rank in range(2):
+            sl = slice(128 * rank, 128 * (rank + 1))
+            tr.adam_state[0] = float(step)  # sr_pack_all ticks it to step + 1 at the start of each pass, as in a rank's step
+            tr._forward_backward(rays[sl].to(DEV), ts[sl].to(DEV), target[sl].to(DEV))
+        tr.n_steps += 1
+        ops.adam_step(tr.state.params, tr.state.grads, tr.exp_avg, tr.exp_avg_sq, tr.n_steps, lr=tr.lr, grad_scale=0.5, zero_grad=True)
+        for m in tr.state.modules:
+            if hasattr(m, "mark_weights_changed"):
+                m.mark_weights_changed()
+    err = maxnorm_rel(tr.state.params.cpu(), r0["params"])
+    upd = maxnorm_rel(tr.state.params.cpu() - _initial_params(args), r0["params"] - _initial_params(args))
+    print(f"2-rank vs accumulated single process: params {err:.1e}, update {upd:.1e}")
+    assert err < 1e-6 and upd < 1e-3
+
+
+def _initial_params(args):
+    from satnerf_amd.models import load_model
+
+    torch.manual_seed(0)
+    m, e = load_model(args), torch.nn.Embedding(30, 4)
+    return torch.cat([torch.cat([p.detach().reshape(-1) for p in m.parameters()]), e.weight.detach().reshape(-1)])
