@@ -41,15 +41,22 @@ class RayBank:
         self._pos += self.batch_size
         return idx
 
-    def next_batch(self, out=None):
-        """(rays (B,11), ts (B,), rgbs (B,3)) gathered on the device; ``out`` = three preallocated tensors to gather into
-        (e.g. the static inputs of a captured hipGraph -- no intermediate copy)."""
+    def gather(self, idx, out=None):
+        """Rows ``idx`` -> (rays (B,11), ts (B,), rgbs (B,3)) on the device; ``out`` = three preallocated tensors of exactly that
+        size to gather into (e.g. the static inputs of a captured hipGraph -- no intermediate copy)."""
         from . import ops
 
-        idx = self.next_indices().contiguous()
+        if out is not None and out[0].shape[0] != idx.numel():
+            raise ValueError(f"gather target holds {out[0].shape[0]} rays but the batch has {idx.numel()}")
+        return ops.gather_batch(self.rays, self.rgbs, self.ts, idx.contiguous(), out)
+
+    def next_batch(self, out=None):
+        """The next batch of the shuffled epoch (``gather`` of ``next_indices``); a short last batch (drop_last=False) that does
+        not fit ``out`` is returned in fresh tensors."""
+        idx = self.next_indices()
         if out is not None and out[0].shape[0] != idx.numel():
             out = None
-        return ops.gather_batch(self.rays, self.rgbs, self.ts, idx, out)
+        return self.gather(idx, out)
 
 
 class DepthBank(RayBank):

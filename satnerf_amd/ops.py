@@ -48,6 +48,7 @@ def _chk(t, name, dtype=torch.float32, allow_none=False):
         raise ValueError(f"{name} is required")
     if not t.is_cuda:
         raise ValueError(f"{name} must live on the GPU (got {t.device}); satnerf_amd has no CPU path")
+    _same_device(t, name)
     if t.dtype != dtype:
         raise ValueError(f"{name} must be {dtype} (got {t.dtype})")
     if not t.is_contiguous():
@@ -55,10 +56,19 @@ def _chk(t, name, dtype=torch.float32, allow_none=False):
     return t
 
 
+def _same_device(t, name):
+    """Launches go to torch's CURRENT stream, i.e. to the current device: a tensor living on another GPU would be touched by the
+    wrong device's kernel."""
+    if t.device.index != torch.cuda.current_device():
+        raise ValueError(f"{name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()} "
+                         "(wrap the call in torch.cuda.device(...) or torch.cuda.set_device)")
+
+
 def _rows(t, name, min_cols):
     """A 2-D fp32 view whose rows may be strided (e.g. rays[:, 3:6]): returns (tensor, row stride in elements)."""
     if t.dim() != 2 or t.shape[1] < min_cols or t.dtype != torch.float32 or not t.is_cuda or t.stride(1) != 1:
         raise ValueError(f"{name} must be a GPU fp32 (N,>={min_cols}) tensor with unit inner stride")
+    _same_device(t, name)
     return t, t.stride(0) if t.shape[0] > 1 else t.shape[1]
 
 

@@ -124,7 +124,28 @@ def inference(model, args, rays_xyz, z_vals, rays_d=None, sun_d=None, rays_t=Non
             "sky": sky, "beta": beta}
 
 
-def render_rays(models, args, rays, ts):
+_ts_checked = {}
+
+
+def validate_ts(ts, models):
+    """``nn.Embedding`` raises IndexError on an out-of-range index (rendering.py:100); the fused kernels index the table
+    directly, so the range is checked here -- once per distinct ``ts`` tensor (it costs a device sync), never inside a hipGraph
+    capture.  Returns ``ts``."""
+    emb = models.get("t") if isinstance(models, dict) else None
+    if ts is None or emb is None or torch.cuda.is_current_stream_capturing():
+        return ts
+    vocab = (emb.weight if hasattr(emb, "weight") else emb).shape[0]
+    key = (ts.data_ptr(), ts.numel(), getattr(ts, "_version", 0), vocab)
+    if _ts_checked.get("key") != key:
+        if ts.numel():
+            lo, hi = int(ts.min()), int(ts.max())
+            if lo < 0 or hi >= vocab:
+                raise IndexError(f"ts holds image indices in [{lo}, {hi}] but the embedding has {vocab} rows (t_embbeding_vocab)")
+        _ts_checked["key"] = key
+    return ts
+
+
+def render_rays(models, args, rays, ts, _ts_validated=False):
     """Render a chunk of rays: stratified sampling -> fused Sat-NeRF MLP -> compositing [-> fine pass]."""
     n_samples, n_importance, variant = args.n_samples, args.n_importance, args.model
     if variant == "nerf":
@@ -135,6 +156,8 @@ def render_rays(models, args, rays, ts):
         raise TypeError("sat-nerf needs per-ray image indices ts (rendering.py:100 would fail in torch.cat)")
     if not rays.is_cuda:
         raise RuntimeError("rays must be on the GPU: satnerf_amd has no CPU path")
+    if not _ts_validated:
+        validate_ts(ts, models)
     if torch.is_grad_enabled() and any(p.requires_grad for p in models["coarse"].parameters()):
         from .autograd import render_rays_train
 
@@ -225,6 +248,7 @@ def render_image_outputs(models, rays, ts, args):
     if not rays.is_cuda:
         raise RuntimeError("rays must be on the GPU: satnerf_amd has no CPU path")
     n_total, s, n_imp = rays.shape[0], args.n_samples, args.n_importance
+    validate_ts(ts, models)
     typ = "fine" if n_imp > 0 else "coarse"
     emb = (models["t"].weight.data if hasattr(models["t"], "weight") else models["t"]).contiguous().float()
     image = torch.empty(n_total, 13, dtype=torch.float32, device=rays.device)
@@ -257,6 +281,8 @@ def render_image_outputs(models, rays, ts, args):
             weights = ops.composite(*comp, sky)[0]
             z_fine = ops.sample_pdf_merge(z, weights, _rng.rand(n, n_imp, dev))
             comp, beta, sky = heads(models["fine"], z_fine)
+            if args.sc_lambda > 0:
+                _rng.randn(n, s + n_imp, dev)  # ... and so does the fine pass's solar-correction pass (draw 6 of SURVEY.md 8c)
         image[i:i + n] = ops.composite_image(*comp, beta, sky)
     out = {k: image[:, a:b] for k, (a, b) in ops.IMAGE_COLUMNS.items()}
     out["depth"], out["acc"] = out["depth"][:, 0], out["acc"][:, 0]
@@ -346,6 +372,7 @@ def batched_inference(models, rays, ts, args):
     chunk_size = args.chunk
     results = defaultdict(list)
     graphed = None
+    validate_ts(ts, models)  # once for the whole image, not per chunk
     if getattr(args, "use_graph", False) and ts is not None and rays.shape[0] >= 2 * chunk_size and type(_rng) is _TorchRng:
         graphed = GraphedRenderer(models, args, chunk_size, rays.device)
     for i in range(0, rays.shape[0], chunk_size):
@@ -353,7 +380,7 @@ def batched_inference(models, rays, ts, args):
         if graphed is not None and r.shape[0] == chunk_size:
             out = {k: v.clone() for k, v in graphed(r, t).items()}
         else:
-            out = render_rays(models, args, r, t)
+            out = render_rays(models, args, r, t, _ts_validated=True)
         for k, v in out.items():
             results[k] += [v]
     for k, v in results.items():

@@ -344,11 +344,22 @@ class Trainer:
     def step_from_bank(self, bank, depth_bank=None):
         """One step on the banks' next batches; with a captured graph the batches are gathered straight into its static inputs."""
         shapes = (bank.batch_size,) + ((depth_bank.batch_size,) if depth_bank is not None else ())
+        from .rendering import validate_ts
+
+        for b in (bank, depth_bank):  # image indices are checked once per bank (nn.Embedding would raise on a bad one)
+            if b is not None and not getattr(b, "_ts_validated", False):
+                validate_ts(b.ts, self.models)
+                b._ts_validated = True
         if self.direct and self._graph is not None and tuple(t.shape[0] for t in self._static[::3]) == shapes:
-            bank.next_batch(out=self._static[:3])
-            if depth_bank is not None:
-                depth_bank.next_batch(out=self._static[3:])
-            return self.step(*self._static[:3], depth=self._static[3:] or None, _inputs_in_place=True)
+            idx = [bank.next_indices()] + ([depth_bank.next_indices()] if depth_bank is not None else [])
+            if all(i.numel() == n for i, n in zip(idx, shapes)):
+                bank.gather(idx[0], out=self._static[:3])
+                if depth_bank is not None:
+                    depth_bank.gather(idx[1], out=self._static[3:])
+                return self.step(*self._static[:3], depth=self._static[3:] or None, _inputs_in_place=True)
+            # a short last batch (drop_last=False): gather it normally; step() re-captures / runs it with its own shape
+            batches = [bank.gather(idx[0])] + ([depth_bank.gather(idx[1])] if depth_bank is not None else [])
+            return self.step(*batches[0], depth=batches[1] if depth_bank is not None else None)
         return self.step(*bank.next_batch(), depth=None if depth_bank is None else depth_bank.next_batch())
 
     def step(self, rays, ts, rgbs, depth=None, _inputs_in_place=False):
@@ -358,6 +369,12 @@ class Trainer:
 
         if depth is not None and not float(getattr(self.args, "ds_lambda", 0.0)) > 0:
             raise ValueError("a depth batch was passed but args.ds_lambda is not > 0 (main.py:51)")
+        if not _inputs_in_place:
+            from .rendering import validate_ts
+
+            validate_ts(ts, self.models)
+            if depth is not None:
+                validate_ts(depth[1], self.models)
         self._apply_schedule()
         if self.direct:
             inputs = (rays, ts, rgbs) + (tuple(depth) if depth is not None else ())

@@ -257,3 +257,47 @@ def _initial_params(args):
     torch.manual_seed(0)
     m, e = load_model(args), torch.nn.Embedding(30, 4)
     return torch.cat([torch.cat([p.detach().reshape(-1) for p in m.parameters()]), e.weight.detach().reshape(-1)])
+
+
+def test_bad_image_index_raises_like_nn_embedding():
+    """``nn.Embedding`` raises IndexError on ts >= t_embbeding_vocab (rendering.py:100); the fused kernels index the table directly,
+    so render_rays / batched_inference / the Trainer check the range up front instead of reading out of bounds."""
+    from satnerf_amd import rendering
+    from satnerf_amd.data import RayBank
+    from satnerf_amd.train import Trainer
+
+    args = O.default_args(mlp_mode="bf16")
+    models = build_models(args)
+    rays, ts = O.synthetic_rays(64, seed=5)
+    bad = ts.clone()
+    bad[7] = 30
+    with pytest.raises(IndexError):
+        with torch.no_grad():
+            rendering.render_rays(models, args, rays.to(DEV), bad.to(DEV))
+    with pytest.raises(IndexError):
+        rendering.batched_inference(models, rays.to(DEV), (-bad).to(DEV), args)
+    tr = Trainer(models, args)
+    with pytest.raises(IndexError):
+        tr.step_from_bank(RayBank(rays.to(DEV), torch.rand(64, 3, device=DEV), bad.to(DEV), 32))
+    with torch.no_grad():  # a valid batch still renders
+        assert torch.isfinite(rendering.render_rays(models, args, rays.to(DEV), ts.to(DEV))["rgb_coarse"]).all()
+
+
+def test_step_from_bank_handles_a_short_last_batch():
+    """drop_last=False: the 44-ray tail of a 300-ray bank must not replay the captured 128-ray step on stale inputs."""
+    from satnerf_amd.data import RayBank
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    torch.manual_seed(0)
+    args = O.default_args(mlp_mode="bf16")
+    models = {"coarse": load_model(args).to(DEV), "t": torch.nn.Embedding(30, 4).to(DEV)}
+    rays, ts = O.synthetic_rays(300, seed=6)
+    bank = RayBank(rays.to(DEV), torch.rand(300, 3, device=DEV), ts.to(DEV), 128, drop_last=False)
+    tr = Trainer(models, args)
+    sizes = []
+    for _ in range(7):  # 128, 128, 44 | 128, 128, 44 | 128
+        tr.step_from_bank(bank)
+        sizes.append(tr._static[0].shape[0])
+    assert sizes == [128, 128, 44, 128, 128, 44, 128]
+    assert torch.isfinite(tr.state.params).all() and tr.n_steps == 7
