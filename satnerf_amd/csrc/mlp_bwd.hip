@@ -113,8 +113,9 @@ __device__ __forceinline__ f32x16 btile(const char* slot, int p0, const uint4 (&
 // through inline asm -- the weight chunks into the shared ring, the tile's saved phases into a wave-private staging ring -- so
 // the compiler never sees a load it would have to wait for (left to hipcc, each tile's phase load became an s_waitcnt vmcnt(0)
 // that also drained the weight prefetch and the workspace stores: 62 % of the wave cycles were spent parked, PMC r02a).  The
-// waits are ours and EXACT: vmcnt retires in order on gfx9, the instruction stream of a wave is fixed, so the number of
-// vector-memory instructions issued after the one being waited for is a compile-time constant of the position in the layer.
+// waits are ours and counted: LOADS retire in order, the instruction stream of a wave is fixed, so the number of vector-memory
+// loads issued after the one being waited for is a compile-time constant of the position in the layer (stores share the counter
+// but complete out of order with respect to loads: they are left out of the count, which can only make a wait longer).
 // Per layer (NP = phase DMAs per tile, NS = workspace stores per tile, ND = weight DMAs per group of 2 chunks):
 //   tile t:   [t even: wait A(t), s_barrier, ND weight DMAs for chunks t+2, t+3]  NP phase DMAs for tile t+2  MFMAs(t)
 //             [t > 0: wait B(t-1), epilogue(t-1) = cos, pack, encode, NS stores]
@@ -283,7 +284,9 @@ __global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
   // ---- bL7 .. bL1: d pre_l -> d a_{l-1}, x cos(phase a_{l-1}) = d pre_{l-1}; scheduled by TrunkSched (above) -------------------
   constexpr long offL = BS::offset_pieces(BS::G_L);
   constexpr int NPH = FMT == SR_FMT8 ? 1 : 2;  // phase units per tile
-  using TS = TrunkSched<NPH, NPH, FMT == SR_FMT8 ? 1 : 0>;
+  // stores are NOT counted (NS = NSS = 0): loads retire in order among themselves, but a store may complete before an older load,
+  // so only "younger LOADS still outstanding" proves that an older load has landed; the price is an occasional wait for a store
+  using TS = TrunkSched<NPH, 0, 0>;  // (counting the stores as well measured the same: 138.3 vs 139.6 us)
   char* stage = smem + kNSLOT * kBSlot + wave * (4 * NPH * 1024);  // this wave's phase staging ring: 4 tiles
   const uint32_t stage_addr = __builtin_amdgcn_readfirstlane(lds_addr_of(stage));
   auto stage_phase = [&](int slot, int frag) {  // frag = logical activation fragment of the tile's first value

@@ -12,6 +12,8 @@ all-reduce is latency bound; it is issued once per step on the compute stream ri
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -192,7 +194,7 @@ class Trainer:
         n, s = rays.shape[0], args.n_samples
         mode = _mode_of(args)
         feat, tau = model.feat, model.t_embedding_dims
-        ticking = self._kernel_rng or (self.world == 1 and self._adam_in_graph)
+        ticking = self._kernel_rng or self._adam_in_graph
         model.repack(mode, backward=True, tick=self.adam_state if ticking else None)
         hi, lo, l0 = model.packed(mode)
         bstream, maps = model.packed_backward()
@@ -228,9 +230,12 @@ class Trainer:
             loss = torch.cat([loss.view(-1), self._sc_pass(rays, ts, z, noise_std).view(-1)])
         if depth is not None:
             loss = torch.cat([loss.view(-1), self._depth_pass(*depth, noise_std * 0.9).view(-1)])  # main.py:132 decays the noise first
-        if self.world == 1 and self._adam_in_graph:  # no all-reduce to wait for: the update rides in the same graph
+        if self._adam_in_graph:  # the update rides in the same graph (single GPU, or RCCL captured: SATNERF_GRAPH_ALLREDUCE=1)
+            if self.world > 1:
+                dist.all_reduce(self.state.grads, op=dist.ReduceOp.SUM)
             # lr < 0: the kernel reads the current rate from sched[1], so a scheduler can change it under graph replay
-            ops.adam_step_graph(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.adam_state, lr=-1.0, zero_grad=True)
+            ops.adam_step_graph(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.adam_state, lr=-1.0,
+                                grad_scale=1.0 / self.world, zero_grad=True)
         return loss
 
     def _sc_pass(self, rays, ts, z, noise_std):
@@ -321,7 +326,13 @@ class Trainer:
 
     def _capture(self, inputs):
         self._static = tuple(t.clone() for t in inputs)
-        self._adam_in_graph = self.world == 1
+        # data parallel: by default the gradient all-reduce and Adam are issued eagerly after the replay (works with every backend;
+        # ~2 launches + the collective's own latency per step).  SATNERF_GRAPH_ALLREDUCE=1 captures the RCCL all-reduce and the
+        # update into the step's graph (NCCL/RCCL collectives are capturable; gloo is not) -- opt-in because it cannot be exercised
+        # on the single-GPU development box.
+        capture_collective = (self.world > 1 and os.environ.get("SATNERF_GRAPH_ALLREDUCE", "0") == "1" and dist.is_initialized()
+                              and dist.get_backend() == "nccl")
+        self._adam_in_graph = self.world == 1 or capture_collective
         self._kernel_rng = float(self.args.noise_std) == 0.0  # (a noisy step still draws randn from torch's generator)
         snapshot = (self.state.params.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.adam_state.clone())
         run = lambda: self._forward_backward(*self._static[:3], depth=self._static[3:] or None)  # noqa: E731
@@ -389,10 +400,10 @@ class Trainer:
             else:
                 inputs = tuple(t.contiguous() for t in inputs)
                 loss = self._forward_backward(*inputs[:3], depth=inputs[3:] or None)
-            if self.world > 1:
+            in_graph = self._adam_in_graph and self._graph is not None and self.use_graph and float(self.args.noise_std) == 0.0
+            if self.world > 1 and not self._adam_in_graph:
                 dist.all_reduce(self.state.grads, op=dist.ReduceOp.SUM)
             self.n_steps += 1
-            in_graph = self._adam_in_graph and self._graph is not None and self.use_graph and float(self.args.noise_std) == 0.0
             if not in_graph and not self._adam_in_graph:  # (an eager direct step after a capture already stepped Adam)
                 ops.adam_step(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.n_steps, lr=self.lr,
                               grad_scale=1.0 / self.world, zero_grad=True)

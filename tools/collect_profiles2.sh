@@ -4,7 +4,7 @@
 set -u
 TAG=${1:-r02}; root=$(pwd); out=$root/gpurun_out/profiles_${TAG}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python $root/bench.py --steps 30 --warmup 10 --no-cpu-baseline"
+B="python $root/bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -d $out/train_stats -o t --output-format csv -- $B > $out/train_stats.log 2>&1
 rocprofv3 --kernel-trace --stats -d $out/fwd_stats -o t --output-format csv -- $B --phase forward > $out/fwd_stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU"; do
