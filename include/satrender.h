@@ -225,6 +225,16 @@ int sr_composite_image(const float* z_vals, const float* sigma, const float* noi
 int sr_latlonalt_from_depth(const float* rays, int ray_stride, const float* depth, int64_t n_rays, const double* center,
                             double range, double* lat, double* lon, double* alt, void* stream);
 
+/* ---- RPC ray generation: datasets/satellite.py:18-65 get_rays + :218-227 normalize_rays + :229-244 sun -------
+ * `rpc` = 90 HOST doubles of the image's RPC00B camera in rpcm's dict order: row_num[20], row_den[20], col_num[20], col_den[20],
+ * row_offset, col_offset, lat_offset, lon_offset, alt_offset, row_scale, col_scale, lat_scale, lon_scale, alt_scale (apply
+ * sat_utils.rescale_rpc for a down-scaled image first).  Pixel i = (col i % width, row i / width) is localised at max_alt (ray
+ * origin) and min_alt in fp64 (Newton on the projection to rpcm's 1e-18 tolerance), converted to ECEF, and written as
+ * rays8 (H*W, 8) fp32 = the reference's <cache_dir>/<img_id>.data content [o(3) d(3) near=0 far] and / or rays11 (H*W, 11) = the
+ * same normalised by `center` (3 HOST doubles) / `range` in fp32 with the image's sun direction appended; either may be NULL. */
+int sr_rpc_rays(const double* rpc, int width, int height, double min_alt, double max_alt, const double* center, double range,
+                double sun_elevation_deg, double sun_azimuth_deg, float* rays11, float* rays8, void* stream);
+
 /* ---- training-step kernels --------------------------------------------------------------
  * sr_satnerf_loss: metrics.SatNerfLoss for the coarse model (metrics.py:21-25,56-73): value = sum of
  * loss_parts[0 .. ceil(N/4)), and grad_scale * dLoss/d{rgb (N,3), weights (N,S), beta (N,S)} in g_*.

@@ -75,6 +75,7 @@ SIGNATURES = {
                               _vp, _vp, _vp]),
     "sr_sample_pdf_merge": (_i, [_vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp]),
     "sr_sample_pdf": (_i, [_vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp]),
+    "sr_rpc_rays": (_i, [_vp, _i, _i, _d, _d, _vp, _d, _d, _d, _vp, _vp, _vp]),
 }
 
 _lib = None

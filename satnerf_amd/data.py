@@ -99,6 +99,34 @@ def rays_from_cache(cached_rays, center, scene_range, sun_elevation_deg, sun_azi
     return out if device is None else out.to(device)
 
 
+def rescale_rpc(rpc, alpha):
+    """``sat_utils.rescale_rpc`` (sat_utils.py:44-57) on an "rpcm"-format dict: the camera of the image resized by ``alpha``."""
+    out = dict(rpc)
+    for k in ("row_scale", "col_scale", "row_offset", "col_offset"):
+        out[k] = float(rpc[k]) * float(alpha)
+    return out
+
+
+def rays_from_rpc(rpc, height, width, min_alt, max_alt, center, scene_range, sun_elevation_deg, sun_azimuth_deg, device="cuda",
+                  img_downscale=1.0, cache_path=None):
+    """The (H*W, 11) ray block of one image straight from its RPC camera, on the GPU (``SatelliteDataset.load_data``,
+    datasets/satellite.py:185-211, for an image without a ``.data`` cache): ``get_rays`` (:18-65) on the pixel grid of the
+    down-scaled image, ``normalize_rays``, sun direction.  ``rpc`` = the JSON's "rpc" dict (rpcm format); ``height`` / ``width``
+    = the FULL-resolution size stored in the JSON (the reference divides them by ``img_downscale`` itself, :191-192).
+    ``cache_path``: also write the reference-compatible ``<cache_dir>/<img_id>.data`` file (torch.save of the (H*W, 8) rays)."""
+    import os
+
+    from . import ops
+
+    h, w = int(height // img_downscale), int(width // img_downscale)
+    rays, cache = ops.rpc_rays(rescale_rpc(rpc, 1.0 / img_downscale), w, h, min_alt, max_alt, center, scene_range, sun_elevation_deg,
+                               sun_azimuth_deg, device, want_cache=cache_path is not None)
+    if cache_path is not None:
+        os.makedirs(os.path.dirname(os.path.abspath(cache_path)), exist_ok=True)
+        torch.save(cache.cpu(), cache_path)
+    return rays
+
+
 def synthetic_rays(n_rays, seed=20240628, n_images=19, far_lo=0.5, far_hi=1.0):
     """Synthetic sat-nerf ray batch for benchmarks (no dataset ships offline): origins U[-1,1]^3, unit directions, near = 0
     (datasets/satellite.py:60), far U[far_lo, far_hi] (scene-normalised, :225-226), one sun direction per synthetic image id

@@ -274,6 +274,34 @@ def latlonalt_from_depth(rays, depth, center, scene_range):
     return out[0], out[1], out[2]
 
 
+RPC_KEYS = ("row_num", "row_den", "col_num", "col_den")
+RPC_SCALARS = ("row_offset", "col_offset", "lat_offset", "lon_offset", "alt_offset", "row_scale", "col_scale", "lat_scale", "lon_scale", "alt_scale")
+
+
+def rpc_rays(rpc, width, height, min_alt, max_alt, center, scene_range, sun_elevation_deg, sun_azimuth_deg, device, want_cache=False):
+    """RPC ray generation of one image on the GPU (sr_rpc_rays): ``rpc`` = dict in rpcm's "rpcm" format (20-term lists row_num,
+    row_den, col_num, col_den + the ten offsets / scales).  Returns (rays (H*W, 11) fp32, cache (H*W, 8) fp32 or None)."""
+    import ctypes
+
+    vals = []
+    for k in RPC_KEYS:
+        c = [float(v) for v in rpc[k]]
+        if len(c) != 20:
+            raise ValueError(f"rpc[{k!r}] must hold the 20 RPC00B coefficients, got {len(c)}")
+        vals += c
+    vals += [float(rpc[k]) for k in RPC_SCALARS]
+    buf = (ctypes.c_double * 90)(*vals)
+    ctr = (ctypes.c_double * 3)(*[float(v) for v in center])
+    n = int(width) * int(height)
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        rays = torch.empty(n, 11, dtype=torch.float32, device=dev)
+        cache = torch.empty(n, 8, dtype=torch.float32, device=dev) if want_cache else None
+        _lib.call("sr_rpc_rays", ctypes.addressof(buf), int(width), int(height), float(min_alt), float(max_alt), ctypes.addressof(ctr),
+                  float(scene_range), float(sun_elevation_deg), float(sun_azimuth_deg), _p(rays), _p(cache), _stream())
+    return rays, cache
+
+
 def sample_pdf(bins, weights, u, eps=1e-5):
     n, nb = bins.shape
     _chk(bins, "bins"), _chk(weights, "weights"), _chk(u, "u")
