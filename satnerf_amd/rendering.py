@@ -299,6 +299,39 @@ def latlonalt_from_depth(rays, depth, center, scene_range):
     return ops.latlonalt_from_depth(rays.float(), depth.to(rays.device), center, scene_range)
 
 
+def batched_inference_sharded(models, rays, ts, args, render_fn=None):
+    """``batched_inference`` of one image over the ranks of an initialised ``torch.distributed`` group ("split an
+    image's rays in contiguous row blocks, concatenate"): rank r renders rows ``shard_rays(N, r, W)`` with the ordinary chunk loop
+    and every rank receives the full per-key tensors (one all-gather per key; ragged shares are padded to the largest).  Models are
+    replicated, rays are independent, so the result equals the single-rank call given the same per-ray draws.  ``render_fn``
+    (default ``batched_inference``) exists so the gather logic can be exercised without a GPU."""
+    import torch.distributed as dist
+
+    from .train import shard_rays
+
+    world, rank = (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
+    render_fn = render_fn or batched_inference
+    n = rays.shape[0]
+    lo, hi = shard_rays(n, rank, world)
+    local = render_fn(models, rays[lo:hi], None if ts is None else ts[lo:hi], args)
+    if world == 1:
+        return local
+    spans = [shard_rays(n, r, world) for r in range(world)]
+    most = max(b - a for a, b in spans)
+    out = {}
+    for k in sorted(local):  # same key order on every rank
+        v = local[k]
+        if v is None:
+            out[k] = None
+            continue
+        pad = torch.zeros((most,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+        pad[:v.shape[0]] = v
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+        out[k] = torch.cat([p[:b - a] for p, (a, b) in zip(parts, spans)], 0)
+    return out
+
+
 class GraphedRenderer:
     """``render_rays`` (no grad) for a FIXED chunk shape replayed from one hipGraph.
 

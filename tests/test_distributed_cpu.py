@@ -67,3 +67,31 @@ def test_shard_rays_covers_everything_once():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _shard_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from satnerf_amd.rendering import batched_inference_sharded
+
+    n = 1003  # ragged: 502 + 501
+    rays = torch.arange(n * 11, dtype=torch.float32).view(n, 11)
+    ts = torch.arange(n)
+
+    def fake_render(models, r, t, args):  # stands in for the GPU renderer: per-ray outputs that identify the ray
+        return {"rgb_coarse": r[:, :3] * 2 + t[:, None].float(), "depth_coarse": r[:, 7] + 1, "weights_coarse": r[:, :4].repeat(1, 16), "sky": None}
+
+    res = batched_inference_sharded({}, rays, ts, None, render_fn=fake_render)
+    full = fake_render({}, rays, ts, None)
+    ok = all((res[k] is None and full[k] is None) or torch.equal(res[k], full[k]) for k in full)
+    out[rank] = bool(ok and res["weights_coarse"].shape == (n, 64))
+    dist.destroy_process_group()
+
+
+def test_sharded_batched_inference_gathers_contiguous_row_blocks():
+    """Evaluation sharding: every rank ends up with the whole image, in ray order, ragged shares included."""
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_shard_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}
