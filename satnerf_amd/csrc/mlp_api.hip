@@ -8,13 +8,19 @@ int launch_fwd_p1a1(const FwdParams&, int, hipStream_t);
 int launch_fwd_p1a2(const FwdParams&, int, hipStream_t);
 int launch_fwd_p3a1(const FwdParams&, int, hipStream_t);
 int launch_fwd_p3a2(const FwdParams&, int, hipStream_t);
+int launch_fwd512_p1a1(const FwdParams&, int, hipStream_t);  // the 512-wide build (mlp_fwd512_*.hip): inference, bf16
+int launch_fwd512_p1a2(const FwdParams&, int, hipStream_t);
+long fwd512_stream_pieces_a1();
+long fwd512_stream_pieces_a2();
 }  // namespace sr
 using namespace sr;
 extern "C" int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, int mode, const uint16_t* stream_hi,
                                   const uint16_t* stream_lo, const float* l0, float* albedo, float* sigma, float* sun_v,
                                   float* beta, uint16_t* acts, int act_fmt, void* stream) {
   SR_REQUIRE(in != nullptr, "sr_satnerf_mlp_fwd: null inputs");
-  SR_REQUIRE(feat == kFeat, "sr_satnerf_mlp_fwd: feat=%d unsupported (this build handles %d)", feat, kFeat);
+  SR_REQUIRE(feat == kFeat || feat == 512, "sr_satnerf_mlp_fwd: feat=%d unsupported (this build handles %d, and 512 for inference)", feat, kFeat);
+  SR_REQUIRE(feat == kFeat || (mode == SR_MODE_BF16 && acts == nullptr),
+             "sr_satnerf_mlp_fwd: feat=512 runs the fused kernel in SR_MODE_BF16 without saving activations (parity mode / training: layer by layer)");
   SR_REQUIRE(tau >= 1 && tau <= 24, "sr_satnerf_mlp_fwd: tau=%d unsupported (1..24)", tau);
   SR_REQUIRE(mode == SR_MODE_BF16 || mode == SR_MODE_BF16X3, "sr_satnerf_mlp_fwd: bad mode %d", mode);
   SR_REQUIRE(stream_hi && l0 && in->org && in->sun && in->temb, "sr_satnerf_mlp_fwd: null pointer argument");
@@ -33,12 +39,14 @@ extern "C" int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, in
   hipStream_t st = (hipStream_t)stream;
   const int save = acts != nullptr ? act_fmt : 0;
   const int auxs = aux_steps(tau);
+  if (feat == 512) return auxs == 1 ? launch_fwd512_p1a1(p, save, st) : launch_fwd512_p1a2(p, save, st);
   if (mode == SR_MODE_BF16) return auxs == 1 ? launch_fwd_p1a1(p, save, st) : launch_fwd_p1a2(p, save, st);
   return auxs == 1 ? launch_fwd_p3a1(p, save, st) : launch_fwd_p3a2(p, save, st);
 }
 
 extern "C" int64_t sr_fwd_stream_elems(int feat, int tau) {
-  if (feat != kFeat || tau < 1 || tau > 24) return -1;
+  if ((feat != kFeat && feat != 512) || tau < 1 || tau > 24) return -1;
+  if (feat == 512) return (aux_steps(tau) == 1 ? fwd512_stream_pieces_a1() : fwd512_stream_pieces_a2()) * 512;
   return (aux_steps(tau) == 1 ? FwdStream<1>::total_pieces() : FwdStream<2>::total_pieces()) * 512;
 }
 

@@ -8,6 +8,7 @@
 #include "mlp_layout.h"
 
 namespace sr {
+inline namespace SR_FEAT_NS {
 
 constexpr int kD = 3;      // prefetch distance, chunks
 constexpr int kNSLOT = 4;  // LDS ring slots (= kD + 1)
@@ -29,7 +30,9 @@ constexpr int kBatchHead = SR_HEAD_BATCH;   // ... and in the head stages (regis
 
 template <int NPASS>
 struct Mode {
-  static constexpr int NW = NPASS == 1 ? 8 : 4;   // waves per workgroup
+  // waves per workgroup: 8 (two per SIMD, <= 256 VGPRs) when a wave's activations fit 256 registers, else 4 (<= 512 VGPRs): the
+  // parity mode (hi + lo planes) and the 512-wide forward (32 + 32 B fragments = 256 registers before anything else)
+  static constexpr int NW = (NPASS == 1 && kFeat <= 256) ? 8 : 4;
   static constexpr int NPA = NPASS == 1 ? 1 : 2;  // A planes (hi[, lo])
   static constexpr int PIECE_BYTES = 1024 * NPA;
 };
@@ -100,4 +103,5 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 
+}  // inline namespace SR_FEAT_NS
 }  // namespace sr

@@ -22,9 +22,20 @@
 // connection's xyz columns, the sun-direction columns and the embedding columns enter the MFMA.
 #pragma once
 
-namespace sr {
+// The trunk width is a compile-time constant of a translation unit: SR_FEAT = 256 (BASELINE's width; every kernel) or 512
+// (opt.py:50's default, what run_all.sh trains sat-nerf with: the forward kernel only, mlp_fwd512_*.hip).  Everything that depends
+// on it lives in an inline namespace named after the width, so the two builds of the same templates never share a symbol.
+#ifndef SR_FEAT
+#define SR_FEAT 256
+#endif
+#define SR_CAT_(a, b) a##b
+#define SR_CAT(a, b) SR_CAT_(a, b)
+#define SR_FEAT_NS SR_CAT(f, SR_FEAT)
 
-constexpr int kFeat = 256;        // trunk width handled by this build (BASELINE fixes 256)
+namespace sr {
+inline namespace SR_FEAT_NS {
+
+constexpr int kFeat = SR_FEAT;    // trunk width of this translation unit
 constexpr int kHalf = kFeat / 2;  // head width
 constexpr int kKS = kFeat / 16;   // k-steps of a feat-wide input (16)
 constexpr int kHS = kHalf / 16;   // k-steps of a head-wide input (8)
@@ -39,7 +50,7 @@ constexpr int aux_steps(int tau) { return (8 + ((tau + 7) / 8) * 8 + 15) / 16; }
 //   G1 (feats, sigma) | G2r (rgb hidden) | Hr | G2s (sun hidden 1) | S2 | S3 | Hs | G2b (beta hidden) | Hb (+aux: biases)
 template <int AUXS>
 struct FwdStream {
-  static constexpr int SLOTP = 16 + AUXS;  // pieces per ring slot
+  static constexpr int SLOTP = kKS + AUXS;  // pieces per ring slot
   static constexpr int NSTAGE = 10;
   static constexpr int N_TRUNK = kTrunkLayers * kMT;
   static constexpr int cnt(int st) {
@@ -47,7 +58,7 @@ struct FwdStream {
     return c[st];
   }
   static constexpr int size(int st) {
-    constexpr int z[NSTAGE] = {16 + AUXS, 16 + AUXS, 16 + AUXS, kHS, 16 + AUXS, kHS + AUXS, kHS + AUXS, kHS, 16 + AUXS, kHS + AUXS};
+    constexpr int z[NSTAGE] = {kKS + AUXS, kKS + AUXS, kKS + AUXS, kHS, kKS + AUXS, kHS + AUXS, kHS + AUXS, kHS, kKS + AUXS, kHS + AUXS};
     return z[st];
   }
   static constexpr int first(int st) {  // global index of the stage's first chunk
@@ -173,4 +184,5 @@ __device__ __forceinline__ float wg_sum_slices(const float* __restrict__ partial
 }
 #endif
 
+}  // inline namespace SR_FEAT_NS
 }  // namespace sr

@@ -1,4 +1,5 @@
-// Kernel parameter blocks shared by the API translation unit and the kernel instantiations.
+// Kernel parameter blocks shared by the API translation unit and the kernel instantiations (independent of the trunk width:
+// they stay outside the per-width inline namespace of mlp_layout.h).
 #pragma once
 #include "common.h"
 

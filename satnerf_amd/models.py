@@ -115,6 +115,8 @@ class SatNeRF(_FlatParamModule):
         # the fused register-resident kernel is built for the BASELINE shape; everything else (opt.py's default fc_units=512
         # included) runs layer by layer through satnerf_amd.generic
         self.fused = feat == 256 and layers == 8 and list(skips) == [4]
+        # ... and a 512-wide build of the forward kernel (opt.py:50's default width): inference in the throughput arithmetic only
+        self._fused_wide = feat == 512 and layers == 8 and list(skips) == [4]
         self.t_embedding_dims = t_embedding_dims
         self.mapping = [nn.Identity(), nn.Identity()]  # plain list, not registered (models/satnerf.py:101)
         self.input_sizes = [3, 0]
@@ -137,6 +139,10 @@ class SatNeRF(_FlatParamModule):
         _sine_init(self.sun_v_net, first_only=True)
         self.beta_from_xyz = nn.Sequential(nn.Linear(t_embedding_dims + feat, half), nl, nn.Linear(half, 1), nn.Softplus())
         self._flatten()
+
+    def fused_forward(self, mode):
+        """True when a no-grad forward in numeric mode ``mode`` runs in the fused kernel (else: layer by layer, satnerf_amd.generic)."""
+        return self.fused or (self._fused_wide and mode == "bf16")
 
     # ---- weight stream ------------------------------------------------------------------------------------
     def packed(self, mode):
@@ -222,7 +228,7 @@ class SatNeRF(_FlatParamModule):
         sun = input_sun_dir.contiguous().float()
         t = input_t.contiguous().float()
         b = xyz.shape[0]
-        if self.fused:
+        if self.fused_forward(mode):
             hi, lo, l0 = self.packed(mode)
             albedo, sigma, sun_v, beta = ops.satnerf_mlp(xyz, None, sun, None, t, None, b, 1, self.feat, self.t_embedding_dims, mode, hi, lo, l0)
         else:

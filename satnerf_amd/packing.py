@@ -124,8 +124,8 @@ def forward_maps(feat=256, tau=4):
 
     Returns dict(idx int32 [n], scale fp32 [n], l0_idx int32 [feat*4], l0_scale fp32 [feat*4], n_params, auxs).
     """
-    if feat != 256:
-        raise ValueError(f"feat={feat} unsupported by this build (256)")
+    if feat not in (256, 512):
+        raise ValueError(f"feat={feat} unsupported by this build (256; 512 for the inference kernel)")
     if not 1 <= tau <= 24:
         raise ValueError(f"t_embedding tau={tau} unsupported (1..24)")
     half, auxs = feat // 2, aux_steps(tau)

@@ -84,11 +84,11 @@ def _mode_of(args):
 def _inference(model, args, rays, z, ts, emb_weight, dir_cols, noise, sky=None):
     """models/satnerf.inference (models/satnerf.py:4-79) for the points rays[:, 0:3] + rays[:, dir_cols] * z."""
     n, s = z.shape
-    if not model.fused:  # widths / depths outside the fused kernel: layer by layer (satnerf_amd.generic)
+    mode = _mode_of(args)
+    if not model.fused_forward(mode):  # widths / depths / modes outside the fused kernel: layer by layer (satnerf_amd.generic)
         from .generic import inference_pass
 
         return inference_pass(model, args, rays, z, ts, emb_weight, dir_cols, noise)
-    mode = _mode_of(args)
     hi, lo, l0 = model.packed(mode)
     albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, dir_cols[0]:dir_cols[1]], rays[:, 8:11], z, emb_weight, ts, n * s, s,
                                                  model.feat, model.t_embedding_dims, mode, hi, lo, l0)
@@ -170,7 +170,7 @@ def render_rays(models, args, rays, ts, _ts_validated=False):
 
     coarse = models["coarse"]
     sky_of = {}
-    if getattr(coarse, "fused", False):  # stratified depths (rendering.py:62-78, perturb = 1) + the coarse sky head in one launch
+    if hasattr(coarse, "fused_forward") and coarse.fused_forward(_mode_of(args)):  # stratified depths (rendering.py:62-78, perturb = 1) + the coarse sky head in one launch
         sk = coarse.sky_color
         z, sky_of["coarse"] = ops.ray_setup(rays, _rng.rand(n, n_samples, dev), n_samples, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data,
                                             sk[2].bias.data)
@@ -263,7 +263,7 @@ def render_image_outputs(models, rays, ts, args):
             sk = model.sky_color
             sky = ops.sky(r[:, 8:11], sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data)
             k = z_cur.shape[1]
-            if model.fused:
+            if model.fused_forward(mode):
                 hi, lo, l0 = model.packed(mode)
                 albedo, sigma, sun_v, beta = ops.satnerf_mlp(r[:, 0:3], r[:, 3:6], r[:, 8:11], z_cur, emb, t, n * k, k, model.feat,
                                                              model.t_embedding_dims, mode, hi, lo, l0)
@@ -355,7 +355,7 @@ class GraphedRenderer:
         mode = _mode_of(self.args)
         for typ in ("coarse", "fine"):
             m = self.models.get(typ)
-            if m is None or not getattr(m, "fused", False):
+            if m is None or not (hasattr(m, "fused_forward") and m.fused_forward(mode)):
                 continue
             stamp = (m.weights_version(), m.flat_params().data_ptr(), mode)
             if self._packed_for.get(typ) != stamp:

@@ -42,7 +42,10 @@ def test_version_and_stream_geometry(handle):
     for tau in (4, 16):
         m = packing.forward_maps(256, tau)
         assert handle.sr_fwd_stream_elems(256, tau) == m["idx"].size == m["scale"].size
-    assert handle.sr_fwd_stream_elems(512, 4) == -1
+    for tau in (4, 16):  # the 512-wide build of the forward kernel (inference): same packer, its own stream geometry
+        m = packing.forward_maps(512, tau)
+        assert handle.sr_fwd_stream_elems(512, tau) == m["idx"].size
+    assert handle.sr_fwd_stream_elems(384, 4) == -1 and handle.sr_bwd_stream_elems(512, 4) == -1
     assert handle.sr_fwd_stream_elems(256, 25) == -1
     assert handle.sr_act_elems_per_tile(256, 16) == 186 * 512 and handle.sr_dpre_elems_per_tile(256, 16) == 186 * 512
     assert handle.sr_act_elems_per_tile(256, 8) == 95 * 512 and handle.sr_dpre_elems_per_tile(256, 8) == 101 * 512  # the 8-bit workspaces

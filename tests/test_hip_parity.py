@@ -551,3 +551,37 @@ def test_edge_cases_empty_and_ragged_inputs_of_the_newer_entry_points():
         rendering.render_image_outputs(models, rays.cpu(), ts.cpu(), args)                                         # no CPU path
     with pytest.raises(NotImplementedError):
         load_model(O.default_args(model="s-nerf"))
+
+
+def test_width_512_fused_forward_kernel():
+    """fc_units=512 (opt.py:50; what run_all.sh trains sat-nerf with), no-grad forward in the throughput arithmetic: the 512-wide
+    build of the fused kernel (csrc/mlp_fwd512_*.hip) against the reference's own render_rays output (bounded like the 256 kernel
+    in bf16) and against the layer-by-layer path, which reproduces that golden to 1e-4."""
+    _, rendering, _ = _lazy()
+    g = load_golden("satnerf_feat512")
+    args = golden_cfg(g)
+    args.mlp_mode = "bf16"
+    models = build_models(args)
+    m = models["coarse"]
+    assert not m.fused and m.fused_forward("bf16") and not m.fused_forward("bf16x3")
+    draws = [d.to(DEV) for d in golden_draws(g)]
+    with torch.no_grad(), rendering.replay_rng(draws):
+        res = rendering.render_rays(models, args, g["rays"].to(DEV), g["ts"].to(DEV))
+    expected = {k[4:]: v for k, v in g.items() if k.startswith("out_")}
+    assert set(res) == set(expected)
+    errs = {k: maxnorm_rel(res[k].cpu(), v) for k, v in expected.items()}
+    print("feat 512 fused bf16", {k: f"{e:.1e}" for k, e in errs.items()})
+    assert max(errs[k] for k in ("rgb_coarse", "depth_coarse", "weights_coarse")) < 2e-2, errs
+    assert max(errs.values()) < 5e-2, errs
+    # per-point outputs through the reference-signature forward: fused bf16 vs the layer path (3-pass) on random points
+    x, sun, t = torch.rand(777, 3, device=DEV) * 2 - 1, torch.nn.functional.normalize(torch.randn(777, 3, device=DEV), dim=1), torch.rand(777, 16, device=DEV)
+    with torch.no_grad():
+        fast = m(x, input_sun_dir=sun, input_t=t, mlp_mode="bf16")
+        slow = m(x, input_sun_dir=sun, input_t=t, mlp_mode="bf16x3")
+    assert fast.shape == slow.shape == (777, 9)
+    assert maxnorm_rel(fast.cpu(), slow.cpu()) < 2e-2
+    # training at this width still goes layer by layer, and the C ABI says so when asked to save activations
+    from satnerf_amd import ops
+    hi, lo, l0 = m.packed("bf16")
+    with pytest.raises(Exception):
+        ops.satnerf_mlp(x, None, sun, None, t, None, 777, 1, 512, 16, "bf16", hi, lo, l0, acts=ops.acts_workspace(777, 256, x.device, 8), fmt=8)
