@@ -150,11 +150,54 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// ---- phases of the stages before the trunk ---------------------------------------------------------------------------------
+// The 28 output tiles before the trunk that multiply by cos(phase) -- bH (12: rgb hidden, sun hidden 3, beta hidden), bS3 (4), bS2
+// (4), bG1 (8) -- take their phases the same way: LDS-DMA into the wave's 4-slot staging ring TWO phase tiles ahead (tile k + 2
+// is requested right after tile k is used; tiles 0, 1 by the prologue), counted wait before the use.  The instruction stream is
+// static, so the loads issued between a request and its use are known: the phase DMAs of tile k + 1 and the weight DMAs of every
+// chunk entered in between (at least min_loads per wave).  PreSched replays that stream at compile time.
+struct PreSched {
+  static constexpr int kTiles = 3 * kMTH + 2 * 2 + 2 * 2 + kMT;  // 28
+  // phase tile k -> logical activation fragment of its first value
+  static constexpr int frag(int k) {
+    if (k < 3 * kMTH) {
+      const int part = k / kMTH, t = k % kMTH;
+      return (part == 0 ? kActRgbh : part == 1 ? kActS3 : kActE1) + 2 * t;
+    }
+    k -= 3 * kMTH;
+    if (k < 4) return kActS2 + 2 * k;  // bS3 multiplies by cos(phase s2)
+    k -= 4;
+    if (k < 4) return kActS1 + 2 * k;  // bS2: cos(phase s1)
+    return kActA0 + 7 * kKS + 2 * (k - 4);  // bG1: cos(phase a7)
+  }
+  static constexpr int chunk_of(int k) {  // the chunk in which phase tile k is used
+    if (k < 3 * kMTH) return BS::G_H;
+    k -= 3 * kMTH;
+    if (k < 4) return BS::G_S3 + k / 2;
+    k -= 4;
+    if (k < 4) return BS::G_S2 + k / 2;
+    return BS::G_G1 + (k - 4);
+  }
+  // loads (lower bound per wave) issued after the request of phase tile k and before its use; nph = phase DMAs per tile.
+  // Request points: tiles 0, 1 in the prologue (after the DMAs of chunks 0..2, before chunk 0 is entered); tile k >= 2 right after
+  // the use of tile k - 2, i.e. inside chunk_of(k - 2).  Entering chunk g requests chunk g + kD.
+  static constexpr int wait(int k, int nph) {
+    int n = 0;
+    const int req_chunk = k >= 2 ? chunk_of(k - 2) : -1;
+    for (int g = req_chunk + 1; g <= chunk_of(k); ++g) n += min_loads<1>(BS::np(g + kD));  // chunks entered after the request
+    if (k + 1 < kTiles) n += nph;  // tile k + 1 is requested in between (after the use of tile k - 1; tile 1 right after tile 0)
+    return n;
+  }
+};
+
 // generic transposed stage: NCHUNK chunks of TPC tiles, each KIN pieces; tile t -> out[2t], out[2t+1], stored to the dpre
 // workspace from logical fragment DF0; AF0 = logical activation fragment of the stage's phases (COS stages)
-template <int FMT, int KIN, int TPC, int NCHUNK, int G0, bool COS, int NOUT, int AF0, int DF0>
+// PK0 = phase-tile index (PreSched) of the stage's first tile; `stage` = the wave's phase staging ring, request(slot, frag) = LDS-DMA
+// of a phase tile into it
+template <int FMT, int KIN, int TPC, int NCHUNK, int G0, bool COS, int NOUT, int PK0, int DF0, class Req>
 __device__ __forceinline__ void bstage(const uint4 (&in)[KIN], uint4 (&out)[NOUT], char* ring, const char* stream, int wave, int lane,
-                                       const uint4* acts_tile, int auxs, uint4* dpre_tile) {
+                                       const char* stage, Req&& request, uint4* dpre_tile) {
+  constexpr int NPH = FMT == SR_FMT8 ? 1 : 2;
   uint32_t eb[2] = {0u, 0u};
   static_for<NCHUNK>([&](auto cc) {
     constexpr int c = decltype(cc)::value, g = G0 + c;
@@ -164,9 +207,14 @@ __device__ __forceinline__ void bstage(const uint4 (&in)[KIN], uint4 (&out)[NOUT
     static_for<TPC>([&](auto tc) {
       constexpr int tt = decltype(tc)::value, t = c * TPC + tt, o = 2 * t;
       Phase<FMT> ph = {};
-      if constexpr (COS) ph.load(acts_tile, auxs, AF0 + 2 * t);
       const f32x16 acc = btile<KIN>(slot, tt * KIN, in, lane);
+      if constexpr (COS) {
+        constexpr int k = PK0 + t;
+        wait_vmcnt<PreSched::wait(k, NPH)>();
+        ph.from_lds(stage + (k & 3) * NPH * 1024, lane);
+      }
       eb[t >> 2] |= bpack<COS, FMT>(acc, ph, out[o], out[o + 1], dpre_tile, DF0 + 2 * t) << (8 * (t & 3));
+      if constexpr (COS && PK0 + t + 2 < PreSched::kTiles) request((PK0 + t + 2) & 3, PreSched::frag(PK0 + t + 2));
     });
   });
   store_scales<FMT, TPC * NCHUNK>(dpre_tile, dp8_group(DF0), eb);
@@ -228,6 +276,17 @@ __global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
     dpre[(FMT == SR_FMT8 ? kD8Sigma : kDpSigma) * 64] = dsig;
   }
 
+  // this wave's phase staging ring (4 tiles) behind the weight ring; the first two phase tiles are requested now
+  constexpr int NPH = FMT == SR_FMT8 ? 1 : 2;  // phase units per tile
+  char* stage = smem + kNSLOT * kBSlot + wave * (4 * NPH * 1024);
+  const uint32_t stage_addr = __builtin_amdgcn_readfirstlane(lds_addr_of(stage));
+  auto stage_phase = [&](int slot, int frag) {  // frag = logical activation fragment of the tile's first value
+    const char* src = reinterpret_cast<const char*>(acts + (A + (FMT == SR_FMT8 ? frag >> 1 : frag)) * 64);
+#pragma unroll
+    for (int k = 0; k < NPH; ++k) glds16(src + k * 1024, stage_addr + (slot * NPH + k) * 1024);
+  };
+  stage_phase(0, PreSched::frag(0)), stage_phase(1, PreSched::frag(1));
+
   // ---- bH: d_head -> d rgb-hidden | d sun-hidden-3 | d beta-hidden (12 tiles x 1 piece, one chunk) --------------------
   uint4 d_rgbh[kHS], d_s3[kHS], d_e1[kHS];
   {
@@ -236,13 +295,14 @@ __global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
     uint32_t eb[3][2] = {};
     static_for<3 * kMTH>([&](auto tc) {
       constexpr int T = decltype(tc)::value, part = T / kMTH, t = T % kMTH;
-      constexpr int act0 = part == 0 ? kActRgbh : (part == 1 ? kActS3 : kActE1);
       constexpr int dp0 = part == 0 ? kDpRgbh : (part == 1 ? kDpS3 : kDpE1);
-      Phase<FMT> ph;
-      ph.load(acts, A, act0 + 2 * t);
       const f32x16 acc = btile<1>(slot, T, dhead, lane);
+      wait_vmcnt<PreSched::wait(T, NPH)>();
+      Phase<FMT> ph;
+      ph.from_lds(stage + (T & 3) * NPH * 1024, lane);
       uint4 o0, o1;
       eb[part][0] |= bpack<true, FMT>(acc, ph, o0, o1, dpre, dp0 + 2 * t) << (8 * t);
+      stage_phase((T + 2) & 3, PreSched::frag(T + 2));
       if constexpr (part == 0) d_rgbh[2 * t] = o0, d_rgbh[2 * t + 1] = o1;
       else if constexpr (part == 1) d_s3[2 * t] = o0, d_s3[2 * t + 1] = o1;
       else d_e1[2 * t] = o0, d_e1[2 * t + 1] = o1;
@@ -255,8 +315,8 @@ __global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
   uint4 d_g2[3 * kHS];  // [d rgbh | d s1 | d e1] : the input of bG2
   {
     uint4 d_s2[kHS], d_s1[kHS];
-    bstage<FMT, kHS, 2, 2, BS::G_S3, true, kHS, kActS2, kDpS2>(d_s3, d_s2, ring, stream, wave, lane, acts, A, dpre);
-    bstage<FMT, kHS, 2, 2, BS::G_S2, true, kHS, kActS1, kDpS1>(d_s2, d_s1, ring, stream, wave, lane, acts, A, dpre);
+    bstage<FMT, kHS, 2, 2, BS::G_S3, true, kHS, 3 * kMTH, kDpS2>(d_s3, d_s2, ring, stream, wave, lane, stage, stage_phase, dpre);
+    bstage<FMT, kHS, 2, 2, BS::G_S2, true, kHS, 3 * kMTH + 4, kDpS1>(d_s2, d_s1, ring, stream, wave, lane, stage, stage_phase, dpre);
 #pragma unroll
     for (int i = 0; i < kHS; ++i) d_g2[i] = d_rgbh[i], d_g2[kHS + i] = d_s1[i], d_g2[2 * kHS + i] = d_e1[i];
   }
@@ -264,7 +324,7 @@ __global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
   uint4 d_g1[kKS + 1];  // [d feats (16) | d sigma_pre (1)] : the input of bG1
   {
     uint4 d_feats[kKS];
-    bstage<FMT, 3 * kHS, 1, kMT, BS::G_G2, false, kKS, 0, kDpFeats>(d_g2, d_feats, ring, stream, wave, lane, acts, A, dpre);
+    bstage<FMT, 3 * kHS, 1, kMT, BS::G_G2, false, kKS, -1, kDpFeats>(d_g2, d_feats, ring, stream, wave, lane, stage, stage_phase, dpre);
     bchunk_enter<BS::G_DT>(ring, stream, wave, lane);
     const f32x16 acc = btile<kHS>(ring + (BS::G_DT % kNSLOT) * kBSlot, 0, d_e1, lane);
     if (valid && prm.d_t) {
@@ -280,20 +340,12 @@ __global__ void __launch_bounds__(512) satnerf_bwd_kernel(const BwdParams prm) {
   }
   // ---- bG1: -> d a7, x cos(phase a7) = d pre_7 ----------------------------------------------------------------------
   uint4 cur[kKS], nxt[kKS];
-  bstage<FMT, kKS + 1, 1, kMT, BS::G_G1, true, kKS, kActA0 + 7 * kKS, kDpL + 7 * kKS>(d_g1, cur, ring, stream, wave, lane, acts, A, dpre);
+  bstage<FMT, kKS + 1, 1, kMT, BS::G_G1, true, kKS, 3 * kMTH + 8, kDpL + 7 * kKS>(d_g1, cur, ring, stream, wave, lane, stage, stage_phase, dpre);
   // ---- bL7 .. bL1: d pre_l -> d a_{l-1}, x cos(phase a_{l-1}) = d pre_{l-1}; scheduled by TrunkSched (above) -------------------
   constexpr long offL = BS::offset_pieces(BS::G_L);
-  constexpr int NPH = FMT == SR_FMT8 ? 1 : 2;  // phase units per tile
   // stores are NOT counted (NS = NSS = 0): loads retire in order among themselves, but a store may complete before an older load,
   // so only "younger LOADS still outstanding" proves that an older load has landed; the price is an occasional wait for a store
   using TS = TrunkSched<NPH, 0, 0>;  // (counting the stores as well measured the same: 138.3 vs 139.6 us)
-  char* stage = smem + kNSLOT * kBSlot + wave * (4 * NPH * 1024);  // this wave's phase staging ring: 4 tiles
-  const uint32_t stage_addr = __builtin_amdgcn_readfirstlane(lds_addr_of(stage));
-  auto stage_phase = [&](int slot, int frag) {  // frag = logical activation fragment of the tile's first value
-    const char* src = reinterpret_cast<const char*>(acts + (A + (FMT == SR_FMT8 ? frag >> 1 : frag)) * 64);
-#pragma unroll
-    for (int k = 0; k < NPH; ++k) glds16(src + k * 1024, stage_addr + (slot * NPH + k) * 1024);
-  };
   // G1's chunk protocol already requested the first trunk chunks; drain everything once and start from a known queue
   wait_then_barrier<0>();
   stage_phase(0, kActA0 + 6 * kKS), stage_phase(1, kActA0 + 6 * kKS + 2);
