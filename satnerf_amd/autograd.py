@@ -86,6 +86,8 @@ def render_rays_train(models, args, rays, ts, rng):
     emb_module = models["t"]
     if not hasattr(emb_module, "weight"):
         raise TypeError("training needs models['t'] to be an nn.Embedding")
+    from .train import _fmt_of
+
     mode = _mode_of(args)
     z = ops.ray_sample(rays, rng.rand(n, n_samples, dev), n_samples)
     result = {}
@@ -97,7 +99,7 @@ def render_rays_train(models, args, rays, ts, rng):
             model._trigger = torch.zeros(1, device=dev, requires_grad=True)
         noise = rng.randn(n, z_cur.shape[1], dev)
         keys = ("rgb", "depth", "weights", "transparency", "albedo", "sun", "sky", "beta")
-        if not model.fused:  # layer-by-layer path: every Linear is its own autograd Function (satnerf_amd.generic)
+        if not model.fused_training(mode, _fmt_of(args)):  # layer-by-layer path: every Linear is its own autograd Function (satnerf_amd.generic)
             from .generic import inference_pass
 
             res = inference_pass(model, args, rays, z_cur, ts, emb_module, (3, 6), noise)

@@ -18,9 +18,9 @@ extern "C" int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, in
                                   const uint16_t* stream_lo, const float* l0, float* albedo, float* sigma, float* sun_v,
                                   float* beta, uint16_t* acts, int act_fmt, void* stream) {
   SR_REQUIRE(in != nullptr, "sr_satnerf_mlp_fwd: null inputs");
-  SR_REQUIRE(feat == kFeat || feat == 512, "sr_satnerf_mlp_fwd: feat=%d unsupported (this build handles %d, and 512 for inference)", feat, kFeat);
-  SR_REQUIRE(feat == kFeat || (mode == SR_MODE_BF16 && acts == nullptr),
-             "sr_satnerf_mlp_fwd: feat=512 runs the fused kernel in SR_MODE_BF16 without saving activations (parity mode / training: layer by layer)");
+  SR_REQUIRE(feat == kFeat || feat == 512, "sr_satnerf_mlp_fwd: feat=%d unsupported (this build handles %d and 512)", feat, kFeat);
+  SR_REQUIRE(feat == kFeat || (mode == SR_MODE_BF16 && (acts == nullptr || act_fmt == SR_FMT8)),
+             "sr_satnerf_mlp_fwd: feat=512 runs the fused kernel in SR_MODE_BF16, saving activations in SR_FMT8 only (parity mode: layer by layer)");
   SR_REQUIRE(tau >= 1 && tau <= 24, "sr_satnerf_mlp_fwd: tau=%d unsupported (1..24)", tau);
   SR_REQUIRE(mode == SR_MODE_BF16 || mode == SR_MODE_BF16X3, "sr_satnerf_mlp_fwd: bad mode %d", mode);
   SR_REQUIRE(stream_hi && l0 && in->org && in->sun && in->temb, "sr_satnerf_mlp_fwd: null pointer argument");
@@ -48,9 +48,4 @@ extern "C" int64_t sr_fwd_stream_elems(int feat, int tau) {
   if ((feat != kFeat && feat != 512) || tau < 1 || tau > 24) return -1;
   if (feat == 512) return (aux_steps(tau) == 1 ? fwd512_stream_pieces_a1() : fwd512_stream_pieces_a2()) * 512;
   return (aux_steps(tau) == 1 ? FwdStream<1>::total_pieces() : FwdStream<2>::total_pieces()) * 512;
-}
-
-extern "C" int64_t sr_act_elems_per_tile(int feat, int fmt) {
-  if (feat != kFeat || (fmt != SR_FMT16 && fmt != SR_FMT8)) return -1;
-  return (int64_t)(fmt == SR_FMT8 ? act8_units(2) : act_ksteps(2)) * 64 * 8;  // sized for the larger aux layout
 }

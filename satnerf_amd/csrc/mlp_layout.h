@@ -105,26 +105,35 @@ constexpr int kDpL = 0, kDpFeats = 8 * kKS, kDpSigma = kDpFeats + kKS, kDpRgbh =
 //   MX8   : identity stages and pre-activation gradients, offset-binary int8 with ONE shared power-of-two scale per lane per DF
 //           (16 values): v = (u - 128) * 2^(E - 133), E = biased exponent of 1.0079 * max|v| -- the micro-scaled int8 of the
 //           OCP MX formats with the block laid along a point's features (what a lane holds) instead of along K.
-// activations (per 32-point tile):  aux (auxs bf16 fragments) | a0..a7 (8 DF each, PHASE8) | feats (8 DF, MX8) |
-//   rgbh s1 e1 s2 s3 (4 DF each, PHASE8) | feats scale unit (lane's 16 B: byte t = E of feats DF t)
-constexpr int kA8Trunk = 0, kA8Feats = 64, kA8Rgbh = 72, kA8S1 = 76, kA8E1 = 80, kA8S2 = 84, kA8S3 = 88, kA8Scale = 92;  // + auxs
-constexpr int act8_units(int auxs) { return auxs + 93; }
-// pre-activation gradients:  d_pre_0..7 (8 DF each) | d_feats (8) | d_rgbh d_s1 d_e1 d_s2 d_s3 (4 each) -- all MX8 -- |
-//   d_sigma_pre, d_head (one bf16 fragment each) | 7 scale units: group g = 0..7 trunk layer, 8 feats, 9 rgbh, 10 s1, 11 e1,
-//   12 s2, 13 s3 keeps byte (g & 1) * 8 + t of the lane's 16 B in unit kD8Scale + (g >> 1)
-constexpr int kD8L = 0, kD8Feats = 64, kD8Rgbh = 72, kD8S1 = 76, kD8E1 = 80, kD8S2 = 84, kD8S3 = 88, kD8Sigma = 92, kD8Head = 93,
-              kD8Scale = 94, kD8Units = 101;
+// activations (per 32-point tile):  aux (auxs bf16 fragments) | a0..a7 (kMT DF each, PHASE8) | feats (kMT DF, MX8) |
+//   rgbh s1 e1 s2 s3 (kMTH DF each, PHASE8) | feats scale unit (lane's 16 B: byte t = E of feats DF t).  The DF of logical
+//   fragment f is unit f >> 1 (+ auxs): feat 256: 64 + 8 + 20 = 92 DF, feat 512: 184.
+constexpr int kA8Scale = (9 * kKS + 5 * kHS) / 2;  // + auxs
+constexpr int act8_units(int auxs) { return auxs + kA8Scale + 1; }
+// pre-activation gradients:  d_pre_0..7 (kMT DF each) | d_feats (kMT) | d_rgbh d_s1 d_e1 d_s2 d_s3 (kMTH each) -- all MX8 -- |
+//   d_sigma_pre, d_head (one bf16 fragment each) | scale units.  Scale group g = 0..7 trunk layer, 8 feats, 9 rgbh, 10 s1, 11 e1,
+//   12 s2, 13 s3 owns a slot of kMT bytes (one per tile of the group); kD8GroupsPerUnit = 16 / kMT slots share a lane's 16 B:
+//   byte (g % kD8GroupsPerUnit) * kMT + t of unit kD8Scale + g / kD8GroupsPerUnit.  feat 256: 7 units (101 in all), feat 512: 14 (200).
+constexpr int kD8Sigma = (9 * kKS + 5 * kHS) / 2, kD8Head = kD8Sigma + 1, kD8Scale = kD8Head + 1;
+constexpr int kD8GroupsPerUnit = 16 / kMT, kD8ScaleUnits = (14 + kD8GroupsPerUnit - 1) / kD8GroupsPerUnit, kD8Units = kD8Scale + kD8ScaleUnits;
+static_assert(kMT <= 16, "a scale slot must fit the lane's 16 bytes");
+constexpr int dp8_unit(int frag) { return frag < kDpSigma ? frag >> 1 : (frag - 1) >> 1; }  // d_sigma_pre sits between the logical fragments
+constexpr int dp8_group(int frag) { return frag < kDpFeats ? frag / kKS : frag < kDpSigma ? 8 : 9 + (frag - kDpRgbh) / kHS; }
 // SR_FMT16 / SR_FMT8 are defined in include/satrender.h
 
 // backward (dX) stream: transposed weights, scale 1, chunk list in consumption order.  A chunk is `tiles(st)` output
-// tiles of `ppt(st)` pieces each (pieces of a tile are contiguous); every chunk fits one 24-piece ring slot.
+// tiles of `ppt(st)` pieces each (pieces of a tile are contiguous); every chunk fits one ring slot of SLOTP pieces (24 at feat
+// 256, 33 at feat 512, where a bG2 tile -- 48 pieces -- is consumed as kG2Split = 2 chunks of 24 accumulating into one tile).
 //   bH (d_head -> d rgbh | d s3 | d e1) | bS3 | bS2 | bG2 ([d rgbh, d s1, d e1] -> d feats) | bDT (d e1 -> d t) |
 //   bG1 ([d feats, d sigma] -> d a7) | bL7 .. bL1 (d pre_l -> d a_{l-1})
+constexpr int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 struct BwdStream {
-  static constexpr int SLOTP = 3 * kHS;  // 24 pieces per ring slot
+  static constexpr int kG2Split = (3 * kHS + 23) / 24;  // chunks per bG2 tile
+  static constexpr int kG2Part = 3 * kHS / kG2Split;    // pieces per bG2 chunk
+  static constexpr int SLOTP = max3(kG2Part, kKS + 1, 3 * kMTH);  // pieces per ring slot
   static constexpr int NSTAGE = 7;
   static constexpr int cnt(int st) {
-    constexpr int c[NSTAGE] = {1, 2, 2, kMT, 1, kMT, kTrunkLayers * kMT};
+    constexpr int c[NSTAGE] = {1, kMTH / 2, kMTH / 2, kMT * kG2Split, 1, kMT, kTrunkLayers * kMT};
     return c[st];
   }
   static constexpr int tiles(int st) {
@@ -132,7 +141,7 @@ struct BwdStream {
     return t[st];
   }
   static constexpr int ppt(int st) {
-    constexpr int z[NSTAGE] = {1, kHS, kHS, 3 * kHS, kHS, kKS + 1, kKS};
+    constexpr int z[NSTAGE] = {1, kHS, kHS, kG2Part, kHS, kKS + 1, kKS};
     return z[st];
   }
   static constexpr int first(int st) {
@@ -140,7 +149,8 @@ struct BwdStream {
     for (int k = 0; k < st; ++k) g += cnt(k);
     return g;
   }
-  static constexpr int G_H = 0, G_S3 = 1, G_S2 = 3, G_G2 = 5, G_DT = G_G2 + kMT, G_G1 = G_DT + 1, G_L = G_G1 + kMT;
+  static constexpr int G_H = 0, G_S3 = 1, G_S2 = G_S3 + kMTH / 2, G_G2 = G_S2 + kMTH / 2, G_DT = G_G2 + kMT * kG2Split, G_G1 = G_DT + 1,
+                       G_L = G_G1 + kMT;
   static constexpr int NCH = G_L + kTrunkLayers * kMT;
   static constexpr int np(int g) {
     if (g < 0 || g >= NCH) return 0;

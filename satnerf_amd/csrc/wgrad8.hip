@@ -33,6 +33,7 @@ struct Wgrad8Params {
   int n_blocks;
   int ak;             // activation units per tile
   int auxs;
+  int dk;  // units per tile of the dpre workspace
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(1024) wgrad8_kernel(const Wgrad8Params prm) {
   const int n_ld = (int)has_prim + (int)has_sec;  // 0..2 DMA instructions per tile
   const int src_unit = lane < 32 ? lane : 32 + ((lane - 8) & 31);  // rotated image: position `lane` holds this source lane's 16 B
   const uint32_t ring = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
-  const long p_stride = (prim & 3) == kSrcDpre ? kD8Units : prm.ak, s_stride = sec_src == kSrcDpre ? kD8Units : prm.ak;
+  const long p_stride = (prim & 3) == kSrcDpre ? prm.dk : prm.ak, s_stride = sec_src == kSrcDpre ? prm.dk : prm.ak;
   const uint4* p_base = ((prim & 3) == kSrcDpre ? prm.dpre : prm.acts) + p_unit * 64 + src_unit;
   const uint4* s_base = (sec_src == kSrcDpre ? prm.dpre : prm.acts) + sec_unit * 64 + (sec_is_aux ? src_unit : lane);
   const int p_off = (p_codec == kRaw16 ? p_dst : p_dst + 1) * kFragStride8;  // a DF lands where its second fragment will be
@@ -234,7 +235,7 @@ using namespace sr;
 
 extern "C" int sr_satnerf_wgrad8(int feat, int tau, int64_t n_points, const uint16_t* dpre, const uint16_t* acts, const int32_t* blocks,
                                  const int32_t* loads, int n_blocks, int n_slices, float* partial, void* stream) {
-  SR_REQUIRE(feat == kFeat, "sr_satnerf_wgrad8: feat=%d unsupported", feat);
+  SR_REQUIRE(feat == 256 || feat == 512, "sr_satnerf_wgrad8: feat=%d unsupported (256, 512)", feat);
   SR_REQUIRE(dpre && acts && blocks && loads && partial, "sr_satnerf_wgrad8: null pointer argument");
   SR_REQUIRE(n_blocks >= 1 && n_slices >= n_blocks, "sr_satnerf_wgrad8: bad plan (%d blocks, %d slices): run sr_wgrad_plan first", n_blocks, n_slices);
   Wgrad8Params p;
@@ -242,7 +243,8 @@ extern "C" int sr_satnerf_wgrad8(int feat, int tau, int64_t n_points, const uint
   p.n_tiles = (n_points + 31) / 32;
   p.n_blocks = n_blocks;
   p.auxs = aux_steps(tau);
-  p.ak = act8_units(p.auxs);
+  p.ak = (int)(sr_act_elems_per_tile(feat, SR_FMT8) / 512) - (2 - p.auxs);  // the size query assumes the 2-step aux layout
+  p.dk = (int)(sr_dpre_elems_per_tile(feat, SR_FMT8) / 512);
   const size_t lds = (size_t)kSlots8 * kSlot8Bytes;
   static bool attr_set = false;
   if (!attr_set) {

@@ -115,7 +115,7 @@ class SatNeRF(_FlatParamModule):
         # the fused register-resident kernel is built for the BASELINE shape; everything else (opt.py's default fc_units=512
         # included) runs layer by layer through satnerf_amd.generic
         self.fused = feat == 256 and layers == 8 and list(skips) == [4]
-        # ... and a 512-wide build of the forward kernel (opt.py:50's default width): inference in the throughput arithmetic only
+        # ... and a 512-wide build of the fused kernels (opt.py:50's default width): throughput arithmetic + 8-bit workspaces only
         self._fused_wide = feat == 512 and layers == 8 and list(skips) == [4]
         self.t_embedding_dims = t_embedding_dims
         self.mapping = [nn.Identity(), nn.Identity()]  # plain list, not registered (models/satnerf.py:101)
@@ -143,6 +143,10 @@ class SatNeRF(_FlatParamModule):
     def fused_forward(self, mode):
         """True when a no-grad forward in numeric mode ``mode`` runs in the fused kernel (else: layer by layer, satnerf_amd.generic)."""
         return self.fused or (self._fused_wide and mode == "bf16")
+
+    def fused_training(self, mode, fmt):
+        """True when forward + backward run in the fused kernels (256: every mode / format; 512: bf16 with the 8-bit workspaces)."""
+        return self.fused or (self._fused_wide and mode == "bf16" and int(fmt) == 8)
 
     # ---- weight stream ------------------------------------------------------------------------------------
     def packed(self, mode):

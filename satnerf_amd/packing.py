@@ -270,11 +270,13 @@ def backward_maps(feat=256, tau=4):
     Returns dict(idx, scale: bwd stream;  blocks int32 [n_blocks, 12] = (rf0, nr0, rf1, nr1, cf0, nc0, cf1, nc1, col_kind, 0, 0, 0):
     up to two row / two column fragment ranges per block (block_rows / block_cols list the fragments);
     gidx int32 [n_params] position of each parameter's gradient in the block-partial buffer (-1: not produced here),
-    gscale fp32 [n_params]).
+    gscale fp32 [n_params]).  feat 256: the hand-packed 14-block table; feat 512 (8-bit workspaces only): 47 blocks generated from
+    the same job list (a 512 x 512 layer = four 256 x 256 blocks).
     """
-    if feat != 256:
-        raise ValueError(f"feat={feat} unsupported by this build (256)")
+    if feat not in (256, 512):
+        raise ValueError(f"feat={feat} unsupported by this build (256, 512)")
     half, auxs = feat // 2, aux_steps(tau)
+    KS, HS = feat // 16, half // 16
     offsets, n_params = param_offsets(satnerf_param_shapes(feat, tau))
 
     def transposed(n_in, parts, in_col0=0):
@@ -291,47 +293,66 @@ def backward_maps(feat=256, tau=4):
             s0 += nslots
         return m
 
-    phi128, phi256, phi16 = slot_to_feat(np.arange(128)), slot_to_feat(np.arange(256)), slot_to_feat(np.arange(16))
+    phi_h, phi_f, phi16 = slot_to_feat(np.arange(half)), slot_to_feat(np.arange(feat)), slot_to_feat(np.arange(16))
     head_rows = lambda lo, hi: np.where((phi16 >= lo) & (phi16 < hi), phi16 - lo, -1)  # noqa: E731
     mats = []
-    # bH: d_head (16 slots, rows 0..4 live) -> d rgb hidden | d sun hidden 3 | d beta hidden (12 tiles x 1 piece)
+    # bH: d_head (16 slots, rows 0..4 live) -> d rgb hidden | d sun hidden 3 | d beta hidden (3 * half / 32 tiles x 1 piece)
     for name, lo, hi in (("rgb_from_xyzdir.2.weight", 0, 3), ("sun_v_net.6.weight", 3, 4), ("beta_from_xyz.2.weight", 4, 5)):
         mats.append(transposed(half, [(name, 16, head_rows(lo, hi))]))
-    mats.append(transposed(half, [("sun_v_net.4.weight", 128, phi128)]))  # bS3
-    mats.append(transposed(half, [("sun_v_net.2.weight", 128, phi128)]))  # bS2
-    mats.append(transposed(feat, [("rgb_from_xyzdir.0.weight", 128, phi128), ("sun_v_net.0.weight", 128, phi128),
-                                  ("beta_from_xyz.0.weight", 128, phi128)]))  # bG2
-    dt = transposed(32, [("beta_from_xyz.0.weight", 128, phi128)], in_col0=feat)  # bDT: rows = t index
+    mats.append(transposed(half, [("sun_v_net.4.weight", half, phi_h)]))  # bS3
+    mats.append(transposed(half, [("sun_v_net.2.weight", half, phi_h)]))  # bS2
+    mats.append(transposed(feat, [("rgb_from_xyzdir.0.weight", half, phi_h), ("sun_v_net.0.weight", half, phi_h),
+                                  ("beta_from_xyz.0.weight", half, phi_h)]))  # bG2
+    dt = transposed(32, [("beta_from_xyz.0.weight", half, phi_h)], in_col0=feat)  # bDT: rows = t index
     dt.idx[tau:, :] = -1
     dt.scl[tau:, :] = 0.0
     mats.append(dt)
     sig_rows = np.where(phi16 == 0, 0, -1)
-    mats.append(transposed(feat, [("feats_from_xyz.weight", 256, phi256), ("sigma_from_xyz.0.weight", 16, sig_rows)]))  # bG1
+    mats.append(transposed(feat, [("feats_from_xyz.weight", feat, phi_f), ("sigma_from_xyz.0.weight", 16, sig_rows)]))  # bG1
     for l in range(7, 0, -1):
-        mats.append(transposed(feat, [(f"fc_net.{2 * l}.weight", 256, phi256)], in_col0=3 if l == 4 else 0))
+        mats.append(transposed(feat, [(f"fc_net.{2 * l}.weight", feat, phi_f)], in_col0=3 if l == 4 else 0))
     parts = [_serialize(m) for m in mats]
     idx = np.concatenate([p[0] for p in parts]).astype(np.int32)
     scale = np.concatenate([p[1] for p in parts]).astype(np.float32)
 
     # ---- weight-gradient jobs: rows = fragments of the dpre workspace, cols = fragments of the saved activations
     A = auxs  # activation fragment offsets (mlp_layout.h)
-    a_frag = lambda l: A + 16 * l  # noqa: E731
-    ACT_FEATS, ACT_RGBH, ACT_S1, ACT_E1, ACT_S2, ACT_S3 = A + 128, A + 144, A + 152, A + 160, A + 168, A + 176
-    DP_FEATS, DP_SIGMA, DP_RGBH, DP_S2, DP_S3, DP_HEAD = 128, 144, 145, 169, 177, 185
+    a_frag = lambda l: A + KS * l  # noqa: E731
+    ACT_FEATS = A + 8 * KS
+    ACT_RGBH, ACT_S1, ACT_E1, ACT_S2, ACT_S3 = (ACT_FEATS + KS + k * HS for k in range(5))
+    DP_FEATS, DP_SIGMA = 8 * KS, 9 * KS
+    DP_RGBH = DP_SIGMA + 1
+    DP_S1, DP_E1, DP_S2, DP_S3, DP_HEAD = (DP_RGBH + k * HS for k in range(1, 6))
     tab = _Blocks()
-    for l in range(1, 8):
-        tab.add([(16 * l, 16)], [(a_frag(l - 1), 16)], KIND_PHASE)
-    tab.add([(DP_FEATS, 16)], [(a_frag(7), 16)], KIND_PHASE)                          # feats_from_xyz
-    tab.add([(DP_SIGMA, 1), (0, 8)], [(a_frag(7), 16)], KIND_PHASE)                   # sigma head + first half of fc_net.0 (aux columns only)
-    tab.add([(DP_RGBH, 16)], [(ACT_FEATS, 16)], KIND_BF16)                            # rgb hidden + sun hidden 1
-    tab.add([(DP_RGBH + 16, 8), (8, 8)], [(ACT_FEATS, 16)], KIND_BF16)                # beta hidden + second half of fc_net.0
-    tab.add([(DP_S2, 8), (DP_S3, 8)], [(ACT_S1, 8), (ACT_S2, 8)], KIND_PHASE)         # sun hidden 2 and 3
-    tab.add([(DP_HEAD, 1)], [(ACT_RGBH, 8), (ACT_S3, 8)], KIND_PHASE)                 # rgb and sun output rows
-    tab.add([(DP_HEAD, 1)], [(ACT_E1, 8)], KIND_PHASE)                                # beta output row
+    if feat == 256:
+        for l in range(1, 8):
+            tab.add([(16 * l, 16)], [(a_frag(l - 1), 16)], KIND_PHASE)
+        tab.add([(DP_FEATS, 16)], [(a_frag(7), 16)], KIND_PHASE)                          # feats_from_xyz
+        tab.add([(DP_SIGMA, 1), (0, 8)], [(a_frag(7), 16)], KIND_PHASE)                   # sigma head + first half of fc_net.0 (aux columns only)
+        tab.add([(DP_RGBH, 16)], [(ACT_FEATS, 16)], KIND_BF16)                            # rgb hidden + sun hidden 1
+        tab.add([(DP_RGBH + 16, 8), (8, 8)], [(ACT_FEATS, 16)], KIND_BF16)                # beta hidden + second half of fc_net.0
+        tab.add([(DP_S2, 8), (DP_S3, 8)], [(ACT_S1, 8), (ACT_S2, 8)], KIND_PHASE)         # sun hidden 2 and 3
+        tab.add([(DP_HEAD, 1)], [(ACT_RGBH, 8), (ACT_S3, 8)], KIND_PHASE)                 # rgb and sun output rows
+        tab.add([(DP_HEAD, 1)], [(ACT_E1, 8)], KIND_PHASE)                                # beta output row
+    else:  # every job cut into blocks of <= 16 row fragments x <= 16 column fragments
+        def tile_job(r0, nr, c0, nc, kind):
+            for rb in range(0, nr, 16):
+                for cb in range(0, max(nc, 1), 16):
+                    tab.add([(r0 + rb, min(16, nr - rb))], [(c0 + cb, min(16, nc - cb))] if nc else [], kind)
+        for l in range(1, 8):
+            tile_job(KS * l, KS, a_frag(l - 1), KS, KIND_PHASE)
+        tile_job(DP_FEATS, KS, a_frag(7), KS, KIND_PHASE)      # feats_from_xyz
+        tile_job(DP_SIGMA, 1, a_frag(7), KS, KIND_PHASE)       # sigma head
+        tile_job(0, KS, 0, 0, KIND_PHASE)                      # fc_net.0: aux columns only
+        tile_job(DP_RGBH, 3 * HS, ACT_FEATS, KS, KIND_BF16)    # rgb / sun-1 / beta hidden layers
+        tile_job(DP_S2, HS, ACT_S1, HS, KIND_PHASE)
+        tile_job(DP_S3, HS, ACT_S2, HS, KIND_PHASE)
+        for c0 in (ACT_RGBH, ACT_S3, ACT_E1):                  # output rows
+            tile_job(DP_HEAD, 1, c0, HS, KIND_PHASE)
     jobs = {"L0": _Job(tab, 0, [])}
     for l in range(1, 8):
-        jobs[f"L{l}"] = _Job(tab, 16 * l, [a_frag(l - 1)])
-    jobs["G1"] = _Job(tab, DP_FEATS, [a_frag(7)])      # rows 0..255 feats, 256.. sigma (DP_SIGMA = DP_FEATS + 16)
+        jobs[f"L{l}"] = _Job(tab, KS * l, [a_frag(l - 1)])
+    jobs["G1"] = _Job(tab, DP_FEATS, [a_frag(7)])      # rows 0..feat-1 feats, feat.. sigma (DP_SIGMA = DP_FEATS + KS)
     jobs["G2"] = _Job(tab, DP_RGBH, [ACT_FEATS])
     jobs["S2"] = _Job(tab, DP_S2, [ACT_S1])
     jobs["S3"] = _Job(tab, DP_S3, [ACT_S2])
@@ -339,7 +360,7 @@ def backward_maps(feat=256, tau=4):
 
     gidx = np.full(n_params, -1, np.int64)
     gscale = np.zeros(n_params, np.float32)
-    inv256, inv128, inv16 = feat_to_slot(256), feat_to_slot(128), feat_to_slot(32)[:16]
+    inv_f, inv_h, inv16 = feat_to_slot(feat), feat_to_slot(half), feat_to_slot(32)[:16]
 
     def put(name, job, row_slots, seg, col_slots, scale_=1.0, cols=None):
         """grad of W[name][r, cols[c]] (or bias[r] when 1-D) lives at job.pos(row_slots[r], seg, col_slots[c])."""
@@ -357,39 +378,39 @@ def backward_maps(feat=256, tau=4):
         gscale[flat] = scale_
 
     AUXC = _Mat
-    put("fc_net.0.weight", jobs["L0"], inv256, "aux", AUXC.AUX_XYZ + np.arange(3), W0_FIRST)
-    put("fc_net.0.bias", jobs["L0"], inv256, "aux", AUXC.AUX_ONE, W0_FIRST)
+    put("fc_net.0.weight", jobs["L0"], inv_f, "aux", AUXC.AUX_XYZ + np.arange(3), W0_FIRST)
+    put("fc_net.0.bias", jobs["L0"], inv_f, "aux", AUXC.AUX_ONE, W0_FIRST)
     for l in range(1, 8):
         name, job = f"fc_net.{2 * l}", jobs[f"L{l}"]
         if l == 4:
-            put(name + ".weight", job, inv256, "aux", AUXC.AUX_XYZ + np.arange(3), cols=[0, 1, 2])
-            put(name + ".weight", job, inv256, 0, inv256, cols=3 + np.arange(256))
+            put(name + ".weight", job, inv_f, "aux", AUXC.AUX_XYZ + np.arange(3), cols=[0, 1, 2])
+            put(name + ".weight", job, inv_f, 0, inv_f, cols=3 + np.arange(feat))
         else:
-            put(name + ".weight", job, inv256, 0, inv256)
-        put(name + ".bias", job, inv256, "aux", AUXC.AUX_ONE)
-    put("feats_from_xyz.weight", jobs["G1"], inv256, 0, inv256)
-    put("feats_from_xyz.bias", jobs["G1"], inv256, "aux", AUXC.AUX_ONE)
-    put("sigma_from_xyz.0.weight", jobs["G1"], np.array([256 + inv16[0]]), 0, inv256)
-    put("sigma_from_xyz.0.bias", jobs["G1"], np.array([256 + inv16[0]]), "aux", AUXC.AUX_ONE)
+            put(name + ".weight", job, inv_f, 0, inv_f)
+        put(name + ".bias", job, inv_f, "aux", AUXC.AUX_ONE)
+    put("feats_from_xyz.weight", jobs["G1"], inv_f, 0, inv_f)
+    put("feats_from_xyz.bias", jobs["G1"], inv_f, "aux", AUXC.AUX_ONE)
+    put("sigma_from_xyz.0.weight", jobs["G1"], np.array([feat + inv16[0]]), 0, inv_f)
+    put("sigma_from_xyz.0.bias", jobs["G1"], np.array([feat + inv16[0]]), "aux", AUXC.AUX_ONE)
     for k, (name, aux0) in enumerate((("rgb_from_xyzdir.0", None), ("sun_v_net.0", AUXC.AUX_SUN), ("beta_from_xyz.0", AUXC.AUX_T))):
-        rows = 128 * k + inv128
-        put(name + ".weight", jobs["G2"], rows, 0, inv256, cols=np.arange(256))
+        rows = half * k + inv_h
+        put(name + ".weight", jobs["G2"], rows, 0, inv_f, cols=np.arange(feat))
         put(name + ".bias", jobs["G2"], rows, "aux", AUXC.AUX_ONE)
         if aux0 is not None:
-            extra = offsets[name + ".weight"][1][1] - 256
-            put(name + ".weight", jobs["G2"], rows, "aux", aux0 + np.arange(extra), cols=256 + np.arange(extra))
-    put("sun_v_net.2.weight", jobs["S2"], inv128, 0, inv128)
-    put("sun_v_net.2.bias", jobs["S2"], inv128, "aux", AUXC.AUX_ONE)
-    put("sun_v_net.4.weight", jobs["S3"], inv128, 0, inv128)
-    put("sun_v_net.4.bias", jobs["S3"], inv128, "aux", AUXC.AUX_ONE)
-    put("rgb_from_xyzdir.2.weight", jobs["H"], inv16[[0, 1, 2]], 0, inv128)
+            extra = offsets[name + ".weight"][1][1] - feat
+            put(name + ".weight", jobs["G2"], rows, "aux", aux0 + np.arange(extra), cols=feat + np.arange(extra))
+    put("sun_v_net.2.weight", jobs["S2"], inv_h, 0, inv_h)
+    put("sun_v_net.2.bias", jobs["S2"], inv_h, "aux", AUXC.AUX_ONE)
+    put("sun_v_net.4.weight", jobs["S3"], inv_h, 0, inv_h)
+    put("sun_v_net.4.bias", jobs["S3"], inv_h, "aux", AUXC.AUX_ONE)
+    put("rgb_from_xyzdir.2.weight", jobs["H"], inv16[[0, 1, 2]], 0, inv_h)
     put("rgb_from_xyzdir.2.bias", jobs["H"], inv16[[0, 1, 2]], "aux", AUXC.AUX_ONE)
-    put("sun_v_net.6.weight", jobs["H"], inv16[[3]], 1, inv128)
+    put("sun_v_net.6.weight", jobs["H"], inv16[[3]], 1, inv_h)
     put("sun_v_net.6.bias", jobs["H"], inv16[[3]], "aux", AUXC.AUX_ONE)
-    put("beta_from_xyz.2.weight", jobs["H"], inv16[[4]], 2, inv128)
+    put("beta_from_xyz.2.weight", jobs["H"], inv16[[4]], 2, inv_h)
     put("beta_from_xyz.2.bias", jobs["H"], inv16[[4]], "aux", AUXC.AUX_ONE)
     return dict(idx=idx, scale=scale, blocks=tab.table(), block_rows=tab.rows, block_cols=tab.cols, gidx=gidx.astype(np.int32), gscale=gscale,
-                n_params=n_params, auxs=auxs, offsets=offsets)
+                n_params=n_params, auxs=auxs, offsets=offsets, feat=feat)
 
 
 # ------------------------------------------------------------------------------------------------ 8-bit workspaces
@@ -397,35 +418,54 @@ def backward_maps(feat=256, tau=4):
 SRC_DPRE, SRC_ACTS = 1, 2
 RAW16, PHASE8, MX8 = 0, 1, 2
 WG8_LOAD_INTS = 20
-D8_SIGMA, D8_HEAD, D8_SCALE, D8_UNITS, A8_SCALE = 92, 93, 94, 101, 92
-_DP_SIGMA, _DP_RGBH, _DP_HEAD = 144, 145, 185
+def fmt8_geometry(feat=256):
+    """Unit (1 KiB) offsets of the 8-bit workspaces (csrc/mlp_layout.h kD8* / kA8*) and the 16-bit fragment numbers they map."""
+    KS, HS = feat // 16, feat // 32
+    MT = KS // 2
+    body = (9 * KS + 5 * HS) // 2
+    gpu = 16 // MT                                   # scale groups per scale unit
+    d8_scale = body + 2
+    return dict(KS=KS, HS=HS, MT=MT, MTH=HS // 2, D8_SIGMA=body, D8_HEAD=body + 1, D8_SCALE=d8_scale, GROUPS_PER_UNIT=gpu,
+                D8_UNITS=d8_scale + (14 + gpu - 1) // gpu, A8_SCALE=body,
+                DP_FEATS=8 * KS, DP_SIGMA=9 * KS, DP_RGBH=9 * KS + 1, DP_HEAD=9 * KS + 1 + 5 * HS, ACT_FEATS=8 * KS)
 
 
-def act8_units(auxs):
-    return auxs + 93
+D8_SIGMA, D8_HEAD, D8_SCALE, D8_UNITS, A8_SCALE = (fmt8_geometry(256)[k] for k in ("D8_SIGMA", "D8_HEAD", "D8_SCALE", "D8_UNITS", "A8_SCALE"))
 
 
-def dpre8_source(f):
+def act8_units(auxs, feat=256):
+    return auxs + fmt8_geometry(feat)["A8_SCALE"] + 1
+
+
+def dpre8_units(feat=256):
+    return fmt8_geometry(feat)["D8_UNITS"]
+
+
+def dpre8_source(f, feat=256):
     """Logical dpre fragment -> dict(unit, codec, half[, scale_unit, scale_byte]) in the 8-bit layout."""
-    if f == _DP_SIGMA:
-        return dict(unit=D8_SIGMA, codec=RAW16, half=0)
-    if f == _DP_HEAD:
-        return dict(unit=D8_HEAD, codec=RAW16, half=0)
-    u = f >> 1 if f < _DP_SIGMA else (f - 1) >> 1
-    half = f & 1 if f < _DP_SIGMA else (f - 1) & 1
-    if u < 72:
-        g, k = u // 8, u % 8           # trunk layers 0..7, d_feats = 8
+    g8 = fmt8_geometry(feat)
+    if f == g8["DP_SIGMA"]:
+        return dict(unit=g8["D8_SIGMA"], codec=RAW16, half=0)
+    if f == g8["DP_HEAD"]:
+        return dict(unit=g8["D8_HEAD"], codec=RAW16, half=0)
+    if f < g8["DP_SIGMA"]:
+        u, half = f >> 1, f & 1
+        g, k = u // g8["MT"], u % g8["MT"]                 # trunk layers 0..7, d_feats = 8
     else:
-        g, k = 9 + (u - 72) // 4, (u - 72) % 4
-    return dict(unit=u, codec=MX8, half=half, scale_unit=D8_SCALE + (g >> 1), scale_byte=(g & 1) * 8 + k)
+        u, half = (f - 1) >> 1, (f - 1) & 1
+        h = u - 9 * g8["MT"]
+        g, k = 9 + h // g8["MTH"], h % g8["MTH"]
+    gpu = g8["GROUPS_PER_UNIT"]
+    return dict(unit=u, codec=MX8, half=half, scale_unit=g8["D8_SCALE"] + g // gpu, scale_byte=(g % gpu) * g8["MT"] + k)
 
 
-def act8_source(f, auxs):
+def act8_source(f, auxs, feat=256):
     """Logical activation fragment (aux offset included, as in the job table) -> its 8-bit source."""
+    g8 = fmt8_geometry(feat)
     a = f - auxs
     assert a >= 0, "aux fragments are fetched by the kernel itself"
-    if 128 <= a < 144:  # feats: identity stage -> MX8
-        return dict(unit=auxs + (a >> 1), codec=MX8, half=a & 1, scale_unit=auxs + A8_SCALE, scale_byte=(a - 128) >> 1)
+    if g8["ACT_FEATS"] <= a < g8["ACT_FEATS"] + g8["KS"]:  # feats: identity stage -> MX8
+        return dict(unit=auxs + (a >> 1), codec=MX8, half=a & 1, scale_unit=auxs + g8["A8_SCALE"], scale_byte=(a - g8["ACT_FEATS"]) >> 1)
     return dict(unit=auxs + (a >> 1), codec=PHASE8, half=a & 1)
 
 
@@ -446,7 +486,7 @@ def wgrad8_loads(feat=256, tau=4):
                 areas.append((src, unit))
             return areas.index((src, unit))
 
-        for base, frags, src, lookup in ((0, rows, SRC_DPRE, dpre8_source), (16, cols, SRC_ACTS, lambda f: act8_source(f, auxs))):
+        for base, frags, src, lookup in ((0, rows, SRC_DPRE, lambda f: dpre8_source(f, feat)), (16, cols, SRC_ACTS, lambda f: act8_source(f, auxs, feat))):
             pos = 0
             while pos < len(frags):
                 d = lookup(frags[pos])

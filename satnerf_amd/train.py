@@ -176,8 +176,10 @@ class Trainer:
         self._seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
         self._adam_in_graph = False
         self.loss_fn = loss_fn
+        from .rendering import _mode_of
+
         self.direct = (loss_fn is None and p.is_cuda and args.n_importance == 0 and args.model == "sat-nerf"
-                       and getattr(models["coarse"], "fused", False))
+                       and hasattr(models["coarse"], "fused_training") and models["coarse"].fused_training(_mode_of(args), _fmt_of(args)))
         self.use_graph = use_graph and self.direct
         self._graph, self._static = None, None
         self.last_rgb = None

@@ -45,10 +45,14 @@ def test_version_and_stream_geometry(handle):
     for tau in (4, 16):  # the 512-wide build of the forward kernel (inference): same packer, its own stream geometry
         m = packing.forward_maps(512, tau)
         assert handle.sr_fwd_stream_elems(512, tau) == m["idx"].size
-    assert handle.sr_fwd_stream_elems(384, 4) == -1 and handle.sr_bwd_stream_elems(512, 4) == -1
+    for feat, tau in ((256, 4), (256, 16), (512, 4), (512, 16)):  # the dX stream, both widths
+        assert handle.sr_bwd_stream_elems(feat, tau) == packing.backward_maps(feat, tau)["idx"].size
+    assert handle.sr_fwd_stream_elems(384, 4) == -1 and handle.sr_bwd_stream_elems(384, 4) == -1
     assert handle.sr_fwd_stream_elems(256, 25) == -1
     assert handle.sr_act_elems_per_tile(256, 16) == 186 * 512 and handle.sr_dpre_elems_per_tile(256, 16) == 186 * 512
     assert handle.sr_act_elems_per_tile(256, 8) == 95 * 512 and handle.sr_dpre_elems_per_tile(256, 8) == 101 * 512  # the 8-bit workspaces
+    assert handle.sr_act_elems_per_tile(512, 8) == packing.act8_units(2, 512) * 512  # 512 wide: 8-bit workspaces only
+    assert handle.sr_dpre_elems_per_tile(512, 8) == packing.dpre8_units(512) * 512 and handle.sr_act_elems_per_tile(512, 16) == -1
     assert handle.sr_act_elems_per_tile(256, 4) == -1 and handle.sr_wgrad8_load_ints() == packing.WG8_LOAD_INTS
 
 

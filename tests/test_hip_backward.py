@@ -352,6 +352,74 @@ def test_layer_path_gradients_vs_oracle_autograd(feat, tau, sc):
     assert errs[worst] < 1e-3, errs
 
 
+@pytest.mark.parametrize("tau,sc,ds", [(4, 0.0, 0.0), (16, 0.1, 0.5)])
+def test_width_512_fused_training_gradients_vs_oracle_autograd(tau, sc, ds):
+    """opt.py:50's default fc_units = 512 (every sat-nerf line of run_all.sh) in the throughput arithmetic: the 512-wide builds of
+    the fused forward / dX kernels + the 8-bit weight-gradient kernel.  The kernel-direct Trainer's gradients of every parameter
+    and of the embedding (colour pass + solar correction + depth supervision) against autograd through the fp32 oracle on the
+    same draws; tolerance = the one of the 256-wide throughput mode (single-pass bf16 MFMA + 8-bit saved state)."""
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    args = O.default_args(fc_units=512, t_embbeding_tau=tau, sc_lambda=sc, ds_lambda=ds, mlp_mode="bf16")
+    params = O.procedural_satnerf_params(512, tau, seed=61)
+    embw = O.procedural_uniform((30, tau), 1.0, 62)
+    m = load_model(args)
+    m.load_state_dict(params)
+    assert not m.fused and m.fused_training("bf16", 8) and not m.fused_training("bf16x3", 16)
+    emb = torch.nn.Embedding(30, tau)
+    emb.load_state_dict({"weight": embw})
+    models = {"coarse": m.to(DEV), "t": emb.to(DEV)}
+    n, nd = 384, 128
+    rays, ts = O.synthetic_rays(n, seed=63)
+    d_rays, d_ts = O.synthetic_rays(nd, seed=64)
+    g = torch.Generator().manual_seed(65)
+    target = torch.rand(n, 3, generator=g)
+    depths = torch.stack([0.3 + 0.4 * torch.rand(nd, generator=g), 0.5 + torch.rand(nd, generator=g)], 1)
+    # the kernel-direct step draws its stratified jitter from torch's device generator: colour batch first, then the depth batch
+    torch.manual_seed(66)
+    u = torch.rand(n, 64, device=DEV).cpu()
+    u_d = torch.rand(nd, 64, device=DEV).cpu()
+    draws = [u, torch.zeros(n, 64)] + ([torch.zeros(n, 64)] if sc > 0 else [])
+    d_draws = [u_d, torch.zeros(nd, 64)] + ([torch.zeros(nd, 64)] if sc > 0 else [])
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    eo = embw.clone().requires_grad_(True)
+    mo = {"coarse": po, "t": eo}
+    lo = O.satnerf_loss(O.render_rays(mo, args, rays, ts, O.ReplayRng(draws)), target, lambda_sc=sc)
+    if ds > 0:
+        lo = lo + O.depth_loss(O.render_rays(mo, args, d_rays, d_ts, O.ReplayRng(d_draws)), depths[:, 0], depths[:, 1], ds)
+    lo.backward()
+
+    tr = Trainer(models, args, use_graph=False)
+    assert tr.direct
+    torch.manual_seed(66)
+    parts = tr._forward_backward(rays.to(DEV), ts.to(DEV), target.to(DEV),
+                                 depth=(d_rays.to(DEV), d_ts.to(DEV), depths.to(DEV)) if ds > 0 else None)
+    lh = parts.sum()
+    assert abs(lh.item() - lo.item()) < 2e-2 * abs(lo.item()), (lh.item(), lo.item())
+    sd = dict(models["coarse"].named_parameters())
+    errs = {k: maxnorm_rel(sd[k].grad.cpu(), po[k].grad) for k in po if po[k].grad is not None}
+    errs["embedding"] = maxnorm_rel(models["t"].weight.grad.cpu(), eo.grad)
+    worst = max(errs, key=errs.get)
+    print(512, tau, "worst", worst, f"{errs[worst]:.1e}")
+    assert errs[worst] < 5e-2, errs  # (the 256-wide step on the same batch: 3e-2, tools/grad_err_widths.py)
+
+
+def test_trainer_width_512_direct_training_run():
+    """512-wide kernel-direct steps (graph-captured) make the loss fall; the parity mode keeps the autograd path."""
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    torch.manual_seed(0)
+    args = O.default_args(fc_units=512, mlp_mode="bf16")
+    tr = Trainer({"coarse": load_model(args).to(DEV), "t": torch.nn.Embedding(30, 4).to(DEV)}, args)
+    assert tr.direct
+    rays, ts = O.synthetic_rays(512, seed=3)
+    target = torch.rand(512, 3, generator=torch.Generator().manual_seed(4)) * 0.2 + 0.4
+    losses = [tr.step(rays.to(DEV), ts.to(DEV), target.to(DEV)).item() for _ in range(12)]
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
+
+
 def test_trainer_runs_width_512_through_autograd_path():
     from satnerf_amd.models import load_model
     from satnerf_amd.train import Trainer

@@ -37,3 +37,18 @@ for tau in (4, 16):
             flop = 65536 * 5259264  # 5,259,264 FLOP per point at feat 512
             line += f" | graphed {dg*1e3:.3f} ms -> {1024/dg/1e6:.2f} M rays/s | MLP kernel {k*1e3:.1f} us = {flop/k/1e9:.0f} TFLOP/s ({flop/k/1e9/2500*100:.0f} % of bf16 peak)"
         print(line)
+
+# ---- training at fc_units = 512: the kernel-direct graph-captured step (bf16 + 8-bit workspaces) against the autograd / layer path (bf16x3)
+from satnerf_amd.train import Trainer  # noqa: E402
+
+target = torch.rand(1024, 3, device=dev) * 0.2 + 0.4
+for mode in ("bf16", "bf16x3"):
+    args = data.default_args(fc_units=512, t_embbeding_tau=4, mlp_mode=mode)
+    torch.manual_seed(0)
+    tr = Trainer({"coarse": load_model(args).to(dev), "t": torch.nn.Embedding(30, 4).to(dev)}, args)
+    nw, nt = (20, 100) if tr.direct else (3, 10)
+    for _ in range(nw): tr.step(rays, ts, target)
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(nt): tr.step(rays, ts, target)
+    torch.cuda.synchronize(); dt = (time.time() - t0) / nt
+    print(f"feat 512 training {mode:7s} ({'kernel-direct, graph' if tr.direct else 'autograd, layer path'}): {dt*1e3:.3f} ms/step -> {1024/dt/1e6:.3f} M rays/s")
