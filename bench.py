@@ -145,7 +145,8 @@ def measure(phase, mode, n_rays, n_samples, steps, warmup, world, rank, dev, wan
         def step():
             stepper.step_from_bank(bank)
     else:
-        graphed = rendering.GraphedRenderer(models, args, n_rays, dev)
+        # stratified jitter drawn inside the sampling kernel (Philox, per-rank seed), as the captured training step does
+        graphed = rendering.GraphedRenderer(models, args, n_rays, dev, kernel_rng=True, seed=1234 + rank)
         use_graph = [True]
 
         def step():
@@ -245,7 +246,8 @@ def main():
         "data": "synthetic", "phase": phase, "prewarm_steps": PREWARM,
         "config": {"workload": f"BASELINE configs[1]: sat-nerf fc_units=256 tau=4, {a.rays} rays x {a.samples} samples per GPU, "
                                f"noise_std=0 sc_lambda=0 n_importance=0, mlp_mode={a.mode}"
-                               + (f", saved state {fmt}-bit" if fmt else ""), "rays_per_gpu": a.rays,
+                               + (f", saved state {fmt}-bit" if fmt else "") + ", stratified jitter drawn in-kernel (Philox-4x32-10)",
+                   "rays_per_gpu": a.rays,
                    "n_samples": a.samples, "parallelism": f"dp{world}"},
         "roofline": roof,
     }

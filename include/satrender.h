@@ -156,9 +156,11 @@ int sr_depth_loss(const float* depth, const float* depths, int depths_stride, in
 int sr_ray_setup(const float* rays, int ray_stride, const float* u, int64_t n_rays, int n_samples, int hidden, const float* w1,
                  const float* b1, const float* w2, const float* b2, float* z_vals, float* sky, void* stream);
 /* the same with the stratified jitter u ~ U[0,1) (rendering.py:77) drawn INSIDE the kernel: Philox-4x32-10 keyed by `seed`,
- * counter = (ray, sample, step) with the step read from the 1-float device counter `step_counter` (NULL = 0; the counter
- * sr_pack_all ticks) -- a captured training step then needs no RNG launch */
-int sr_ray_setup_rng(const float* rays, int ray_stride, uint64_t seed, const float* step_counter, int64_t n_rays, int n_samples,
+ * counter = (ray, sample, step) with the step read from the device counter `step_counter[0]` (NULL = 0; the counter
+ * sr_pack_all ticks) -- a captured training step then needs no RNG launch.  tick != 0: this launch also advances the counter
+ * (captured forward passes have no sr_pack_all): `step_counter` is then a 4-float block as `sched`, [0] += 1 once every
+ * workgroup has read it, [3] is scratch (an arrival counter, zero-initialised by the caller) */
+int sr_ray_setup_rng(const float* rays, int ray_stride, uint64_t seed, float* step_counter, int tick, int64_t n_rays, int n_samples,
                      int hidden, const float* w1, const float* b1, const float* w2, const float* b2, float* z_vals, float* sky,
                      void* stream);
 int sr_render_loss(const float* z_vals, const float* sigma, const float* noise, float noise_std, const float* albedo,

@@ -57,7 +57,7 @@ SIGNATURES = {
     "sr_ray_setup": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sr_sc_loss": (_i, [_vp, _vp, _vp, _f, _vp, _i64, _i, _f, _vp, _vp, _vp]),
     "sr_depth_loss": (_i, [_vp, _vp, _i, _i, _i64, _f, _vp, _vp, _vp]),
-    "sr_ray_setup_rng": (_i, [_vp, _i, C.c_uint64, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sr_ray_setup_rng": (_i, [_vp, _i, C.c_uint64, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sr_render_loss": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sr_satnerf_loss": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sr_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i64, _i, _vp]),

@@ -128,15 +128,32 @@ __device__ __forceinline__ void philox4x32(uint32_t k0, uint32_t k1, uint32_t c[
   }
 }
 
+// A launch that draws from the device-side step counter can also advance it (forward graphs have no sr_pack_all to do so): every
+// workgroup reads counter[0] first, then checks in at the arrival counter kept in counter[3] (uint32 bits); the LAST one to
+// check in -- every other workgroup has read by then -- stores step + 1 and resets the arrival counter for the next launch.
+__device__ __forceinline__ void tick_when_all_read(float* counter, uint32_t step_read) {
+  asm volatile("" ::"v"(step_read));  // the value has arrived
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* arrive = reinterpret_cast<unsigned*>(counter + 3);
+    __threadfence();
+    if (atomicAdd(arrive, 1u) == gridDim.x - 1) {
+      counter[0] = (float)(step_read + 1u);
+      atomicExch(arrive, 0u);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) ray_setup_kernel(const float* __restrict__ rays, int ray_stride, const float* __restrict__ u, long n_rays,
                                                        int S, int hidden, const float* __restrict__ w1, const float* __restrict__ b1,
                                                        const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ z_out,
-                                                       float* __restrict__ sky, unsigned long long seed, const float* __restrict__ step_counter) {
+                                                       float* __restrict__ sky, unsigned long long seed, float* __restrict__ step_counter, int tick) {
   const int lane = threadIdx.x & 63;
   const long r = (long)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
+  const uint32_t rng_step = step_counter ? (uint32_t)step_counter[0] : 0u;
+  if (tick) tick_when_all_read(step_counter, rng_step);
   if (r >= n_rays) return;
   const float* ray = rays + r * ray_stride;
-  const uint32_t rng_step = step_counter ? (uint32_t)step_counter[0] : 0u;
   {
 #pragma clang fp contract(off)
     const float near = ray[6], far = ray[7];
@@ -705,19 +722,20 @@ extern "C" int sr_ray_setup(const float* rays, int ray_stride, const float* u, i
   SR_REQUIRE(ray_stride >= 11 && n_samples >= 2, "sr_ray_setup: ray_stride>=11 and n_samples>=2 required");
   if (n_rays <= 0) return 0;
   hipLaunchKernelGGL(ray_setup_kernel, dim3((unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(256), 0, (hipStream_t)stream, rays,
-                     ray_stride, u, (long)n_rays, n_samples, hidden, w1, b1, w2, b2, z_vals, sky, 0ull, (const float*)nullptr);
+                     ray_stride, u, (long)n_rays, n_samples, hidden, w1, b1, w2, b2, z_vals, sky, 0ull, (float*)nullptr, 0);
   return check_launch("ray_setup_kernel");
 }
 
-extern "C" int sr_ray_setup_rng(const float* rays, int ray_stride, uint64_t seed, const float* step_counter, int64_t n_rays, int n_samples,
+extern "C" int sr_ray_setup_rng(const float* rays, int ray_stride, uint64_t seed, float* step_counter, int tick, int64_t n_rays, int n_samples,
                                 int hidden, const float* w1, const float* b1, const float* w2, const float* b2, float* z_vals, float* sky,
                                 void* stream) {
+  SR_REQUIRE(!tick || step_counter, "sr_ray_setup_rng: tick needs the 4-float step counter block");
   SR_REQUIRE(rays && w1 && b1 && w2 && b2 && z_vals && sky, "sr_ray_setup_rng: null pointer");
   SR_REQUIRE(ray_stride >= 11 && n_samples >= 2, "sr_ray_setup_rng: ray_stride>=11 and n_samples>=2 required");
   if (n_rays <= 0) return 0;
   hipLaunchKernelGGL(ray_setup_kernel, dim3((unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(256), 0, (hipStream_t)stream, rays,
                      ray_stride, (const float*)nullptr, (long)n_rays, n_samples, hidden, w1, b1, w2, b2, z_vals, sky, (unsigned long long)seed,
-                     step_counter);
+                     step_counter, tick);
   return check_launch("ray_setup_kernel");
 }
 

@@ -456,17 +456,20 @@ def depth_loss(depth, depths, lambda_ds, use_weights=True):
     return parts, g
 
 
-def ray_setup(rays, u, n_samples, w1, b1, w2, b2, seed=0, step_counter=None):
+def ray_setup(rays, u, n_samples, w1, b1, w2, b2, seed=0, step_counter=None, tick=False):
     """Fused sr_ray_sample_fwd + sr_sky_fwd: returns (z (N,S), sky (N,3)).  ``u`` = (N,S) uniform jitter, or None to draw it inside
-    the kernel (Philox keyed by ``seed``, stepping with the 1-float device tensor ``step_counter``)."""
+    the kernel (Philox keyed by ``seed``, stepping with the device counter ``step_counter[0]``; ``tick``: the launch advances the
+    counter itself -- ``step_counter`` is then a zero-initialised 4-float block)."""
     rays, stride = _rows(rays, "rays", 11)
     n = rays.shape[0]
     z = torch.empty(n, n_samples, dtype=torch.float32, device=rays.device)
     sky_rgb = torch.empty(n, 3, dtype=torch.float32, device=rays.device)
     w = (_p(_chk(w1, "w1")), _p(_chk(b1, "b1")), _p(_chk(w2, "w2")), _p(_chk(b2, "b2")))
     if u is None:
-        _lib.call("sr_ray_setup_rng", _p(rays), stride, int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_chk(step_counter, "step_counter", allow_none=True)), n,
-                  n_samples, w1.shape[0], *w, _p(z), _p(sky_rgb), _stream())
+        if tick and (step_counter is None or step_counter.numel() < 4):
+            raise ValueError("tick=True needs step_counter = a zero-initialised float32 block of 4")
+        _lib.call("sr_ray_setup_rng", _p(rays), stride, int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_chk(step_counter, "step_counter", allow_none=True)),
+                  int(bool(tick)), n, n_samples, w1.shape[0], *w, _p(z), _p(sky_rgb), _stream())
     else:
         _lib.call("sr_ray_setup", _p(rays), stride, _p(_chk(u, "u")), n, n_samples, w1.shape[0], *w, _p(z), _p(sky_rgb), _stream())
     return z, sky_rgb

@@ -62,7 +62,29 @@ class _ReplayRng:
     rand = randn = _next
 
 
+class _KernelRng(_TorchRng):
+    """The stratified jitter of the fused path is drawn INSIDE the sampling kernel (Philox-4x32-10 keyed by ``seed``, counter =
+    (ray, sample, step); ``counter`` = a 4-float device block whose [0] the launch advances): the same distribution as
+    ``torch.rand`` but not torch's stream, so a captured forward needs no RNG launch and none of the generator-state
+    bookkeeping torch adds to a graph.  The ``randn`` of models/satnerf.py:58 is skipped while ``noise_std == 0`` (it is
+    multiplied by zero there); every other draw still comes from torch."""
+
+    def __init__(self, seed, counter):
+        self.seed, self.counter = int(seed), counter
+
+
 _rng = _TorchRng()
+
+
+@contextlib.contextmanager
+def kernel_rng(seed, counter):
+    """Draw ``render_rays``' stratified jitter inside the kernel (see ``_KernelRng``); ``counter`` = zeros(4) float32 on the GPU."""
+    global _rng
+    prev, _rng = _rng, _KernelRng(seed, counter)
+    try:
+        yield _rng
+    finally:
+        _rng = prev
 
 
 @contextlib.contextmanager
@@ -172,17 +194,23 @@ def render_rays(models, args, rays, ts, _ts_validated=False):
     sky_of = {}
     if hasattr(coarse, "fused_forward") and coarse.fused_forward(_mode_of(args)):  # stratified depths (rendering.py:62-78, perturb = 1) + the coarse sky head in one launch
         sk = coarse.sky_color
-        z, sky_of["coarse"] = ops.ray_setup(rays, _rng.rand(n, n_samples, dev), n_samples, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data,
-                                            sk[2].bias.data)
+        if isinstance(_rng, _KernelRng):
+            z, sky_of["coarse"] = ops.ray_setup(rays, None, n_samples, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data,
+                                                seed=_rng.seed, step_counter=_rng.counter, tick=True)
+        else:
+            z, sky_of["coarse"] = ops.ray_setup(rays, _rng.rand(n, n_samples, dev), n_samples, sk[0].weight.data, sk[0].bias.data,
+                                                sk[2].weight.data, sk[2].bias.data)
     else:
         z = ops.ray_sample(rays, _rng.rand(n, n_samples, dev), n_samples)
     result = {}
 
+    skip_noise = isinstance(_rng, _KernelRng) and args.noise_std == 0
+
     def run(typ, z_cur):
-        noise = _rng.randn(n, z_cur.shape[1], dev)  # models/satnerf.py:58 -- always drawn
+        noise = None if skip_noise else _rng.randn(n, z_cur.shape[1], dev)  # models/satnerf.py:58 -- always drawn
         res = _inference(models[typ], args, rays, z_cur, ts, emb, (3, 6), noise, sky_of.get(typ))
         if args.sc_lambda > 0:  # solar correction: same depths along the sun direction (rendering.py:102-108)
-            noise_sc = _rng.randn(n, z_cur.shape[1], dev)
+            noise_sc = None if skip_noise else _rng.randn(n, z_cur.shape[1], dev)
             sc = _inference(models[typ], args, rays, z_cur, ts, emb, (8, 11), noise_sc)
             res["weights_sc"], res["transparency_sc"], res["sun_sc"] = sc["weights"], sc["transparency"], sc["sun"]
         for k, v in res.items():
@@ -340,10 +368,14 @@ class GraphedRenderer:
     torch's generator exactly as eager calls would), so results and the random stream are unchanged.  Outputs are views of
     static buffers: they are overwritten by the next call -- clone what must survive.  Weights may change between calls
     (their streams are re-packed before the replay when they did) but not be re-allocated.
+
+    ``kernel_rng=True`` (``seed``): the stratified jitter is drawn inside the sampling kernel instead (``_KernelRng``: same
+    distribution, its own counter-based stream) -- the graph then holds no RNG launches and no generator bookkeeping.
     """
 
-    def __init__(self, models, args, n_rays, device):
+    def __init__(self, models, args, n_rays, device, kernel_rng=False, seed=0):
         self.models, self.args, self.n = models, args, n_rays
+        self._krng = (int(seed), torch.zeros(4, dtype=torch.float32, device=device)) if kernel_rng else None
         self.rays = torch.zeros(n_rays, 11, device=device)
         self.ts = torch.zeros(n_rays, dtype=torch.int64, device=device)
         self._rgbs = torch.zeros(n_rays, 3, device=device)  # gather target for a ray bank's colours (unused by rendering)
@@ -363,6 +395,9 @@ class GraphedRenderer:
                 self._packed_for[typ] = (m.weights_version(), m.flat_params().data_ptr(), mode)
 
     def _run(self):
+        if self._krng is not None:
+            with kernel_rng(*self._krng):
+                return render_rays(self.models, self.args, self.rays, self.ts)
         return render_rays(self.models, self.args, self.rays, self.ts)
 
     @torch.no_grad()
