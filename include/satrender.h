@@ -106,6 +106,56 @@ int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, int mode, con
                        const uint16_t* stream_lo, const float* l0, float* albedo, float* sigma, float* sun_v,
                        float* beta, uint16_t* acts, int act_fmt, void* stream);
 
+/* ---- one-launch render pass (no grad): rendering.py:62-81 (stratified sampling) -> models/satnerf.py:20-49 (the MLP over
+ *      every sample) -> models/satnerf.py:52-70 (compositing) + the per-ray sky head (:138-143) -- the same arithmetic as
+ *      sr_ray_setup -> sr_satnerf_mlp_fwd -> sr_composite_fwd, bit for bit, with the per-point values handed from the MLP to
+ *      the compositing through LDS: a workgroup owns sr_render_points_per_block(feat, mode) consecutive points = whole rays,
+ *      so n_samples must divide that number (64 and 128 do; other S: use the three separate launches).
+ * rays (N, ray_stride >= 11) = o d near far sun; ts (N) image indices into temb (vocab, tau).
+ * depths: z_in (N,S) given (the fine pass), else stratified with jitter u (N,S), else (both NULL) with jitter drawn in the kernel:
+ *   Philox keyed by `seed`, stepping with step_counter[0]; tick != 0: the launch advances that counter (see sr_ray_setup_rng).
+ * noise (N,S) or NULL with noise_std; sky_*: the sky head's weights (hidden, 3), (hidden), (3, hidden), (3).
+ * outputs: z_out (N,S) [NULL ok], albedo (N,S,3), sun_v (N,S), beta (N,S), sigma (N,S) [NULL ok], sky (N,3), weights (N,S),
+ *   transparency (N,S), depth (N), rgb (N,3) clamped to [0,1]. */
+typedef struct sr_render_args {
+  const float* rays;
+  int ray_stride;
+  const int64_t* ts;
+  const float* temb;
+  int64_t n_rays;
+  int n_samples;
+  const float* z_in;
+  const float* u;
+  uint64_t seed;
+  float* step_counter;
+  int tick;
+  const float* noise;
+  float noise_std;
+  int sky_hidden;
+  const float* sky_w1;
+  const float* sky_b1;
+  const float* sky_w2;
+  const float* sky_b2;
+} sr_render_args;
+
+typedef struct sr_render_outputs {
+  float* z_vals;
+  float* albedo;
+  float* sigma;
+  float* sun_v;
+  float* beta;
+  float* sky;
+  float* weights;
+  float* transparency;
+  float* depth;
+  float* rgb;
+} sr_render_outputs;
+
+int sr_satnerf_render_fwd(const sr_render_args* in, int feat, int tau, int mode, const uint16_t* stream_hi, const uint16_t* stream_lo,
+                          const float* l0, const sr_render_outputs* out, void* stream);
+/* points a workgroup of the fused kernel owns (256 / 128), or -1 when (feat, mode) has no fused build */
+int sr_render_points_per_block(int feat, int mode);
+
 /* ---- backward of the fused MLP: replaces autograd through SatNeRF.forward (models/satnerf.py:156-208) ------------
  * sr_satnerf_mlp_bwd: data-gradient chain.  Inputs: the forward's saved `acts`, its four outputs and the gradients of
  * those outputs (g_* may be NULL = 0); bwd_stream = packed transposed weights (sr_pack_stream with

@@ -23,6 +23,16 @@ class MlpInputs(C.Structure):
                 ("z", _vp), ("temb", _vp), ("ts", _vp), ("n_points", _i64), ("n_samples", _i)]
 
 
+class RenderArgs(C.Structure):
+    _fields_ = [("rays", _vp), ("ray_stride", _i), ("ts", _vp), ("temb", _vp), ("n_rays", _i64), ("n_samples", _i), ("z_in", _vp), ("u", _vp),
+                ("seed", C.c_uint64), ("step_counter", _vp), ("tick", _i), ("noise", _vp), ("noise_std", _f), ("sky_hidden", _i),
+                ("sky_w1", _vp), ("sky_b1", _vp), ("sky_w2", _vp), ("sky_b2", _vp)]
+
+
+class RenderOutputs(C.Structure):
+    _fields_ = [(k, _vp) for k in ("z_vals", "albedo", "sigma", "sun_v", "beta", "sky", "weights", "transparency", "depth", "rgb")]
+
+
 class LinearSrc(C.Structure):
     _fields_ = [("x", _vp), ("ld", _i), ("k", _i), ("act", _i), ("w0", _f), ("row_div", _i)]
 
@@ -37,6 +47,8 @@ SIGNATURES = {
     "sr_fwd_stream_elems": (_i64, [_i, _i]),
     "sr_bwd_stream_elems": (_i64, [_i, _i]),
     "sr_act_elems_per_tile": (_i64, [_i, _i]),
+    "sr_satnerf_render_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sr_render_points_per_block": (_i, [_i, _i]),
     "sr_pack_stream": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "sr_dpre_elems_per_tile": (_i64, [_i, _i]),
     "sr_unpack_grads": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _vp]),

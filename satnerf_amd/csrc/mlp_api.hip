@@ -30,6 +30,7 @@ extern "C" int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, in
   if (in->n_points <= 0) return 0;
   FwdParams p;
   p.in = *in;
+  p.rend = RenderParams{};
   p.stream_hi = (const char*)stream_hi;
   p.stream_lo = (const char*)stream_lo;
   p.l0 = (const float4*)l0;
@@ -48,4 +49,47 @@ extern "C" int64_t sr_fwd_stream_elems(int feat, int tau) {
   if ((feat != kFeat && feat != 512) || tau < 1 || tau > 24) return -1;
   if (feat == 512) return (aux_steps(tau) == 1 ? fwd512_stream_pieces_a1() : fwd512_stream_pieces_a2()) * 512;
   return (aux_steps(tau) == 1 ? FwdStream<1>::total_pieces() : FwdStream<2>::total_pieces()) * 512;
+}
+
+extern "C" int sr_render_points_per_block(int feat, int mode) {
+  if (mode != SR_MODE_BF16 && mode != SR_MODE_BF16X3) return -1;
+  if (feat == kFeat) return mode == SR_MODE_BF16 ? 256 : 128;  // Mode<NPASS>::NW * 32
+  if (feat == 512 && mode == SR_MODE_BF16) return 128;
+  return -1;
+}
+
+extern "C" int sr_satnerf_render_fwd(const sr_render_args* in, int feat, int tau, int mode, const uint16_t* stream_hi, const uint16_t* stream_lo,
+                                     const float* l0, const sr_render_outputs* out, void* stream) {
+  SR_REQUIRE(in != nullptr && out != nullptr, "sr_satnerf_render_fwd: null argument block");
+  const int per_block = sr_render_points_per_block(feat, mode);
+  SR_REQUIRE(per_block > 0, "sr_satnerf_render_fwd: no fused kernel for feat=%d mode=%d (256: both modes; 512: SR_MODE_BF16)", feat, mode);
+  SR_REQUIRE(tau >= 1 && tau <= 24, "sr_satnerf_render_fwd: tau=%d unsupported (1..24)", tau);
+  SR_REQUIRE(in->n_samples >= 2 && per_block % in->n_samples == 0,
+             "sr_satnerf_render_fwd: n_samples=%d must be >= 2 and divide %d (sr_render_points_per_block)", in->n_samples, per_block);
+  SR_REQUIRE(in->rays && in->ts && in->temb && in->ray_stride >= 11, "sr_satnerf_render_fwd: rays (stride >= 11), ts and temb are required");
+  SR_REQUIRE(stream_hi && l0 && (mode != SR_MODE_BF16X3 || stream_lo), "sr_satnerf_render_fwd: null weight stream");
+  SR_REQUIRE(in->sky_w1 && in->sky_b1 && in->sky_w2 && in->sky_b2 && in->sky_hidden >= 1, "sr_satnerf_render_fwd: the sky head's weights are required");
+  SR_REQUIRE(out->weights && out->transparency, "sr_satnerf_render_fwd: weights and transparency outputs are required");
+  SR_REQUIRE(!in->tick || in->step_counter, "sr_satnerf_render_fwd: tick needs the 4-float step counter block");
+  if (in->n_rays <= 0) return 0;
+  FwdParams p;
+  p.in.org = in->rays, p.in.org_stride = in->ray_stride;
+  p.in.dir = in->rays + 3, p.in.dir_stride = in->ray_stride;
+  p.in.sun = in->rays + 8, p.in.sun_stride = in->ray_stride;
+  p.in.z = nullptr, p.in.temb = in->temb, p.in.ts = in->ts;
+  p.in.n_points = in->n_rays * in->n_samples, p.in.n_samples = in->n_samples;
+  RenderParams& r = p.rend;
+  r.rays = in->rays, r.ray_stride = in->ray_stride, r.z_in = in->z_in, r.u = in->u, r.seed = in->seed, r.step_counter = in->step_counter;
+  r.tick = in->tick, r.noise = in->noise, r.noise_std = in->noise_std, r.sky_hidden = in->sky_hidden;
+  r.w1 = in->sky_w1, r.b1 = in->sky_b1, r.w2 = in->sky_w2, r.b2 = in->sky_b2;
+  r.z_out = out->z_vals, r.sky = out->sky, r.weights = out->weights, r.transp = out->transparency, r.depth = out->depth, r.rgb = out->rgb;
+  r.n_rays = in->n_rays;
+  p.stream_hi = (const char*)stream_hi, p.stream_lo = (const char*)stream_lo, p.l0 = (const float4*)l0;
+  p.albedo = out->albedo, p.sigma = out->sigma, p.sun_v = out->sun_v, p.beta = out->beta;
+  p.acts = nullptr, p.tau = tau;
+  hipStream_t st = (hipStream_t)stream;
+  const int auxs = aux_steps(tau);
+  if (feat == 512) return auxs == 1 ? launch_fwd512_p1a1(p, 0, st) : launch_fwd512_p1a2(p, 0, st);
+  if (mode == SR_MODE_BF16) return auxs == 1 ? launch_fwd_p1a1(p, 0, st) : launch_fwd_p1a2(p, 0, st);
+  return auxs == 1 ? launch_fwd_p3a1(p, 0, st) : launch_fwd_p3a2(p, 0, st);
 }

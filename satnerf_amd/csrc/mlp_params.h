@@ -5,8 +5,32 @@
 
 namespace sr {
 
+// the fused render pass around the MLP (csrc/mlp_fwd.inc REND): stratified sampling in the prologue, the sky head and the
+// sigma->alpha compositing of the workgroup's rays in the epilogue.  rays == NULL: plain MLP launch.
+struct RenderParams {
+  const float* rays;       // (N, ray_stride >= 11): o(3) d(3) near far sun(3)
+  int ray_stride;
+  const float* z_in;       // (N,S) given depths (fine pass), or NULL: stratified from u / the in-kernel RNG
+  const float* u;          // (N,S) jitter, or NULL: Philox(seed, step_counter[0])
+  unsigned long long seed;
+  float* step_counter;
+  int tick;
+  const float* noise;      // (N,S) or NULL
+  float noise_std;
+  int sky_hidden;
+  const float *w1, *b1, *w2, *b2;
+  float* z_out;            // (N,S) or NULL
+  float* sky;              // (N,3)
+  float* weights;          // (N,S)
+  float* transp;           // (N,S)
+  float* depth;            // (N)
+  float* rgb;              // (N,3)
+  long n_rays;
+};
+
 struct FwdParams {
   sr_mlp_inputs in;
+  RenderParams rend;
   const char* stream_hi;
   const char* stream_lo;
   const float4* l0;

@@ -7,6 +7,7 @@
 
 #include "common.h"
 #include "mlp_layout.h"
+#include "ray_device.h"
 
 namespace sr {
 
@@ -29,50 +30,7 @@ int check_launch(const char* what) {
 
 constexpr int kRaysPerBlock = 4;  // 4 waves = 256 threads
 
-// ---- wave primitives (64 lanes) ---------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
-// inclusive scans across the wave
-__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_up(v, d, 64);
-    if (lane >= d) v *= o;
-  }
-  return v;
-}
-__device__ __forceinline__ float wave_scan_add(float v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_up(v, d, 64);
-    if (lane >= d) v += o;
-  }
-  return v;
-}
-__device__ __forceinline__ float wave_rscan_add(float v, int lane) {  // inclusive suffix sum
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_down(v, d, 64);
-    if (lane + d < 64) v += o;
-  }
-  return v;
-}
-
-// ---- stratified sampling: rendering.py:62-78 ---------------------------------------------------------------
-// torch.linspace(0,1,S) in fp32: step = 1/(S-1); i < S/2 ? i*step : 1 - step*(S-1-i), the latter FUSED (one
-// rounding) -- ATen RangeFactories as compiled; checked bit-for-bit against torch.linspace for S in {2,7,50,64,128}.
-__device__ __forceinline__ float linspace01(int i, int n, float step) {
-  return i < n / 2 ? (float)i * step : __builtin_fmaf(-step, (float)(n - 1 - i), 1.0f);
-}
-__device__ __forceinline__ float lerp_near_far(float near, float far, float s) {
-#pragma clang fp contract(off)
-  const float a = near * (1.0f - s), b = far * s;  // rendering.py:67, this exact form
-  return a + b;
-}
-
+// ---- stratified sampling: rendering.py:62-78 (ray_device.h stratified_z) ---------------------------------
 __global__ void __launch_bounds__(256) ray_sample_kernel(const float* __restrict__ rays, int ray_stride, const float* __restrict__ u,
                                                         long n_rays, int S, float* __restrict__ z_out) {
 #pragma clang fp contract(off)
@@ -80,15 +38,7 @@ __global__ void __launch_bounds__(256) ray_sample_kernel(const float* __restrict
   if (idx >= n_rays * S) return;
   const long r = idx / S;
   const int j = (int)(idx - r * S);
-  const float near = rays[r * ray_stride + 6], far = rays[r * ray_stride + 7];
-  const float step = 1.0f / (float)(S - 1);
-  const float zj = lerp_near_far(near, far, linspace01(j, S, step));
-  float lower = zj, upper = zj;
-  if (j > 0) lower = 0.5f * (lerp_near_far(near, far, linspace01(j - 1, S, step)) + zj);
-  if (j < S - 1) upper = 0.5f * (zj + lerp_near_far(near, far, linspace01(j + 1, S, step)));
-  const float span = upper - lower;
-  const float jit = span * u[idx];
-  z_out[idx] = lower + jit;
+  z_out[idx] = stratified_z(rays[r * ray_stride + 6], rays[r * ray_stride + 7], j, S, u[idx]);
 }
 
 // ---- sky colour head, one wave per ray: models/satnerf.py:138-143,201 --------------------------------------
@@ -98,52 +48,12 @@ __global__ void __launch_bounds__(256) sky_kernel(const float* __restrict__ sun,
   const int lane = threadIdx.x & 63;
   const long r = (long)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
   if (r >= n) return;
-  const float sx = sun[r * sun_stride], sy = sun[r * sun_stride + 1], sz = sun[r * sun_stride + 2];
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-  for (int k = lane; k < hidden; k += 64) {
-    float hk = __builtin_fmaf(w1[k * 3 + 2], sz, __builtin_fmaf(w1[k * 3 + 1], sy, __builtin_fmaf(w1[k * 3], sx, b1[k])));
-    hk = hk > 0.f ? hk : 0.f;
-    a0 = __builtin_fmaf(w2[k], hk, a0);
-    a1 = __builtin_fmaf(w2[hidden + k], hk, a1);
-    a2 = __builtin_fmaf(w2[2 * hidden + k], hk, a2);
-  }
-  a0 = wave_sum(a0), a1 = wave_sum(a1), a2 = wave_sum(a2);
-  if (lane == 0) {
-    sky[r * 3 + 0] = sigmoid_f(a0 + b2[0]);
-    sky[r * 3 + 1] = sigmoid_f(a1 + b2[1]);
-    sky[r * 3 + 2] = sigmoid_f(a2 + b2[2]);
-  }
+  float k0, k1, k2;
+  sky_ray(sun[r * sun_stride], sun[r * sun_stride + 1], sun[r * sun_stride + 2], hidden, w1, b1, w2, b2, lane, k0, k1, k2);
+  if (lane == 0) sky[r * 3 + 0] = k0, sky[r * 3 + 1] = k1, sky[r * 3 + 2] = k2;
 }
 
 // ---- sampling + sky head in one launch (training fast path), one wave per ray ---------------------------------------------------
-// Philox-4x32-10 (Salmon et al., SC'11): counter-based, so a captured launch draws fresh jitter on every replay from a
-// device-side step counter -- no RNG kernel, no generator-state bookkeeping in the graph.
-__device__ __forceinline__ void philox4x32(uint32_t k0, uint32_t k1, uint32_t c[4]) {
-#pragma unroll
-  for (int round = 0; round < 10; ++round) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    c[0] = n0, c[1] = (uint32_t)p1, c[2] = n2, c[3] = (uint32_t)p0;
-    k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
-  }
-}
-
-// A launch that draws from the device-side step counter can also advance it (forward graphs have no sr_pack_all to do so): every
-// workgroup reads counter[0] first, then checks in at the arrival counter kept in counter[3] (uint32 bits); the LAST one to
-// check in -- every other workgroup has read by then -- stores step + 1 and resets the arrival counter for the next launch.
-__device__ __forceinline__ void tick_when_all_read(float* counter, uint32_t step_read) {
-  asm volatile("" ::"v"(step_read));  // the value has arrived
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned* arrive = reinterpret_cast<unsigned*>(counter + 3);
-    __threadfence();
-    if (atomicAdd(arrive, 1u) == gridDim.x - 1) {
-      counter[0] = (float)(step_read + 1u);
-      atomicExch(arrive, 0u);
-    }
-  }
-}
-
 __global__ void __launch_bounds__(256) ray_setup_kernel(const float* __restrict__ rays, int ray_stride, const float* __restrict__ u, long n_rays,
                                                        int S, int hidden, const float* __restrict__ w1, const float* __restrict__ b1,
                                                        const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ z_out,
@@ -154,58 +64,15 @@ __global__ void __launch_bounds__(256) ray_setup_kernel(const float* __restrict_
   if (tick) tick_when_all_read(step_counter, rng_step);
   if (r >= n_rays) return;
   const float* ray = rays + r * ray_stride;
-  {
-#pragma clang fp contract(off)
-    const float near = ray[6], far = ray[7];
-    const float step = 1.0f / (float)(S - 1);
-    for (int j = lane; j < S; j += 64) {
-      const float zj = lerp_near_far(near, far, linspace01(j, S, step));
-      float lower = zj, upper = zj;
-      if (j > 0) lower = 0.5f * (lerp_near_far(near, far, linspace01(j - 1, S, step)) + zj);
-      if (j < S - 1) upper = 0.5f * (zj + lerp_near_far(near, far, linspace01(j + 1, S, step)));
-      const float span = upper - lower;
-      float uj;
-      if (u) {
-        uj = u[r * S + j];
-      } else {  // uniform in [0,1) with 24 random bits: counter = (ray, sample / 4, step), key = seed
-        uint32_t c[4] = {static_cast<uint32_t>(r), static_cast<uint32_t>(static_cast<unsigned long long>(r) >> 32), static_cast<uint32_t>(j >> 2), rng_step};
-        philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), c);
-        uj = (float)(c[j & 3] >> 8) * 5.9604644775390625e-8f;
-      }
-      const float jit = span * uj;
-      z_out[r * S + j] = lower + jit;
-    }
-  }
-  const float sx = ray[8], sy = ray[9], sz = ray[10];
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-  for (int k = lane; k < hidden; k += 64) {
-    float hk = __builtin_fmaf(w1[k * 3 + 2], sz, __builtin_fmaf(w1[k * 3 + 1], sy, __builtin_fmaf(w1[k * 3], sx, b1[k])));
-    hk = hk > 0.f ? hk : 0.f;
-    a0 = __builtin_fmaf(w2[k], hk, a0);
-    a1 = __builtin_fmaf(w2[hidden + k], hk, a1);
-    a2 = __builtin_fmaf(w2[2 * hidden + k], hk, a2);
-  }
-  a0 = wave_sum(a0), a1 = wave_sum(a1), a2 = wave_sum(a2);
-  if (lane == 0) {
-    sky[r * 3 + 0] = sigmoid_f(a0 + b2[0]);
-    sky[r * 3 + 1] = sigmoid_f(a1 + b2[1]);
-    sky[r * 3 + 2] = sigmoid_f(a2 + b2[2]);
-  }
+  const float near = ray[6], far = ray[7];
+  for (int j = lane; j < S; j += 64)
+    z_out[r * S + j] = stratified_z(near, far, j, S, u ? u[r * S + j] : philox_uniform(seed, r, j, rng_step));
+  float k0, k1, k2;
+  sky_ray(ray[8], ray[9], ray[10], hidden, w1, b1, w2, b2, lane, k0, k1, k2);
+  if (lane == 0) sky[r * 3 + 0] = k0, sky[r * 3 + 1] = k1, sky[r * 3 + 2] = k2;
 }
 
 // ---- compositing: models/satnerf.py:52-70 --------------------------------------------------------------------
-// One wave per ray; samples are processed in segments of 64 (lane = sample) with a running transmittance carry.
-__device__ __forceinline__ void alpha_of(const float* z, const float* sigma, const float* noise, float noise_std, long base,
-                                         int j, int S, float& delta, float& dens, float& alpha) {
-#pragma clang fp contract(off)
-  delta = (j < S - 1) ? (z[base + j + 1] - z[base + j]) : 1e10f;
-  float s = sigma[base + j];
-  if (noise) s = s + noise[base + j] * noise_std;
-  dens = s;
-  const float rl = s > 0.f ? s : 0.f;
-  alpha = 1.0f - expf(-delta * rl);
-}
-
 __global__ void __launch_bounds__(256) composite_fwd_kernel(const float* __restrict__ z, const float* __restrict__ sigma,
                                                            const float* __restrict__ noise, float noise_std,
                                                            const float* __restrict__ albedo, const float* __restrict__ sun_v,
@@ -218,46 +85,9 @@ __global__ void __launch_bounds__(256) composite_fwd_kernel(const float* __restr
   const long base = r * S;
   float k0 = 1.f, k1 = 1.f, k2 = 1.f;
   if (sky) k0 = sky[r * 3], k1 = sky[r * 3 + 1], k2 = sky[r * 3 + 2];
-  float carry = 1.f, dsum = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
-  for (int j0 = 0; j0 < S; j0 += 64) {
-    const int j = j0 + lane;
-    const bool on = j < S;
-    float delta, dens, alpha = 0.f;
-    if (on) alpha_of(z, sigma, noise, noise_std, base, j, S, delta, dens, alpha);
-    float f;
-    {
-#pragma clang fp contract(off)
-      f = on ? (1.0f - alpha) + 1e-10f : 1.f;
-    }
-    const float incl = wave_scan_mul(f, lane);
-    float excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 1.f;
-    const float T = carry * excl;
-    carry = carry * __shfl(incl, 63, 64);
-    if (on) {
-      const float w = alpha * T;
-      weights[base + j] = w;
-      transp[base + j] = T;
-      dsum += w * z[base + j];
-      if (albedo) {
-        const float* a = albedo + (base + j) * 3;
-        float i0 = 1.f, i1 = 1.f, i2 = 1.f;
-        if (sun_v) {
-          const float sv = sun_v[base + j];
-          i0 = sv + (1.f - sv) * k0, i1 = sv + (1.f - sv) * k1, i2 = sv + (1.f - sv) * k2;  // :68
-        }
-        c0 += w * a[0] * i0, c1 += w * a[1] * i1, c2 += w * a[2] * i2;
-      }
-    }
-  }
-  dsum = wave_sum(dsum), c0 = wave_sum(c0), c1 = wave_sum(c1), c2 = wave_sum(c2);
-  if (lane == 0) {
-    if (depth) depth[r] = dsum;
-    if (rgb) {
-      if (clamp_rgb) c0 = fminf(fmaxf(c0, 0.f), 1.f), c1 = fminf(fmaxf(c1, 0.f), 1.f), c2 = fminf(fmaxf(c2, 0.f), 1.f);
-      rgb[r * 3] = c0, rgb[r * 3 + 1] = c1, rgb[r * 3 + 2] = c2;
-    }
-  }
+  composite_ray(z + base, sigma + base, noise ? noise + base : nullptr, noise_std, albedo ? albedo + base * 3 : nullptr,
+                sun_v ? sun_v + base : nullptr, k0, k1, k2, S, lane, clamp_rgb, weights + base, transp + base, depth ? depth + r : nullptr,
+                rgb ? rgb + r * 3 : nullptr);
 }
 
 // Whole-image evaluation: the same compositing, keeping per ray only what

@@ -147,6 +147,42 @@ def satnerf_mlp(org, direction, sun, z, temb, ts, n_points, n_samples, feat, tau
     return albedo, sigma, sun_v, beta
 
 
+def render_fused_ok(feat, mode, n_samples):
+    """True when sr_satnerf_render_fwd covers (feat, mode) and ``n_samples`` divides the points a workgroup owns."""
+    per_block = _lib.lib().sr_render_points_per_block(int(feat), MODES[mode])
+    return per_block > 0 and n_samples >= 2 and per_block % n_samples == 0
+
+
+def render_fwd(rays, ts, temb, n_samples, feat, tau, mode, stream_hi, stream_lo, l0, sky_w1, sky_b1, sky_w2, sky_b2, z=None, u=None, noise=None,
+               noise_std=0.0, seed=0, step_counter=None, tick=False, want_z=True):
+    """One launch: stratified sampling (or given depths ``z``) -> fused MLP -> sky head + compositing (sr_satnerf_render_fwd).
+    Depths: ``z`` (N,S) given, else stratified with ``u`` (N,S), else jitter drawn in the kernel (``seed``, ``step_counter``, ``tick``).
+    Returns dict(z, albedo (N,S,3), sun_v (N,S), beta (N,S), sky (N,3), weights, transparency (N,S), depth (N), rgb (N,3))."""
+    rays, stride = _rows(rays, "rays", 11)
+    n, s, dev = rays.shape[0], int(n_samples), rays.device
+    _chk(ts, "ts", torch.int64), _chk(temb, "temb")
+    for t, nm in ((z, "z"), (u, "u"), (noise, "noise")):
+        if t is not None and tuple(_chk(t, nm).shape) != (n, s):
+            raise ValueError(f"{nm} must be ({n},{s}), got {tuple(t.shape)}")
+    if tick and (step_counter is None or step_counter.numel() < 4):
+        raise ValueError("tick=True needs step_counter = a zero-initialised float32 block of 4")
+    e = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+    out = {"z": z if z is not None else (e(n, s) if want_z else None), "albedo": e(n, s, 3), "sun_v": e(n, s), "beta": e(n, s), "sky": e(n, 3),
+           "weights": e(n, s), "transparency": e(n, s), "depth": e(n), "rgb": e(n, 3)}
+    args = _lib.RenderArgs(_p(rays), stride, _p(ts), _p(temb), n, s, _p(z), _p(u), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                           _p(_chk(step_counter, "step_counter", allow_none=True)), int(bool(tick)), _p(noise), float(noise_std), sky_w1.shape[0],
+                           _p(_chk(sky_w1, "w1")), _p(_chk(sky_b1, "b1")), _p(_chk(sky_w2, "w2")), _p(_chk(sky_b2, "b2")))
+    outs = _lib.RenderOutputs(_p(out["z"]) if z is None else None, _p(out["albedo"]), None, _p(out["sun_v"]), _p(out["beta"]), _p(out["sky"]),
+                              _p(out["weights"]), _p(out["transparency"]), _p(out["depth"]), _p(out["rgb"]))
+    ev = kernel_timer.span("mlp_fwd") if kernel_timer is not None else None
+    if ev:
+        ev[0].record()
+    _lib.call("sr_satnerf_render_fwd", C.byref(args), feat, tau, MODES[mode], _p(stream_hi), _p(stream_lo), _p(_chk(l0, "l0")), C.byref(outs), _stream())
+    if ev:
+        ev[1].record()
+    return out
+
+
 def composite(z, sigma, noise, noise_std, albedo, sun_v, sky_rgb, clamp_rgb=True):
     n, s = z.shape
     dev = z.device

@@ -74,6 +74,19 @@ class _KernelRng(_TorchRng):
 
 
 _rng = _TorchRng()
+_FUSED_RENDER = os.environ.get("SATNERF_FUSED_RENDER", "1") != "0"
+
+
+@contextlib.contextmanager
+def fused_render(enabled):
+    """Switch the one-launch render pass (sr_satnerf_render_fwd) on / off; off = sampling, MLP and compositing as separate
+    launches (the same arithmetic bit for bit -- tests compare the two)."""
+    global _FUSED_RENDER
+    prev, _FUSED_RENDER = _FUSED_RENDER, bool(enabled)
+    try:
+        yield
+    finally:
+        _FUSED_RENDER = prev
 
 
 @contextlib.contextmanager
@@ -191,36 +204,69 @@ def render_rays(models, args, rays, ts, _ts_validated=False):
     emb = emb.contiguous().float()
 
     coarse = models["coarse"]
-    sky_of = {}
-    if hasattr(coarse, "fused_forward") and coarse.fused_forward(_mode_of(args)):  # stratified depths (rendering.py:62-78, perturb = 1) + the coarse sky head in one launch
-        sk = coarse.sky_color
-        if isinstance(_rng, _KernelRng):
-            z, sky_of["coarse"] = ops.ray_setup(rays, None, n_samples, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data,
-                                                seed=_rng.seed, step_counter=_rng.counter, tick=True)
-        else:
-            z, sky_of["coarse"] = ops.ray_setup(rays, _rng.rand(n, n_samples, dev), n_samples, sk[0].weight.data, sk[0].bias.data,
-                                                sk[2].weight.data, sk[2].bias.data)
-    else:
-        z = ops.ray_sample(rays, _rng.rand(n, n_samples, dev), n_samples)
+    mode = _mode_of(args)
+    kernel = isinstance(_rng, _KernelRng)
+    skip_noise = kernel and args.noise_std == 0
+    use_noise = args.noise_std != 0
     result = {}
 
-    skip_noise = isinstance(_rng, _KernelRng) and args.noise_std == 0
+    def fused_ok(model, s):
+        return _FUSED_RENDER and hasattr(model, "fused_forward") and model.fused_forward(mode) and ops.render_fused_ok(model.feat, mode, s)
 
-    def run(typ, z_cur):
+    def sc_pass(typ, z_cur, res):  # solar correction: same depths along the sun direction (rendering.py:102-108)
+        noise_sc = None if skip_noise else _rng.randn(n, z_cur.shape[1], dev)
+        sc = _inference(models[typ], args, rays, z_cur, ts, emb, (8, 11), noise_sc)
+        res["weights_sc"], res["transparency_sc"], res["sun_sc"] = sc["weights"], sc["transparency"], sc["sun"]
+
+    def run_fused(typ, z_cur, u_cur):
+        """sampling (coarse) / given depths (fine) -> MLP -> sky head + compositing in ONE launch (sr_satnerf_render_fwd)."""
+        model = models[typ]
+        s = n_samples if z_cur is None else z_cur.shape[1]
+        noise = None if skip_noise else _rng.randn(n, s, dev)  # models/satnerf.py:58 -- always drawn
+        hi, lo, l0 = model.packed(mode)
+        sk = model.sky_color
+        need_z = n_importance > 0 or args.sc_lambda > 0
+        draw = z_cur is None and u_cur is None
+        o = ops.render_fwd(rays, ts, emb, s, model.feat, model.t_embedding_dims, mode, hi, lo, l0, sk[0].weight.data, sk[0].bias.data,
+                           sk[2].weight.data, sk[2].bias.data, z=z_cur, u=u_cur, noise=noise if use_noise else None, noise_std=args.noise_std,
+                           seed=_rng.seed if draw else 0, step_counter=_rng.counter if draw else None, tick=draw, want_z=need_z)
+        res = {"rgb": o["rgb"], "depth": o["depth"], "weights": o["weights"], "transparency": o["transparency"], "albedo": o["albedo"],
+               "sun": o["sun_v"].unsqueeze(-1), "sky": o["sky"].unsqueeze(1).expand(n, s, 3), "beta": o["beta"].unsqueeze(-1)}
+        if args.sc_lambda > 0:
+            sc_pass(typ, o["z"], res)
+        for k, v in res.items():
+            result[f"{k}_{typ}"] = v
+        return o["z"]
+
+    def run(typ, z_cur, sky=None):
         noise = None if skip_noise else _rng.randn(n, z_cur.shape[1], dev)  # models/satnerf.py:58 -- always drawn
-        res = _inference(models[typ], args, rays, z_cur, ts, emb, (3, 6), noise, sky_of.get(typ))
-        if args.sc_lambda > 0:  # solar correction: same depths along the sun direction (rendering.py:102-108)
-            noise_sc = None if skip_noise else _rng.randn(n, z_cur.shape[1], dev)
-            sc = _inference(models[typ], args, rays, z_cur, ts, emb, (8, 11), noise_sc)
-            res["weights_sc"], res["transparency_sc"], res["sun_sc"] = sc["weights"], sc["transparency"], sc["sun"]
+        res = _inference(models[typ], args, rays, z_cur, ts, emb, (3, 6), noise, sky)
+        if args.sc_lambda > 0:
+            sc_pass(typ, z_cur, res)
         for k, v in res.items():
             result[f"{k}_{typ}"] = v
 
-    run("coarse", z)
+    if fused_ok(coarse, n_samples):
+        z = run_fused("coarse", None, None if kernel else _rng.rand(n, n_samples, dev))
+    elif hasattr(coarse, "fused_forward") and coarse.fused_forward(mode):  # stratified depths (rendering.py:62-78, perturb = 1) + the coarse sky head in one launch
+        sk = coarse.sky_color
+        if kernel:
+            z, sky = ops.ray_setup(rays, None, n_samples, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data,
+                                   seed=_rng.seed, step_counter=_rng.counter, tick=True)
+        else:
+            z, sky = ops.ray_setup(rays, _rng.rand(n, n_samples, dev), n_samples, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data,
+                                   sk[2].bias.data)
+        run("coarse", z, sky)
+    else:
+        z = ops.ray_sample(rays, _rng.rand(n, n_samples, dev), n_samples)
+        run("coarse", z)
     if n_importance > 0:  # rendering.py:118-156
         u = _rng.rand(n, n_importance, dev)
         z_fine = ops.sample_pdf_merge(z, result["weights_coarse"], u)
-        run("fine", z_fine)
+        if fused_ok(models["fine"], z_fine.shape[1]):
+            run_fused("fine", z_fine, None)
+        else:
+            run("fine", z_fine)
     return result
 
 

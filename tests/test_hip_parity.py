@@ -463,6 +463,38 @@ def test_graphed_renderer_kernel_rng_draws_fresh_uniform_jitter_and_matches_orac
         assert maxnorm_rel(got[k].cpu(), want[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize("mode,feat,s,n_imp,sc,noise", [("bf16x3", 256, 64, 0, 0.0, 0.0), ("bf16", 256, 64, 64, 0.0, 0.3), ("bf16", 256, 128, 0, 0.1, 0.0),
+                                                        ("bf16x3", 256, 32, 32, 0.0, 0.0), ("bf16", 512, 64, 0, 0.0, 0.0), ("bf16", 256, 16, 0, 0.0, 0.0)])
+def test_one_launch_render_is_bit_identical_to_the_three_launches(mode, feat, s, n_imp, sc, noise):
+    """sr_satnerf_render_fwd (sampling -> MLP -> sky head + compositing in ONE launch, per-point values handed over in LDS)
+    against sr_ray_setup -> sr_satnerf_mlp_fwd -> sr_composite_fwd on the same draws: every result tensor identical, ragged ray
+    counts (the last workgroup is partly empty), coarse + fine, solar correction, noise."""
+    _, rendering, _ = _lazy()
+    from satnerf_amd import ops
+
+    tau = 16 if feat == 512 else 4
+    args = O.default_args(mlp_mode=mode, fc_units=feat, t_embbeding_tau=tau, n_samples=s, n_importance=n_imp, sc_lambda=sc, noise_std=noise)
+    models = build_models(args)
+    assert ops.render_fused_ok(feat, mode, s)
+    for n in (1, 37, 300):
+        rays, ts = O.synthetic_rays(n, seed=80 + n)
+        rays, ts = rays.to(DEV), ts.to(DEV)
+        g = torch.Generator().manual_seed(5)
+        draws = [torch.rand(n, s, generator=g), torch.randn(n, s, generator=g)] + ([torch.randn(n, s, generator=g)] if sc > 0 else [])
+        if n_imp > 0:
+            draws += [torch.rand(n, n_imp, generator=g), torch.randn(n, s + n_imp, generator=g)] + ([torch.randn(n, s + n_imp, generator=g)] if sc > 0 else [])
+        draws = [d.to(DEV) for d in draws]
+        with torch.no_grad(), rendering.replay_rng(draws), rendering.fused_render(True):
+            one = rendering.render_rays(models, args, rays, ts)
+        with torch.no_grad(), rendering.replay_rng(draws), rendering.fused_render(False):
+            three = rendering.render_rays(models, args, rays, ts)
+        assert set(one) == set(three)
+        for k in one:
+            assert one[k].shape == three[k].shape, k
+            assert torch.equal(one[k], three[k]), (k, n, float((one[k] - three[k]).abs().max()))
+    assert not ops.render_fused_ok(feat, mode, 50) and not ops.render_fused_ok(384, mode, 64)
+
+
 def test_public_inference_signature_matches_render_rays():
     """rendering.inference(model, args, rays_xyz, z_vals, rays_d, sun_d, rays_t) -- the reference's models.satnerf.inference
     signature with explicit points and embedding vectors -- agrees with the fused ray path on the same depths and noise."""
