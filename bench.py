@@ -145,13 +145,15 @@ def measure(phase, mode, n_rays, n_samples, steps, warmup, world, rank, dev, wan
         def step():
             stepper.step_from_bank(bank)
     else:
-        # stratified jitter drawn inside the sampling kernel (Philox, per-rank seed), as the captured training step does
-        graphed = rendering.GraphedRenderer(models, args, n_rays, dev, kernel_rng=True, seed=1234 + rank)
+        # one kernel per step: the render kernel walks this rank's share of the HBM-resident bank chunk by chunk (as
+        # eval_satnerf.batched_inference walks an image) and draws the stratified jitter itself (Philox, per-rank seed)
+        share = slice(rank, None, world)
+        graphed = rendering.GraphedRenderer(models, args, n_rays, dev, seed=1234 + rank, bank=(bank.rays[share], bank.ts[share]))
         use_graph = [True]
 
         def step():
             if use_graph[0]:
-                graphed.render_next(bank)  # batch gathered straight into the graph's static inputs
+                graphed.replay()  # the next n_rays rows of the bank
             else:
                 rays_b, ts_b, _ = bank.next_batch()
                 with torch.no_grad():
@@ -246,7 +248,8 @@ def main():
         "data": "synthetic", "phase": phase, "prewarm_steps": PREWARM,
         "config": {"workload": f"BASELINE configs[1]: sat-nerf fc_units=256 tau=4, {a.rays} rays x {a.samples} samples per GPU, "
                                f"noise_std=0 sc_lambda=0 n_importance=0, mlp_mode={a.mode}"
-                               + (f", saved state {fmt}-bit" if fmt else "") + ", stratified jitter drawn in-kernel (Philox-4x32-10)",
+                               + (f", saved state {fmt}-bit" if fmt else "") + ", stratified jitter drawn in-kernel (Philox-4x32-10)"
+                               + (", rays = consecutive chunks of the HBM-resident bank (one kernel per step)" if phase == "forward" else ""),
                    "rays_per_gpu": a.rays,
                    "n_samples": a.samples, "parallelism": f"dp{world}"},
         "roofline": roof,

@@ -115,6 +115,9 @@ int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, int mode, con
  * depths: z_in (N,S) given (the fine pass), else stratified with jitter u (N,S), else (both NULL) with jitter drawn in the kernel:
  *   Philox keyed by `seed`, stepping with step_counter[0]; tick != 0: the launch advances that counter (see sr_ray_setup_rng).
  * noise (N,S) or NULL with noise_std; sky_*: the sky head's weights (hidden, 3), (hidden), (3, hidden), (3).
+ * bank_chunks > 0: `rays` / `ts` are a resident bank of bank_chunks x N rows and the launch renders chunk
+ *   (step_counter[0] mod bank_chunks) of it -- with tick, a captured launch walks the bank chunk by chunk, replay after
+ *   replay, as eval_satnerf.py:46-66 walks an image, with no host work and no gather in between (outputs: the chunk's N rays).
  * outputs: z_out (N,S) [NULL ok], albedo (N,S,3), sun_v (N,S), beta (N,S), sigma (N,S) [NULL ok], sky (N,3), weights (N,S),
  *   transparency (N,S), depth (N), rgb (N,3) clamped to [0,1]. */
 typedef struct sr_render_args {
@@ -136,6 +139,7 @@ typedef struct sr_render_args {
   const float* sky_b1;
   const float* sky_w2;
   const float* sky_b2;
+  int64_t bank_chunks;
 } sr_render_args;
 
 typedef struct sr_render_outputs {

@@ -26,7 +26,7 @@ class MlpInputs(C.Structure):
 class RenderArgs(C.Structure):
     _fields_ = [("rays", _vp), ("ray_stride", _i), ("ts", _vp), ("temb", _vp), ("n_rays", _i64), ("n_samples", _i), ("z_in", _vp), ("u", _vp),
                 ("seed", C.c_uint64), ("step_counter", _vp), ("tick", _i), ("noise", _vp), ("noise_std", _f), ("sky_hidden", _i),
-                ("sky_w1", _vp), ("sky_b1", _vp), ("sky_w2", _vp), ("sky_b2", _vp)]
+                ("sky_w1", _vp), ("sky_b1", _vp), ("sky_w2", _vp), ("sky_b2", _vp), ("bank_chunks", _i64)]
 
 
 class RenderOutputs(C.Structure):

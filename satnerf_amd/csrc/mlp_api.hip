@@ -71,6 +71,7 @@ extern "C" int sr_satnerf_render_fwd(const sr_render_args* in, int feat, int tau
   SR_REQUIRE(in->sky_w1 && in->sky_b1 && in->sky_w2 && in->sky_b2 && in->sky_hidden >= 1, "sr_satnerf_render_fwd: the sky head's weights are required");
   SR_REQUIRE(out->weights && out->transparency, "sr_satnerf_render_fwd: weights and transparency outputs are required");
   SR_REQUIRE(!in->tick || in->step_counter, "sr_satnerf_render_fwd: tick needs the 4-float step counter block");
+  SR_REQUIRE(in->bank_chunks >= 0 && (in->bank_chunks == 0 || in->step_counter), "sr_satnerf_render_fwd: bank_chunks needs the step counter");
   if (in->n_rays <= 0) return 0;
   FwdParams p;
   p.in.org = in->rays, p.in.org_stride = in->ray_stride;
@@ -83,7 +84,7 @@ extern "C" int sr_satnerf_render_fwd(const sr_render_args* in, int feat, int tau
   r.tick = in->tick, r.noise = in->noise, r.noise_std = in->noise_std, r.sky_hidden = in->sky_hidden;
   r.w1 = in->sky_w1, r.b1 = in->sky_b1, r.w2 = in->sky_w2, r.b2 = in->sky_b2;
   r.z_out = out->z_vals, r.sky = out->sky, r.weights = out->weights, r.transp = out->transparency, r.depth = out->depth, r.rgb = out->rgb;
-  r.n_rays = in->n_rays;
+  r.n_rays = in->n_rays, r.bank_chunks = in->bank_chunks;
   p.stream_hi = (const char*)stream_hi, p.stream_lo = (const char*)stream_lo, p.l0 = (const float4*)l0;
   p.albedo = out->albedo, p.sigma = out->sigma, p.sun_v = out->sun_v, p.beta = out->beta;
   p.acts = nullptr, p.tau = tau;

@@ -26,6 +26,7 @@ struct RenderParams {
   float* depth;            // (N)
   float* rgb;              // (N,3)
   long n_rays;
+  long bank_chunks;        // > 0: rays / ts hold bank_chunks x n_rays rows, this launch renders chunk step_counter[0] % bank_chunks
 };
 
 struct FwdParams {

@@ -154,12 +154,17 @@ def render_fused_ok(feat, mode, n_samples):
 
 
 def render_fwd(rays, ts, temb, n_samples, feat, tau, mode, stream_hi, stream_lo, l0, sky_w1, sky_b1, sky_w2, sky_b2, z=None, u=None, noise=None,
-               noise_std=0.0, seed=0, step_counter=None, tick=False, want_z=True):
+               noise_std=0.0, seed=0, step_counter=None, tick=False, want_z=True, bank_chunks=0):
     """One launch: stratified sampling (or given depths ``z``) -> fused MLP -> sky head + compositing (sr_satnerf_render_fwd).
     Depths: ``z`` (N,S) given, else stratified with ``u`` (N,S), else jitter drawn in the kernel (``seed``, ``step_counter``, ``tick``).
+    ``bank_chunks`` > 0: ``rays`` / ``ts`` are a bank of bank_chunks x N rows and the launch renders chunk step_counter[0] % bank_chunks.
     Returns dict(z, albedo (N,S,3), sun_v (N,S), beta (N,S), sky (N,3), weights, transparency (N,S), depth (N), rgb (N,3))."""
     rays, stride = _rows(rays, "rays", 11)
     n, s, dev = rays.shape[0], int(n_samples), rays.device
+    if bank_chunks:
+        if rays.shape[0] % bank_chunks or ts.numel() != rays.shape[0] or step_counter is None:
+            raise ValueError("bank mode: rays / ts must hold bank_chunks x N rows and step_counter is required")
+        n = rays.shape[0] // bank_chunks
     _chk(ts, "ts", torch.int64), _chk(temb, "temb")
     for t, nm in ((z, "z"), (u, "u"), (noise, "noise")):
         if t is not None and tuple(_chk(t, nm).shape) != (n, s):
@@ -171,7 +176,7 @@ def render_fwd(rays, ts, temb, n_samples, feat, tau, mode, stream_hi, stream_lo,
            "weights": e(n, s), "transparency": e(n, s), "depth": e(n), "rgb": e(n, 3)}
     args = _lib.RenderArgs(_p(rays), stride, _p(ts), _p(temb), n, s, _p(z), _p(u), int(seed) & 0xFFFFFFFFFFFFFFFF,
                            _p(_chk(step_counter, "step_counter", allow_none=True)), int(bool(tick)), _p(noise), float(noise_std), sky_w1.shape[0],
-                           _p(_chk(sky_w1, "w1")), _p(_chk(sky_b1, "b1")), _p(_chk(sky_w2, "w2")), _p(_chk(sky_b2, "b2")))
+                           _p(_chk(sky_w1, "w1")), _p(_chk(sky_b1, "b1")), _p(_chk(sky_w2, "w2")), _p(_chk(sky_b2, "b2")), int(bank_chunks))
     outs = _lib.RenderOutputs(_p(out["z"]) if z is None else None, _p(out["albedo"]), None, _p(out["sun_v"]), _p(out["beta"]), _p(out["sky"]),
                               _p(out["weights"]), _p(out["transparency"]), _p(out["depth"]), _p(out["rgb"]))
     ev = kernel_timer.span("mlp_fwd") if kernel_timer is not None else None

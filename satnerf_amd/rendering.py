@@ -69,8 +69,8 @@ class _KernelRng(_TorchRng):
     bookkeeping torch adds to a graph.  The ``randn`` of models/satnerf.py:58 is skipped while ``noise_std == 0`` (it is
     multiplied by zero there); every other draw still comes from torch."""
 
-    def __init__(self, seed, counter):
-        self.seed, self.counter = int(seed), counter
+    def __init__(self, seed, counter, bank_chunks=0):
+        self.seed, self.counter, self.bank_chunks = int(seed), counter, int(bank_chunks)
 
 
 _rng = _TorchRng()
@@ -90,10 +90,12 @@ def fused_render(enabled):
 
 
 @contextlib.contextmanager
-def kernel_rng(seed, counter):
-    """Draw ``render_rays``' stratified jitter inside the kernel (see ``_KernelRng``); ``counter`` = zeros(4) float32 on the GPU."""
+def kernel_rng(seed, counter, bank_chunks=0):
+    """Draw ``render_rays``' stratified jitter inside the kernel (see ``_KernelRng``); ``counter`` = zeros(4) float32 on the GPU.
+    ``bank_chunks`` > 0: the rays / ts passed to ``render_rays`` are a bank of that many equal chunks and each call renders the
+    chunk the device counter points at (``GraphedRenderer(bank=...)``)."""
     global _rng
-    prev, _rng = _rng, _KernelRng(seed, counter)
+    prev, _rng = _rng, _KernelRng(seed, counter, bank_chunks)
     try:
         yield _rng
     finally:
@@ -229,7 +231,8 @@ def render_rays(models, args, rays, ts, _ts_validated=False):
         draw = z_cur is None and u_cur is None
         o = ops.render_fwd(rays, ts, emb, s, model.feat, model.t_embedding_dims, mode, hi, lo, l0, sk[0].weight.data, sk[0].bias.data,
                            sk[2].weight.data, sk[2].bias.data, z=z_cur, u=u_cur, noise=noise if use_noise else None, noise_std=args.noise_std,
-                           seed=_rng.seed if draw else 0, step_counter=_rng.counter if draw else None, tick=draw, want_z=need_z)
+                           seed=_rng.seed if draw else 0, step_counter=_rng.counter if draw else None, tick=draw, want_z=need_z,
+                           bank_chunks=chunks)
         res = {"rgb": o["rgb"], "depth": o["depth"], "weights": o["weights"], "transparency": o["transparency"], "albedo": o["albedo"],
                "sun": o["sun_v"].unsqueeze(-1), "sky": o["sky"].unsqueeze(1).expand(n, s, 3), "beta": o["beta"].unsqueeze(-1)}
         if args.sc_lambda > 0:
@@ -246,6 +249,11 @@ def render_rays(models, args, rays, ts, _ts_validated=False):
         for k, v in res.items():
             result[f"{k}_{typ}"] = v
 
+    chunks = _rng.bank_chunks if kernel else 0
+    if chunks:  # rays / ts = a resident bank; the launch picks its chunk from the device counter
+        if not fused_ok(coarse, n_samples) or n_importance > 0 or args.sc_lambda > 0 or use_noise:
+            raise NotImplementedError("bank-walking renders need the one-launch coarse pass (no fine model / solar correction / noise)")
+        n = n // chunks
     if fused_ok(coarse, n_samples):
         z = run_fused("coarse", None, None if kernel else _rng.rand(n, n_samples, dev))
     elif hasattr(coarse, "fused_forward") and coarse.fused_forward(mode):  # stratified depths (rendering.py:62-78, perturb = 1) + the coarse sky head in one launch
@@ -419,9 +427,23 @@ class GraphedRenderer:
     distribution, its own counter-based stream) -- the graph then holds no RNG launches and no generator bookkeeping.
     """
 
-    def __init__(self, models, args, n_rays, device, kernel_rng=False, seed=0):
+    def __init__(self, models, args, n_rays, device, kernel_rng=False, seed=0, bank=None):
         self.models, self.args, self.n = models, args, n_rays
-        self._krng = (int(seed), torch.zeros(4, dtype=torch.float32, device=device)) if kernel_rng else None
+        self._krng = (int(seed), torch.zeros(4, dtype=torch.float32, device=device)) if (kernel_rng or bank is not None) else None
+        self._chunks, self._launches = 0, 0
+        if bank is not None:
+            # ``bank`` = (rays (M,11), ts (M,)) resident on the GPU: every replay renders the NEXT n_rays rows (wrapping around), as
+            # eval_satnerf.batched_inference walks an image chunk by chunk -- the kernel takes its chunk from the device counter,
+            # so a step is one graph replay of one kernel: no gather launch, no host work (sr_render_args.bank_chunks)
+            b_rays, b_ts = bank
+            self._chunks = b_rays.shape[0] // n_rays
+            if self._chunks < 1 or not b_rays.is_cuda:
+                raise ValueError("bank must hold at least n_rays rows on the GPU")
+            self.rays = b_rays[:self._chunks * n_rays].contiguous().float()
+            self.ts = b_ts.reshape(-1)[:self._chunks * n_rays].contiguous().long()
+            validate_ts(self.ts, models)
+            self._rgbs, self.graph, self.out, self._packed_for = None, None, None, {}
+            return
         self.rays = torch.zeros(n_rays, 11, device=device)
         self.ts = torch.zeros(n_rays, dtype=torch.int64, device=device)
         self._rgbs = torch.zeros(n_rays, 3, device=device)  # gather target for a ray bank's colours (unused by rendering)
@@ -440,10 +462,15 @@ class GraphedRenderer:
                 m.repack(mode)
                 self._packed_for[typ] = (m.weights_version(), m.flat_params().data_ptr(), mode)
 
+    @property
+    def last_chunk(self):
+        """Bank mode: index of the chunk the most recent replay rendered (rows last_chunk * n .. + n of the bank)."""
+        return (self._launches - 1) % self._chunks if self._chunks else None
+
     def _run(self):
         if self._krng is not None:
-            with kernel_rng(*self._krng):
-                return render_rays(self.models, self.args, self.rays, self.ts)
+            with kernel_rng(*self._krng, bank_chunks=self._chunks):
+                return render_rays(self.models, self.args, self.rays, self.ts, _ts_validated=bool(self._chunks))
         return render_rays(self.models, self.args, self.rays, self.ts)
 
     @torch.no_grad()
@@ -455,16 +482,20 @@ class GraphedRenderer:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 self._run()  # warm-up outside capture: lazy initialisation (LDS attributes, index maps)
+                self._launches += 1
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.out = self._run()
         self.graph.replay()
+        self._launches += 1
         return self.out
 
     def render_next(self, bank):
         """Gather the bank's next batch straight into the static inputs and render it."""
+        if self._chunks:
+            raise RuntimeError("this renderer walks its own bank: call replay()")
         if bank.batch_size != self.n:
             raise ValueError(f"GraphedRenderer was built for {self.n} rays, the bank serves {bank.batch_size}")
         bank.next_batch(out=(self.rays, self.ts, self._rgbs))
@@ -472,6 +503,8 @@ class GraphedRenderer:
 
     @torch.no_grad()
     def __call__(self, rays, ts):
+        if self._chunks:
+            raise RuntimeError("this renderer walks its own bank: call replay()")
         if rays.shape[0] != self.n:
             raise ValueError(f"GraphedRenderer was built for {self.n} rays, got {rays.shape[0]}")
         self.rays.copy_(rays)

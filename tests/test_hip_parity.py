@@ -495,6 +495,47 @@ def test_one_launch_render_is_bit_identical_to_the_three_launches(mode, feat, s,
     assert not ops.render_fused_ok(feat, mode, 50) and not ops.render_fused_ok(384, mode, 64)
 
 
+def test_bank_walking_renderer_renders_chunk_after_chunk():
+    """GraphedRenderer(bank=...): a replay is ONE kernel that takes its chunk of the resident ray bank from the device counter
+    (sr_render_args.bank_chunks) and advances it.  (i) With explicit jitter the bank launch for chunk k equals the plain launch
+    on rows k*n..(k+1)*n bit for bit; (ii) graph replays walk the chunks in order, wrap around, draw fresh jitter per visit and
+    equal an eager launch with the counter set by hand."""
+    from satnerf_amd import ops, rendering
+
+    args = O.default_args(mlp_mode="bf16x3")
+    models = build_models(args)
+    m = models["coarse"]
+    n, chunks = 96, 3
+    rays, ts = O.synthetic_rays(n * chunks + 17, seed=91)  # 17 rows too many: the tail is not a full chunk and is never visited
+    rays, ts = rays.to(DEV), ts.to(DEV)
+    hi, lo, l0 = m.packed("bf16x3")
+    sk = [m.sky_color[0].weight.data, m.sky_color[0].bias.data, m.sky_color[2].weight.data, m.sky_color[2].bias.data]
+    emb = models["t"].weight.data
+    u = torch.rand(n, 64, device=DEV)
+    for k in (0, 2, 4):
+        ctr = torch.tensor([k, 0, 0, 0], dtype=torch.float32, device=DEV)
+        a = ops.render_fwd(rays[:n * chunks], ts[:n * chunks], emb, 64, 256, 4, "bf16x3", hi, lo, l0, *sk, u=u, step_counter=ctr, bank_chunks=chunks)
+        c = k % chunks
+        b = ops.render_fwd(rays[c * n:(c + 1) * n], ts[c * n:(c + 1) * n], emb, 64, 256, 4, "bf16x3", hi, lo, l0, *sk, u=u)
+        for key in a:
+            assert torch.equal(a[key], b[key]), (key, k)
+        assert int(ctr[0].item()) == k  # no tick asked for
+    gr = rendering.GraphedRenderer(models, args, n, DEV, seed=5, bank=(rays, ts))
+    seen = []
+    for _ in range(5):
+        out = {k: v.clone() for k, v in gr.replay().items()}
+        step = gr._launches - 1
+        assert gr.last_chunk == step % chunks and int(gr._krng[1][0].item()) == step + 1
+        ctr = torch.tensor([step, 0, 0, 0], dtype=torch.float32, device=DEV)
+        want = ops.render_fwd(gr.rays, gr.ts, emb, 64, 256, 4, "bf16x3", hi, lo, l0, *sk, seed=5, step_counter=ctr, bank_chunks=chunks, want_z=False)
+        assert torch.equal(out["rgb_coarse"], want["rgb"]) and torch.equal(out["weights_coarse"], want["weights"])
+        seen.append((gr.last_chunk, out["depth_coarse"]))
+    assert [c for c, _ in seen] == [1, 2, 0, 1, 2]  # (the warm-up launch before the capture took chunk 0)
+    assert not torch.equal(seen[0][1], seen[3][1])  # same chunk, another step: fresh jitter
+    with pytest.raises(RuntimeError):
+        gr(rays[:n], ts[:n])
+
+
 def test_public_inference_signature_matches_render_rays():
     """rendering.inference(model, args, rays_xyz, z_vals, rays_d, sun_d, rays_t) -- the reference's models.satnerf.inference
     signature with explicit points and embedding vectors -- agrees with the fused ray path on the same depths and noise."""
