@@ -300,9 +300,11 @@ int sr_satnerf_loss(const float* rgb, const float* weights, const float* beta, c
                     int n_samples, float beta_min, float grad_scale, const float* sched, float* loss_parts, float* g_rgb,
                     float* g_weights, float* g_beta, void* stream);
 /* batch gather from a GPU-resident ray bank: rows idx[0..n) of rays (.,11), rgbs (.,3), ts (.) -> contiguous batch tensors
- * (replaces DataLoader collate + host-to-device copy, main.py:96-110) */
+ * (replaces DataLoader collate + host-to-device copy, main.py:96-110).  cursor != NULL (a zero-initialised 4-float device
+ * block, [3] scratch): idx holds the shuffled indices of a whole epoch = `batches` x n entries, the launch gathers batch
+ * cursor[0] and advances the cursor modulo `batches` -- inside a captured training step the sampler needs no host work */
 int sr_gather_batch(const float* rays, const float* rgbs, const int64_t* ts, const int64_t* idx, int64_t n, float* out_rays,
-                    float* out_rgbs, int64_t* out_ts, void* stream);
+                    float* out_rgbs, int64_t* out_ts, float* cursor, int64_t batches, void* stream);
 int sr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                  float beta2, float eps, float grad_scale, int64_t step, int zero_grad, void* stream);
 

@@ -84,14 +84,15 @@ __device__ __forceinline__ float philox_uniform(unsigned long long seed, long r,
 // workgroup reads counter[0] first, then checks in at the arrival counter kept in counter[3] (uint32 bits); the LAST one to
 // check in -- every other workgroup has read by then -- stores step + 1 and resets the arrival counter for the next launch.
 // Contains a workgroup barrier: call it from uniform control flow.
-__device__ __forceinline__ void tick_when_all_read(float* counter, uint32_t step_read) {
+// modulo > 0: the counter wraps (a cursor over the batches of an epoch).
+__device__ __forceinline__ void tick_when_all_read(float* counter, uint32_t step_read, uint32_t modulo = 0u) {
   asm volatile("" ::"v"(step_read));  // the value has arrived
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned* arrive = reinterpret_cast<unsigned*>(counter + 3);
     __threadfence();
     if (atomicAdd(arrive, 1u) == gridDim.x - 1) {
-      counter[0] = (float)(step_read + 1u);
+      counter[0] = (float)(modulo != 0u && step_read + 1u >= modulo ? 0u : step_read + 1u);
       atomicExch(arrive, 0u);
     }
   }

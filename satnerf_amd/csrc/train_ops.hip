@@ -3,6 +3,7 @@
 #include <math.h>
 
 #include "common.h"
+#include "ray_device.h"
 
 namespace sr {
 
@@ -189,12 +190,18 @@ __global__ void __launch_bounds__(256) render_loss_kernel(const float* __restric
 __global__ void __launch_bounds__(256) gather_batch_kernel(const float* __restrict__ rays, const float* __restrict__ rgbs,
                                                           const long long* __restrict__ ts, const long long* __restrict__ idx, long n,
                                                           float* __restrict__ out_rays, float* __restrict__ out_rgbs,
-                                                          long long* __restrict__ out_ts) {
+                                                          long long* __restrict__ out_ts, float* __restrict__ cursor, unsigned batches) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const long b = t >> 4;
   const int c = (int)(t & 15);
+  long first = 0;
+  if (cursor) {  // idx holds a whole epoch: this launch takes batch cursor[0] of it and moves the cursor on (captured steps)
+    const uint32_t k = (uint32_t)cursor[0];
+    tick_when_all_read(cursor, k, batches);
+    first = (long)k * n;
+  }
   if (b >= n) return;
-  const long src = idx[b];
+  const long src = idx[first + b];
   if (c < 11) out_rays[b * 11 + c] = rays[src * 11 + c];
   else if (c < 14) out_rgbs[b * 3 + (c - 11)] = rgbs[src * 3 + (c - 11)];
   else if (c == 14) out_ts[b] = ts[src];
@@ -337,11 +344,12 @@ extern "C" int sr_render_loss(const float* z_vals, const float* sigma, const flo
 }
 
 extern "C" int sr_gather_batch(const float* rays, const float* rgbs, const int64_t* ts, const int64_t* idx, int64_t n, float* out_rays,
-                               float* out_rgbs, int64_t* out_ts, void* stream) {
+                               float* out_rgbs, int64_t* out_ts, float* cursor, int64_t batches, void* stream) {
   SR_REQUIRE(rays && rgbs && ts && idx && out_rays && out_rgbs && out_ts, "sr_gather_batch: null pointer");
+  SR_REQUIRE(cursor == nullptr || (batches >= 1 && batches < (1 << 24)), "sr_gather_batch: a cursor needs 1 <= batches < 2^24");
   if (n <= 0) return 0;
   hipLaunchKernelGGL(gather_batch_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rays, rgbs,
-                     (const long long*)ts, (const long long*)idx, (long)n, out_rays, out_rgbs, (long long*)out_ts);
+                     (const long long*)ts, (const long long*)idx, (long)n, out_rays, out_rgbs, (long long*)out_ts, cursor, (unsigned)batches);
   return check_launch("gather_batch_kernel");
 }
 

@@ -41,6 +41,37 @@ class RayBank:
         self._pos += self.batch_size
         return idx
 
+    # ---- in-graph sampler: the captured training step gathers its own batch (no host work between replays) ----------------------
+    def graph_source(self):
+        """(epoch index buffer (batches * B,) int64, cursor zeros(4) float32, batches) for ``ops.gather_batch(..., cursor=...)`` inside a
+        captured step: the launch takes batch cursor[0] of the buffer and advances the cursor; ``graph_advance()`` after every
+        replay keeps the host in step and reshuffles the buffer IN PLACE when an epoch ends.  Needs drop_last (full batches)."""
+        if not self.drop_last:
+            raise ValueError("the in-graph sampler serves full batches only (drop_last=True)")
+        if getattr(self, "_gperm", None) is None:
+            self._gbatches = len(self)
+            if self._gbatches < 1:
+                raise ValueError("the bank holds less than one batch")
+            self._gperm = torch.empty(self._gbatches * self.batch_size, dtype=torch.int64, device=self.rays.device)
+            self._gcursor = torch.zeros(4, dtype=torch.float32, device=self.rays.device)
+            self.graph_reset()
+        return self._gperm, self._gcursor, self._gbatches
+
+    def graph_reset(self):
+        """Start a fresh epoch at batch 0 (also after the capture's warm-up passes moved the cursor)."""
+        self._new_epoch()
+        self._gperm.copy_(self._perm[:self._gperm.numel()])
+        self._gcursor.zero_()
+        self._gpos = 0
+
+    def graph_advance(self):
+        """Host mirror of the device cursor: call once per replay; the next epoch's shuffle is written when the last batch is out."""
+        self._gpos += 1
+        if self._gpos == self._gbatches:
+            self._new_epoch()
+            self._gperm.copy_(self._perm[:self._gperm.numel()])  # stream-ordered after the replay that used the old epoch
+            self._gpos = 0
+
     def gather(self, idx, out=None):
         """Rows ``idx`` -> (rays (B,11), ts (B,), rgbs (B,3)) on the device; ``out`` = three preallocated tensors of exactly that
         size to gather into (e.g. the static inputs of a captured hipGraph -- no intermediate copy)."""

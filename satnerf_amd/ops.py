@@ -530,16 +530,22 @@ def render_loss(z, sigma, noise, noise_std, albedo, sun_v, beta, sky_rgb, target
     return loss, rgb, d_sigma, d_albedo, d_sun, g_beta, d_sky
 
 
-def gather_batch(rays, rgbs, ts, idx, out=None):
-    """Rows ``idx`` of the ray bank -> (rays (B,11), ts (B,), rgbs (B,3)), one launch."""
+def gather_batch(rays, rgbs, ts, idx, out=None, cursor=None, batches=0):
+    """Rows ``idx`` of the ray bank -> (rays (B,11), ts (B,), rgbs (B,3)), one launch.  With ``cursor`` (zeros(4) float32) ``idx``
+    holds a whole epoch of ``batches`` x B indices: the launch takes batch cursor[0] and advances the cursor (captured steps)."""
     n = idx.numel()
+    if cursor is not None:
+        if batches < 1 or n % batches or cursor.numel() < 4:
+            raise ValueError("cursor mode: idx must hold batches x B indices and cursor 4 floats")
+        n //= batches
     if rays.shape[1] != 11 or rgbs.shape[1] != 3:
         raise ValueError("gather_batch expects (N,11) rays and (N,3) rgbs")
     if out is None:
         out = (torch.empty(n, 11, dtype=torch.float32, device=rays.device), torch.empty(n, dtype=torch.int64, device=rays.device),
                torch.empty(n, 3, dtype=torch.float32, device=rays.device))
     _lib.call("sr_gather_batch", _p(_chk(rays, "rays")), _p(_chk(rgbs, "rgbs")), _p(_chk(ts, "ts", torch.int64)), _p(_chk(idx, "idx", torch.int64)), n,
-              _p(_chk(out[0], "out_rays")), _p(_chk(out[2], "out_rgbs")), _p(_chk(out[1], "out_ts", torch.int64)), _stream())
+              _p(_chk(out[0], "out_rays")), _p(_chk(out[2], "out_rgbs")), _p(_chk(out[1], "out_ts", torch.int64)),
+              _p(_chk(cursor, "cursor", allow_none=True)), int(batches), _stream())
     return out
 
 

@@ -181,7 +181,7 @@ class Trainer:
         self.direct = (loss_fn is None and p.is_cuda and args.n_importance == 0 and args.model == "sat-nerf"
                        and hasattr(models["coarse"], "fused_training") and models["coarse"].fused_training(_mode_of(args), _fmt_of(args)))
         self.use_graph = use_graph and self.direct
-        self._graph, self._static = None, None
+        self._graph, self._static, self._graph_banks = None, None, None
         self.last_rgb = None
         self.last_loss = None
 
@@ -326,8 +326,17 @@ class Trainer:
         torch.save({"state_dict": sd, "global_step": self.n_steps, "epoch": self.current_epoch(),
                     "optimizer": {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "lr": self.lr, "step": self.n_steps}}, path)
 
-    def _capture(self, inputs):
+    def _gather_from_banks(self):
+        """(inside the captured step) every bank gathers its next batch into the static inputs and moves its device cursor on"""
+        from . import ops
+
+        for k, b in enumerate(self._graph_banks):
+            idx, cursor, batches = b.graph_source()
+            ops.gather_batch(b.rays, b.rgbs, b.ts, idx, out=self._static[3 * k:3 * k + 3], cursor=cursor, batches=batches)
+
+    def _capture(self, inputs, banks=None):
         self._static = tuple(t.clone() for t in inputs)
+        self._graph_banks = tuple(banks) if banks else None
         # data parallel: by default the gradient all-reduce and Adam are issued eagerly after the replay (works with every backend;
         # ~2 launches + the collective's own latency per step).  SATNERF_GRAPH_ALLREDUCE=1 captures the RCCL all-reduce and the
         # update into the step's graph (NCCL/RCCL collectives are capturable; gloo is not) -- opt-in because it cannot be exercised
@@ -337,7 +346,11 @@ class Trainer:
         self._adam_in_graph = self.world == 1 or capture_collective
         self._kernel_rng = float(self.args.noise_std) == 0.0  # (a noisy step still draws randn from torch's generator)
         snapshot = (self.state.params.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.adam_state.clone())
-        run = lambda: self._forward_backward(*self._static[:3], depth=self._static[3:] or None)  # noqa: E731
+        def run():
+            if self._graph_banks:
+                self._gather_from_banks()
+            return self._forward_backward(*self._static[:3], depth=self._static[3:] or None)
+
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up on a side stream: lazy inits (LDS attributes, maps) happen outside capture
@@ -349,6 +362,8 @@ class Trainer:
         if self._adam_in_graph:  # the warm-up passes stepped the optimizer: roll them back
             self.state.params.copy_(snapshot[0]), self.exp_avg.copy_(snapshot[1]), self.exp_avg_sq.copy_(snapshot[2])
         self.adam_state.copy_(snapshot[3])  # ... and ticked the step counter (the jitter RNG's step) in every configuration
+        for b in self._graph_banks or ():    # ... and moved the banks' cursors
+            b.graph_reset()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._static_loss = run()
@@ -363,6 +378,19 @@ class Trainer:
             if b is not None and not getattr(b, "_ts_validated", False):
                 validate_ts(b.ts, self.models)
                 b._ts_validated = True
+        banks = (bank,) + ((depth_bank,) if depth_bank is not None else ())
+        if (self.direct and self.use_graph and float(self.args.noise_std) == 0.0 and all(b.drop_last for b in banks)
+                and os.environ.get("SATNERF_GRAPH_SAMPLER", "1") != "0"):
+            # the captured step samples for itself: its first launches gather the banks' next batches (device cursors over the
+            # epoch's shuffled indices), so a step is ONE graph replay -- no eager launch, no host-side index arithmetic
+            if self._graph is None or getattr(self, "_graph_banks", None) is None or tuple(map(id, self._graph_banks)) != tuple(map(id, banks)):
+                first = [b.gather(b.graph_source()[0][:b.batch_size]) for b in banks]
+                self._apply_schedule()
+                self._capture(tuple(t for batch in first for t in batch), banks=banks)
+            out = self.step(*self._static[:3], depth=self._static[3:] or None, _inputs_in_place=True)
+            for b in banks:
+                b.graph_advance()
+            return out
         if self.direct and self._graph is not None and tuple(t.shape[0] for t in self._static[::3]) == shapes:
             idx = [bank.next_indices()] + ([depth_bank.next_indices()] if depth_bank is not None else [])
             if all(i.numel() == n for i, n in zip(idx, shapes)):
@@ -392,7 +420,8 @@ class Trainer:
         if self.direct:
             inputs = (rays, ts, rgbs) + (tuple(depth) if depth is not None else ())
             if self.use_graph and float(self.args.noise_std) == 0.0:
-                if self._graph is None or [t.shape for t in self._static] != [t.shape for t in inputs]:
+                stale = getattr(self, "_graph_banks", None) is not None and not _inputs_in_place  # that graph gathers from its banks
+                if self._graph is None or stale or [t.shape for t in self._static] != [t.shape for t in inputs]:
                     self._capture(inputs)
                 if not _inputs_in_place:
                     for dst, src in zip(self._static, inputs):

@@ -301,3 +301,51 @@ def test_step_from_bank_handles_a_short_last_batch():
         sizes.append(tr._static[0].shape[0])
     assert sizes == [128, 128, 44, 128, 128, 44, 128]
     assert torch.isfinite(tr.state.params).all() and tr.n_steps == 7
+
+
+def test_captured_step_samples_its_own_batches_from_the_bank():
+    """Trainer.step_from_bank with a graph: the captured step's first launch gathers batch cursor[0] of the epoch's shuffled index
+    buffer and advances the device cursor (sr_gather_batch cursor mode) -- a step is one graph replay.  The batches the steps
+    trained on are exactly the bank's shuffled epochs, in order, every ray once per epoch, reshuffled between epochs; and the
+    losses equal those of a twin trainer fed the same batches through the eager gather."""
+    from satnerf_amd.data import RayBank
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    n_bank, bs = 5 * 64 + 20, 64  # 5 full batches per epoch, 20 rays dropped per epoch (drop_last)
+    rays, ts = O.synthetic_rays(n_bank, seed=201)
+    rays[:, 6] = torch.arange(n_bank) * 1e-6  # tag every ray (near): tells which rows a step saw
+    rgbs = torch.rand(n_bank, 3, generator=torch.Generator().manual_seed(202))
+
+    def make():
+        torch.manual_seed(0)
+        args = O.default_args(mlp_mode="bf16")
+        models = {"coarse": load_model(args).to(DEV), "t": torch.nn.Embedding(30, 4).to(DEV)}
+        return Trainer(models, args), RayBank(rays.to(DEV), rgbs.to(DEV), ts.to(DEV), bs, seed=9)
+
+    tr, bank = make()
+    seen, losses = [], []
+    for _ in range(12):
+        losses.append(tr.step_from_bank(bank).item())
+        seen.append((tr._static[0][:, 6] * 1e6).round().long().cpu())
+    assert tr._graph is not None and tr._graph_banks == (bank,)
+    epochs = [torch.cat(seen[e * 5:(e + 1) * 5]) for e in range(2)]
+    for e in epochs:
+        assert e.numel() == 5 * bs and e.unique().numel() == 5 * bs  # every ray at most once per epoch
+    assert not torch.equal(epochs[0], epochs[1])                     # reshuffled
+    assert int(bank._gcursor[0].item()) == 12 % 5 and int(bank._gcursor[3].item()) == 0
+    # twin: same seeds, batches through the eager gather of the same index sequence (in-kernel jitter is keyed by the step)
+    tr2, bank2 = make()
+    os.environ["SATNERF_GRAPH_SAMPLER"] = "0"
+    try:
+        bank2._new_epoch()  # (the graph sampler drew one extra shuffle for the capture's first gather + reset)
+        losses2 = []
+        for k in range(12):
+            if k % 5 == 0:
+                bank2._new_epoch()
+            idx = bank2._perm[(k % 5) * bs:(k % 5 + 1) * bs]
+            assert torch.equal((bank2.rays[idx][:, 6] * 1e6).round().long().cpu(), seen[k])
+            losses2.append(tr2.step(*bank2.gather(idx)).item())
+    finally:
+        del os.environ["SATNERF_GRAPH_SAMPLER"]
+    assert max(abs(a - b) for a, b in zip(losses, losses2)) < 1e-5 * max(losses), (losses, losses2)
