@@ -380,9 +380,11 @@ class Trainer:
                 b._ts_validated = True
         banks = (bank,) + ((depth_bank,) if depth_bank is not None else ())
         if (self.direct and self.use_graph and float(self.args.noise_std) == 0.0 and all(b.drop_last for b in banks)
-                and os.environ.get("SATNERF_GRAPH_SAMPLER", "1") != "0"):
-            # the captured step samples for itself: its first launches gather the banks' next batches (device cursors over the
-            # epoch's shuffled indices), so a step is ONE graph replay -- no eager launch, no host-side index arithmetic
+                and os.environ.get("SATNERF_GRAPH_SAMPLER", "0") == "1"):
+            # opt-in: the captured step samples for itself -- its first launches gather the banks' next batches (device cursors over
+            # the epoch's shuffled indices), so a step is ONE graph replay with no eager launch and no host-side index arithmetic.
+            # Off by default: on MI355X it is at best as fast as the eager gather in front of the replay (443-446 us either way,
+            # tools/probe_inflight.py) and on some boxes bench.py measured it 15 % slower (profiles/r02_ab_variants.txt)
             if self._graph is None or getattr(self, "_graph_banks", None) is None or tuple(map(id, self._graph_banks)) != tuple(map(id, banks)):
                 first = [b.gather(b.graph_source()[0][:b.batch_size]) for b in banks]
                 self._apply_schedule()

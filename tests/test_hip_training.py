@@ -325,9 +325,13 @@ def test_captured_step_samples_its_own_batches_from_the_bank():
 
     tr, bank = make()
     seen, losses = [], []
-    for _ in range(12):
-        losses.append(tr.step_from_bank(bank).item())
-        seen.append((tr._static[0][:, 6] * 1e6).round().long().cpu())
+    os.environ["SATNERF_GRAPH_SAMPLER"] = "1"  # opt-in
+    try:
+        for _ in range(12):
+            losses.append(tr.step_from_bank(bank).item())
+            seen.append((tr._static[0][:, 6] * 1e6).round().long().cpu())
+    finally:
+        del os.environ["SATNERF_GRAPH_SAMPLER"]
     assert tr._graph is not None and tr._graph_banks == (bank,)
     epochs = [torch.cat(seen[e * 5:(e + 1) * 5]) for e in range(2)]
     for e in epochs:
@@ -336,16 +340,12 @@ def test_captured_step_samples_its_own_batches_from_the_bank():
     assert int(bank._gcursor[0].item()) == 12 % 5 and int(bank._gcursor[3].item()) == 0
     # twin: same seeds, batches through the eager gather of the same index sequence (in-kernel jitter is keyed by the step)
     tr2, bank2 = make()
-    os.environ["SATNERF_GRAPH_SAMPLER"] = "0"
-    try:
-        bank2._new_epoch()  # (the graph sampler drew one extra shuffle for the capture's first gather + reset)
-        losses2 = []
-        for k in range(12):
-            if k % 5 == 0:
-                bank2._new_epoch()
-            idx = bank2._perm[(k % 5) * bs:(k % 5 + 1) * bs]
-            assert torch.equal((bank2.rays[idx][:, 6] * 1e6).round().long().cpu(), seen[k])
-            losses2.append(tr2.step(*bank2.gather(idx)).item())
-    finally:
-        del os.environ["SATNERF_GRAPH_SAMPLER"]
+    bank2._new_epoch()  # (the graph sampler drew one extra shuffle for the capture's first gather + reset)
+    losses2 = []
+    for k in range(12):
+        if k % 5 == 0:
+            bank2._new_epoch()
+        idx = bank2._perm[(k % 5) * bs:(k % 5 + 1) * bs]
+        assert torch.equal((bank2.rays[idx][:, 6] * 1e6).round().long().cpu(), seen[k])
+        losses2.append(tr2.step(*bank2.gather(idx)).item())
     assert max(abs(a - b) for a, b in zip(losses, losses2)) < 1e-5 * max(losses), (losses, losses2)
