@@ -72,7 +72,10 @@ def test_gradients_match_reference_golden(mode, fmt):
     errs["embedding"] = maxnorm_rel(models["t"].weight.grad.cpu(), g["grad_embedding"])
     print(mode, fmt, {k: f"{e:.1e}" for k, e in errs.items()})
     assert len(errs) == 14
-    assert max(errs.values()) < GRAD_TOL, errs
+    # per arithmetic (measured max over the 14 tensors: 7.0e-3 | 1.4e-2 | 2.1e-2): the backward GEMMs are single-pass bf16 in every
+    # mode; the throughput mode adds bf16 forward activations, its 8-bit workspaces add the PHASE8 / MX8 rounding of the saved state
+    tol = {("bf16x3", 16): 1.2e-2, ("bf16", 16): 2.2e-2, ("bf16", 8): GRAD_TOL}[(mode, fmt)]
+    assert max(errs.values()) < tol, errs
     # every p.grad is a view of ONE flat buffer
     flat = models["coarse"].flat_grads()
     assert next(models["coarse"].parameters()).grad.data_ptr() == flat.data_ptr()
