@@ -112,6 +112,11 @@ def satnerf_param_shapes(feat=256, tau=4, layers=8, skips=(4,)):
     return shapes
 
 
+def snerf_param_shapes(feat=256, layers=8, skips=(4,)):
+    """``state_dict`` keys -> shapes of ``ShadowNeRF`` (``models/snerf.py:78-154``): Sat-NeRF without the uncertainty head."""
+    return {k: v for k, v in satnerf_param_shapes(feat, 4, layers, skips).items() if not k.startswith("beta_from_xyz")}
+
+
 def nerf_param_shapes(feat=256, layers=8, skips=(4,), map_xyz=10, map_dir=4):
     """``state_dict`` keys -> shapes of classic ``NeRF`` (``models/nerf.py:156-177``)."""
     in_xyz, in_dir = 2 * map_xyz * 3, 2 * map_dir * 3
@@ -172,6 +177,11 @@ def procedural_satnerf_params(feat=256, tau=4, seed=1, layers=8, skips=(4,), sca
             bound = (1.0 / fan_in) if first else math.sqrt(6.0 / fan_in)
         out[name] = procedural_uniform(shp, bound * scale, seed * 1000 + k)
     return out
+
+
+def procedural_snerf_params(feat=256, seed=1):
+    """``ShadowNeRF`` weights: the Sat-NeRF recipe without the uncertainty head (same hash streams for the shared tensors)."""
+    return {k: v for k, v in procedural_satnerf_params(feat, 4, seed).items() if not k.startswith("beta_from_xyz")}
 
 
 def procedural_nerf_params(feat=256, seed=1):
@@ -270,6 +280,8 @@ def satnerf_mlp(p, xyz, sun_d, t_emb, layers=8, skips=(4,), rgb_padding=0.001):
     sun_v = torch.sigmoid(F.linear(s, p["sun_v_net.6.weight"], p["sun_v_net.6.bias"]))
     k = torch.relu(F.linear(sun_d, p["sky_color.0.weight"], p["sky_color.0.bias"]))
     sky = torch.sigmoid(F.linear(k, p["sky_color.2.weight"], p["sky_color.2.bias"]))  # :201
+    if t_emb is None:  # ShadowNeRF.forward (models/snerf.py:156-196): the same network without the uncertainty head -> (B,8)
+        return torch.cat([rgb, sigma, sun_v, sky], 1)
     b = torch.cat([feats, t_emb], -1)  # :204, t last
     b = torch.sin(1.0 * F.linear(b, p["beta_from_xyz.0.weight"], p["beta_from_xyz.0.bias"]))
     beta = F.softplus(F.linear(b, p["beta_from_xyz.2.weight"], p["beta_from_xyz.2.bias"]))
@@ -338,6 +350,20 @@ def satnerf_inference(p, args, xyz, z, sun_d, t_emb, rng):
             "albedo": albedo, "sun": sun_v, "sky": sky, "beta": beta}
 
 
+def snerf_inference(p, args, xyz, z, sun_d, rng):
+    """``models/snerf.inference`` (``models/snerf.py:4-75``): Sat-NeRF's compositing without beta; sky comes per point."""
+    n, s = z.shape
+    sun_p = torch.repeat_interleave(sun_d, repeats=s, dim=0)
+    out = _chunked(lambda a, b: satnerf_mlp(p, a, b, None), args.chunk, xyz.reshape(-1, 3), sun_p).view(n, s, 8)
+    albedo, sigma, sun_v, sky = out[..., :3], out[..., 3], out[..., 4:5], out[..., 5:8]
+    noise = rng.randn(sigma.shape, sigma.device) * args.noise_std  # :57
+    weights, transparency = alpha_composite(z, sigma, noise)
+    depth = torch.sum(weights * z, -1)
+    irradiance = sun_v + (1 - sun_v) * sky  # :66
+    rgb = torch.clamp(torch.sum(weights.unsqueeze(-1) * albedo * irradiance, -2), min=0.0, max=1.0)
+    return {"rgb": rgb, "depth": depth, "weights": weights, "transparency": transparency, "albedo": albedo, "sun": sun_v, "sky": sky}
+
+
 def nerf_inference(p, args, xyz, z, rays_d, rng):
     """Classic ``models/nerf.inference`` (``models/nerf.py:71-133``): no clamp, no irradiance."""
     n, s = z.shape
@@ -354,7 +380,7 @@ def nerf_inference(p, args, xyz, z, rays_d, rng):
 
 
 def render_rays(models, args, rays, ts, rng=None):
-    """``rendering.render_rays`` (``rendering.py:52-158``) for model in {sat-nerf, nerf}.
+    """``rendering.render_rays`` (``rendering.py:52-158``) for model in {sat-nerf, s-nerf, nerf}.
 
     ``models``: {'coarse': params, ['fine': params], ['t': embedding weight (V,tau) or nn.Embedding]}.
     Deviation (documented): with n_importance>0 AND sc_lambda>0 the reference
@@ -379,6 +405,14 @@ def render_rays(models, args, rays, ts, rng=None):
             res = satnerf_inference(p, args, xyz, z_cur, sun_d, t_emb, rng)
             if args.sc_lambda > 0:  # rendering.py:102-108
                 sc = satnerf_inference(p, args, points_along(o, sun_d, z_cur), z_cur, sun_d, t_emb, rng)
+                res["weights_sc"], res["transparency_sc"], res["sun_sc"] = sc["weights"], sc["transparency"], sc["sun"]
+        elif args.model == "s-nerf":  # rendering.py:85-96 (coarse); the fine branch of the reference references an undefined
+            if typ != "coarse":       # name (rays_d_, rendering.py:133) and cannot run
+                raise NotImplementedError("s-nerf with n_importance > 0 fails in the reference (rendering.py:133, NameError)")
+            sun_d = rays[:, 8:11]
+            res = snerf_inference(p, args, xyz, z_cur, sun_d, rng)
+            if args.sc_lambda > 0:
+                sc = snerf_inference(p, args, points_along(o, sun_d, z_cur), z_cur, sun_d, rng)
                 res["weights_sc"], res["transparency_sc"], res["sun_sc"] = sc["weights"], sc["transparency"], sc["sun"]
         elif args.model == "nerf":
             res = nerf_inference(p, args, xyz, z_cur, d, rng)

@@ -137,8 +137,11 @@ class SatNeRF(_FlatParamModule):
         _sine_init(self.fc_net, first_only=True)
         _sine_init(self.sun_v_net)
         _sine_init(self.sun_v_net, first_only=True)
-        self.beta_from_xyz = nn.Sequential(nn.Linear(t_embedding_dims + feat, half), nl, nn.Linear(half, 1), nn.Softplus())
+        self._make_beta_head(t_embedding_dims, feat, half, nl)
         self._flatten()
+
+    def _make_beta_head(self, tau, feat, half, nl):
+        self.beta_from_xyz = nn.Sequential(nn.Linear(tau + feat, half), nl, nn.Linear(half, 1), nn.Softplus())
 
     def fused_forward(self, mode):
         """True when a no-grad forward in numeric mode ``mode`` runs in the fused kernel (else: layer by layer, satnerf_amd.generic)."""
@@ -146,6 +149,8 @@ class SatNeRF(_FlatParamModule):
 
     def fused_training(self, mode, fmt):
         """True when forward + backward run in the fused kernels (256: every mode / format; 512: bf16 with the 8-bit workspaces)."""
+        if int(fmt) == 32:  # parity-grade backward: the layer-by-layer path (train._fmt_of)
+            return False
         return self.fused or (self._fused_wide and mode == "bf16" and int(fmt) == 8)
 
     # ---- weight stream ------------------------------------------------------------------------------------
@@ -247,6 +252,56 @@ class SatNeRF(_FlatParamModule):
         return torch.cat([albedo, sigma.unsqueeze(1), sun_v.unsqueeze(1), sky, beta.unsqueeze(1)], 1)
 
 
+class ShadowNeRF(SatNeRF):
+    """``models.snerf.ShadowNeRF`` (models/snerf.py:78-196): Sat-NeRF without the transient embedding and the uncertainty head --
+    same trunk, density / albedo / sun-visibility / sky heads, same ``state_dict`` keys, same init RNG stream.  It runs on the
+    Sat-NeRF kernels as is: the uncertainty head exists as frozen ZERO weights (its output is ignored, it receives no gradient
+    -- g_beta = 0 -- and Adam leaves zeros at zero), the embedding is a 1-row zero table indexed by ts = 0; the head costs 5 % of
+    the FLOPs, which is what a template flag on the fused kernels would save.  ``state_dict`` / ``load_state_dict`` hide the
+    dummy head, so reference checkpoints (``nerf_coarse.*`` without ``beta_from_xyz``) load unchanged."""
+
+    number_of_outputs = 8  # rgb 3, sigma 1, sun visibility 1, sky rgb 3 (models/snerf.py:85)
+
+    def __init__(self, layers=8, feat=256, mapping=False, mapping_sizes=[10, 4], skips=[4], siren=True):
+        super().__init__(layers=layers, feat=feat, mapping=mapping, mapping_sizes=mapping_sizes, skips=skips, siren=siren, t_embedding_dims=4)
+        self._dummy_t = None
+        self._register_state_dict_hook(ShadowNeRF._drop_beta)
+        self._register_load_state_dict_pre_hook(self._inject_beta)
+
+    def _make_beta_head(self, tau, feat, half, nl):
+        with torch.random.fork_rng(devices=[]):  # the reference's ctor draws nothing here: keep torch's generator where it left it
+            super()._make_beta_head(tau, feat, half, nl)
+        for p in self.beta_from_xyz.parameters():
+            p.data.zero_()
+            p.requires_grad_(False)
+
+    @staticmethod
+    def _drop_beta(module, state_dict, prefix, local_metadata):
+        for k in [k for k in state_dict if k.startswith(prefix + "beta_from_xyz.")]:
+            del state_dict[k]
+        return state_dict
+
+    def _inject_beta(self, state_dict, prefix, *unused):
+        for k, v in self.beta_from_xyz.state_dict().items():
+            state_dict.setdefault(prefix + "beta_from_xyz." + k, torch.zeros_like(v))
+
+    def dummy_embedding(self):
+        """The 1-row zero embedding the Sat-NeRF kernels index with ts = 0 (it only feeds the dead uncertainty head)."""
+        dev = self._flat.device
+        if self._dummy_t is None or self._dummy_t.weight.device != dev:
+            emb = nn.Embedding(1, self.t_embedding_dims)
+            emb.weight.data.zero_()
+            self._dummy_t = emb.to(dev)
+        return self._dummy_t
+
+    def forward(self, input_xyz, input_dir=None, input_sun_dir=None, sigma_only=False, mlp_mode=None):
+        if input_sun_dir is None:
+            raise TypeError("ShadowNeRF.forward needs input_sun_dir (models/snerf.py:190)")
+        t = torch.zeros(input_xyz.shape[0], self.t_embedding_dims, device=input_xyz.device)
+        out = super().forward(input_xyz, input_dir, input_sun_dir, t, sigma_only=sigma_only, mlp_mode=mlp_mode)
+        return out if sigma_only else out[:, :8].contiguous()
+
+
 class NeRF(_FlatParamModule):
     """Classic NeRF (models/nerf.py:135-227): positional encoding, ReLU trunk, direction-conditioned colour head; same
     ``state_dict`` keys.  BASELINE configs[0] is a CPU plumbing run in the reference; here it runs layer by layer through the
@@ -294,5 +349,5 @@ def load_model(args):
     if args.model == "nerf":
         return NeRF(layers=args.fc_layers, feat=args.fc_units)
     if args.model == "s-nerf":
-        raise NotImplementedError("model s-nerf is out of scope (SURVEY.md section 2); sat-nerf and nerf are built")
+        return ShadowNeRF(layers=args.fc_layers, feat=args.fc_units)
     raise ValueError(f"model {args.model} is not valid")

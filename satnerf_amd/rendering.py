@@ -187,8 +187,10 @@ def render_rays(models, args, rays, ts, _ts_validated=False):
     n_samples, n_importance, variant = args.n_samples, args.n_importance, args.model
     if variant == "nerf":
         return _render_rays_nerf(models, args, rays)
+    if variant == "s-nerf":
+        return _render_rays_snerf(models, args, rays)
     if variant != "sat-nerf":
-        raise NotImplementedError(f"model {variant}: sat-nerf and nerf are built on the HIP path (s-nerf: SURVEY.md section 2, out of scope)")
+        raise ValueError(f"model {variant} is not valid")
     if ts is None:
         raise TypeError("sat-nerf needs per-ray image indices ts (rendering.py:100 would fail in torch.cat)")
     if not rays.is_cuda:
@@ -276,6 +278,28 @@ def render_rays(models, args, rays, ts, _ts_validated=False):
         else:
             run("fine", z_fine)
     return result
+
+
+def _as_satnerf(models, args):
+    """s-nerf on the Sat-NeRF kernels: (models with the 1-row zero embedding, args with model = 'sat-nerf')."""
+    import copy
+
+    if args.n_importance > 0:
+        raise NotImplementedError("s-nerf with n_importance > 0 fails in the reference itself (rendering.py:133 reads an undefined name)")
+    coarse = models["coarse"]
+    if not hasattr(coarse, "dummy_embedding"):
+        raise TypeError("args.model == 's-nerf' needs models['coarse'] = satnerf_amd.models.ShadowNeRF (load_model)")
+    args2 = copy.copy(args)
+    args2.model = "sat-nerf"
+    return {"coarse": coarse, "t": coarse.dummy_embedding()}, args2
+
+
+def _render_rays_snerf(models, args, rays):
+    """``render_rays`` for s-nerf (rendering.py:85-96, models/snerf.py:4-75): ``ts`` is unused, the result has no ``beta``."""
+    models2, args2 = _as_satnerf(models, args)
+    ts0 = torch.zeros(rays.shape[0], dtype=torch.int64, device=rays.device)
+    res = render_rays(models2, args2, rays, ts0, _ts_validated=True)
+    return {k: v for k, v in res.items() if not k.startswith("beta_")}
 
 
 def _render_rays_nerf(models, args, rays):

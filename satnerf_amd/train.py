@@ -19,15 +19,20 @@ import torch.distributed as dist
 
 
 def _fmt_of(args):
-    """Format of the saved training state (include/satrender.h SR_FMT*): ``args.bwd_fmt`` (16 | 8) when given, else the
-    numeric mode's default -- 8-bit for the throughput mode ``bf16``, 16-bit for the parity mode ``bf16x3``."""
+    """Format of the saved training state (include/satrender.h SR_FMT*): ``args.bwd_fmt`` (32 | 16 | 8) when given, else the
+    numeric mode's default -- 8-bit for the throughput mode ``bf16``, 16-bit for the parity mode ``bf16x3``.
+    32 = parity-grade backward: fp32 saved activations and 3-pass (hi/lo split) bf16 GEMMs for dX and dW, i.e. the
+    layer-by-layer path (satnerf_amd.generic) in ``bf16x3`` -- gradients within 2e-4 of the reference's (the fused backward's
+    single-pass bf16 GEMMs: 7e-3), several times slower."""
     from . import ops
     from .rendering import _mode_of
 
     fmt = getattr(args, "bwd_fmt", None)
     fmt = ops.default_fmt(_mode_of(args)) if fmt is None else int(fmt)
-    if fmt not in (8, 16):
-        raise ValueError(f"bwd_fmt must be 8 or 16, got {fmt}")
+    if fmt not in (8, 16, 32):
+        raise ValueError(f"bwd_fmt must be 8, 16 or 32, got {fmt}")
+    if fmt == 32 and _mode_of(args) != "bf16x3":
+        raise ValueError("bwd_fmt=32 (parity-grade backward) belongs to mlp_mode='bf16x3'")
     if fmt == 8 and _mode_of(args) != "bf16":
         raise ValueError("the 8-bit workspace format belongs to mlp_mode='bf16'")
     return fmt
@@ -155,6 +160,11 @@ class Trainer:
         StepLR(step_size=1, gamma=``lr_gamma``) per epoch (main.py:86-94, train_utils.py:41-57) and ``metrics.SNerfLoss`` instead
         of ``SatNerfLoss`` while epoch < ``warmup_epochs`` (main.py:128-131 hard-codes 2).  None = constant rate, SatNerfLoss
         from the first step (what bench.py measures)."""
+        self._snerf = args.model == "s-nerf"
+        if self._snerf:  # s-nerf trains on the Sat-NeRF kernels: dead uncertainty head, 1-row zero embedding, SNerfLoss throughout
+            from .rendering import _as_satnerf
+
+            models, args = _as_satnerf(models, args)
         self.models, self.args, self.world, self.lr = models, args, world_size, lr
         self.lr0, self.lr_gamma, self.steps_per_epoch, self.warmup_epochs = lr, lr_gamma, steps_per_epoch, warmup_epochs
         if args.model == "sat-nerf" and args.n_importance > 0 and loss_fn is None:
@@ -191,6 +201,10 @@ class Trainer:
         from . import ops
         from .rendering import _mode_of
 
+        if self._snerf:  # (also inside a captured step, whose static ts may hold a bank's image ids)
+            ts = self._zero_ts(ts)
+            if depth is not None:
+                depth = (depth[0], self._zero_ts(depth[1]), depth[2])
         model, emb = self.models["coarse"], self.models["t"]
         args = self.args
         n, s = rays.shape[0], args.n_samples
@@ -299,8 +313,17 @@ class Trainer:
         (``self.train_steps += 1``), so step k (0-based) sees epoch (k + 1) // steps_per_epoch."""
         return 0 if not self.steps_per_epoch else (self.n_steps + 1) // int(self.steps_per_epoch)
 
+    def _zero_ts(self, ts):
+        n = ts.shape[0]
+        cache = self.__dict__.setdefault("_zero_ts_cache", {})
+        if n not in cache:
+            cache[n] = torch.zeros(n, dtype=torch.int64, device=self.state.params.device)
+        return cache[n]
+
     def warming_up(self):
         """True while the reference trains with SNerfLoss (main.py:128: sat-nerf, epoch < 2)."""
+        if self._snerf:  # metrics.load_loss: s-nerf trains with SNerfLoss from start to end (metrics.py:94-98)
+            return True
         return bool(self.steps_per_epoch) and self.args.model == "sat-nerf" and self.current_epoch() < self.warmup_epochs
 
     def _apply_schedule(self):
@@ -321,7 +344,7 @@ class Trainer:
         (main.py:51-58: nerf_coarse. / nerf_fine. / embedding_t.) plus the optimizer moments and the step count."""
         sd = {}
         for prefix, key in (("nerf_coarse.", "coarse"), ("nerf_fine.", "fine"), ("embedding_t.", "t")):
-            if key in self.models:
+            if key in self.models and not (self._snerf and key == "t"):
                 sd.update({prefix + k: v.detach().cpu().clone() for k, v in self.models[key].state_dict().items()})
         torch.save({"state_dict": sd, "global_step": self.n_steps, "epoch": self.current_epoch(),
                     "optimizer": {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "lr": self.lr, "step": self.n_steps}}, path)
@@ -375,7 +398,7 @@ class Trainer:
         from .rendering import validate_ts
 
         for b in (bank, depth_bank):  # image indices are checked once per bank (nn.Embedding would raise on a bad one)
-            if b is not None and not getattr(b, "_ts_validated", False):
+            if b is not None and not self._snerf and not getattr(b, "_ts_validated", False):
                 validate_ts(b.ts, self.models)
                 b._ts_validated = True
         banks = (bank,) + ((depth_bank,) if depth_bank is not None else ())
@@ -412,6 +435,10 @@ class Trainer:
 
         if depth is not None and not float(getattr(self.args, "ds_lambda", 0.0)) > 0:
             raise ValueError("a depth batch was passed but args.ds_lambda is not > 0 (main.py:51)")
+        if self._snerf:  # image indices are not an input of s-nerf: every ray reads row 0 of the zero embedding
+            ts = self._zero_ts(ts)
+            if depth is not None:
+                depth = (depth[0], self._zero_ts(depth[1]), depth[2])
         if not _inputs_in_place:
             from .rendering import validate_ts
 

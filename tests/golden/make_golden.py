@@ -83,6 +83,8 @@ def ref_models(args, seed_coarse=1, seed_fine=2, emb_seed=7):
     models = {}
     if args.model == "sat-nerf":
         mk = lambda s: O.procedural_satnerf_params(args.fc_units, args.t_embbeding_tau, seed=s)  # noqa: E731
+    elif args.model == "s-nerf":
+        mk = lambda s: O.procedural_snerf_params(args.fc_units, seed=s)  # noqa: E731
     else:
         mk = lambda s: O.procedural_nerf_params(args.fc_units, seed=s)  # noqa: E731
     m = ref_load_model(args)
@@ -127,6 +129,36 @@ def render_case(name, n_rays, ray_seed, **kw):
     save(name, **arrays)
 
 
+def snerf_case():
+    """s-nerf (models/snerf.py, rendering.py:85-96): render_rays with solar correction, SNerfLoss and a few of its gradients."""
+    import metrics as ref_metrics  # (imports the stubs above)
+
+    args = O.default_args(model="s-nerf", sc_lambda=0.05)
+    rays, ts = O.synthetic_rays(48, seed=31)
+    models = ref_models(args)
+    with Capture() as cap:
+        res = ref_rendering.render_rays(models, args, rays, ts)
+    target = torch.rand(48, 3, generator=torch.Generator().manual_seed(32))
+    loss, _ = ref_metrics.SNerfLoss(lambda_sc=0.05)(res, target)
+    loss.backward()
+    grads = {"grad_" + k: v.grad for k, v in models["coarse"].named_parameters()
+             if k in ("fc_net.0.weight", "fc_net.10.weight", "sigma_from_xyz.0.weight", "rgb_from_xyzdir.0.weight", "sun_v_net.4.weight",
+                      "sun_v_net.6.weight", "sky_color.0.weight", "sky_color.2.bias")}
+    arrays = {"rays": rays, "ts": ts, "target": target, "loss": loss.detach(), "cfg": np.array(repr(vars(args)))}
+    arrays.update({f"draw{i}": d for i, d in enumerate(cap.draws)})
+    arrays.update({"out_" + k: v.detach().contiguous() for k, v in res.items()})
+    # ShadowNeRF.forward alone (B,8) + sigma_only
+    g = torch.Generator().manual_seed(33)
+    xyz = torch.rand(131, 3, generator=g) * 2 - 1
+    sun = torch.nn.functional.normalize(torch.randn(131, 3, generator=g), dim=1)
+    with torch.no_grad():
+        arrays["fwd_xyz"], arrays["fwd_sun"] = xyz, sun
+        arrays["fwd_out"] = models["coarse"](xyz, input_sun_dir=sun)
+        arrays["fwd_sigma_only"] = models["coarse"](xyz, input_sun_dir=sun, sigma_only=True)
+    arrays["state_keys"] = np.array(list(models["coarse"].state_dict().keys()))
+    save("snerf_sc", **arrays, **grads)
+
+
 def latlonalt_case():
     """datasets/satellite.py:246-275 (depth -> ECEF -> lat/lon/alt, fp64) on synthetic rays around a JAX-like scene centre."""
     from types import SimpleNamespace
@@ -146,13 +178,16 @@ def latlonalt_case():
 
 def main():
     ap = argparse.ArgumentParser(description=__doc__)
-    ap.add_argument("--only", default=None, help="regenerate one fixture group (latlonalt)")
+    ap.add_argument("--only", default=None, help="regenerate one fixture group (latlonalt | snerf)")
     only = ap.parse_args().only
     torch.manual_seed(0)
     torch.set_num_threads(8)
     if only == "latlonalt":
         return latlonalt_case()
+    if only == "snerf":
+        return snerf_case()
     latlonalt_case()
+    snerf_case()
 
     # full render_rays variants
     render_case("satnerf_coarse", 96, 11)

@@ -40,6 +40,8 @@ def make_models(args, device="cpu", seed_coarse=1, seed_fine=2, emb_seed=7):
     """Procedural parameter dicts identical to the ones make_golden.py loaded into the reference modules."""
     if args.model == "sat-nerf":
         mk = lambda s: O.procedural_satnerf_params(args.fc_units, args.t_embbeding_tau, seed=s)  # noqa: E731
+    elif args.model == "s-nerf":
+        mk = lambda s: O.procedural_snerf_params(args.fc_units, seed=s)  # noqa: E731
     else:
         mk = lambda s: O.procedural_nerf_params(args.fc_units, seed=s)  # noqa: E731
     models = {"coarse": {k: v.to(device) for k, v in mk(seed_coarse).items()}}

@@ -30,6 +30,35 @@ def test_render_rays_matches_reference(name):
         assert maxnorm_rel(res[k], v) <= TOL, (k, maxnorm_rel(res[k], v))
 
 
+def test_snerf_matches_reference():
+    """s-nerf (models/snerf.py + rendering.py:85-96): render_rays with solar correction, ShadowNeRF.forward, SNerfLoss and its
+    gradients against the reference's own outputs."""
+    g = load_golden("snerf_sc")
+    args = golden_cfg(g)
+    assert args.model == "s-nerf"
+    models = make_models(args)
+    assert list(models["coarse"]) == [str(k) for k in g["state_keys"]]  # ShadowNeRF's state_dict keys, in order
+    p = {k: v.clone().requires_grad_(True) for k, v in models["coarse"].items()}
+    res = O.render_rays({"coarse": p}, args, g["rays"], g["ts"], O.ReplayRng(golden_draws(g)))
+    expected = {k[4:]: v for k, v in g.items() if k.startswith("out_")}
+    assert set(res) == set(expected)
+    for k, v in expected.items():
+        assert res[k].shape == v.shape, k
+        assert maxnorm_rel(res[k], v) <= TOL, (k, maxnorm_rel(res[k], v))
+    loss = O.snerf_loss(res, g["target"], lambda_sc=0.05)
+    assert abs(loss.item() - float(g["loss"])) <= TOL * abs(float(g["loss"]))
+    loss.backward()
+    grads = [k for k in g if k.startswith("grad_")]
+    assert len(grads) == 8
+    for k in grads:
+        assert maxnorm_rel(p[k[5:]].grad, g[k]) <= 1e-5, k
+    with torch.no_grad():
+        out = O.satnerf_mlp(models["coarse"], g["fwd_xyz"], g["fwd_sun"], None)
+    assert out.shape == (131, 8) and maxnorm_rel(out, g["fwd_out"]) <= TOL and maxnorm_rel(out[:, 3:4], g["fwd_sigma_only"]) <= TOL
+    with pytest.raises(NotImplementedError):  # the reference's own fine branch cannot run (NameError at rendering.py:133)
+        O.render_rays({"coarse": models["coarse"], "fine": models["coarse"]}, O.default_args(model="s-nerf", n_importance=8), g["rays"], g["ts"])
+
+
 def test_mlp_forward_matches_reference():
     g = load_golden("mlp_forward")
     p = O.procedural_satnerf_params(256, 4, seed=1)
