@@ -264,7 +264,7 @@ class ShadowNeRF(SatNeRF):
 
     def __init__(self, layers=8, feat=256, mapping=False, mapping_sizes=[10, 4], skips=[4], siren=True):
         super().__init__(layers=layers, feat=feat, mapping=mapping, mapping_sizes=mapping_sizes, skips=skips, siren=siren, t_embedding_dims=4)
-        self._dummy_t = None
+        self._dummy = []  # plain list: the 1-row zero embedding must NOT become a submodule (parameters() / state_dict stay the reference's)
         self._register_state_dict_hook(ShadowNeRF._drop_beta)
         self._register_load_state_dict_pre_hook(self._inject_beta)
 
@@ -288,11 +288,12 @@ class ShadowNeRF(SatNeRF):
     def dummy_embedding(self):
         """The 1-row zero embedding the Sat-NeRF kernels index with ts = 0 (it only feeds the dead uncertainty head)."""
         dev = self._flat.device
-        if self._dummy_t is None or self._dummy_t.weight.device != dev:
-            emb = nn.Embedding(1, self.t_embedding_dims)
+        if not self._dummy or self._dummy[0].weight.device != dev:
+            with torch.random.fork_rng(devices=[]):
+                emb = nn.Embedding(1, self.t_embedding_dims)
             emb.weight.data.zero_()
-            self._dummy_t = emb.to(dev)
-        return self._dummy_t
+            self._dummy[:] = [emb.to(dev)]
+        return self._dummy[0]
 
     def forward(self, input_xyz, input_dir=None, input_sun_dir=None, sigma_only=False, mlp_mode=None):
         if input_sun_dir is None:

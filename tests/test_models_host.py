@@ -52,8 +52,14 @@ def test_cpu_inputs_fail_loudly_no_fallback():
         rendering.render_rays({"coarse": m, "t": torch.nn.Embedding(30, 4)}, args, rays, ts)
     with pytest.raises(TypeError):
         rendering.render_rays({"coarse": m, "t": torch.nn.Embedding(30, 4)}, args, rays, None)
-    with pytest.raises(NotImplementedError):
-        load_model(O.default_args(model="s-nerf"))
+    sn = load_model(O.default_args(model="s-nerf"))  # ShadowNeRF: the reference's keys / parameter count, no uncertainty head in sight
+    assert list(sn.state_dict()) == list(O.snerf_param_shapes(256)) and sn.number_of_outputs == 8
+    assert sum(p.numel() for p in sn.parameters() if p.requires_grad) == sum(int(torch.tensor(v).prod()) for v in O.snerf_param_shapes(256).values())
+    sn.load_state_dict(O.procedural_snerf_params(256, seed=2))  # strict load of the reference layout
+    sn.dummy_embedding()
+    assert list(sn.state_dict()) == list(O.snerf_param_shapes(256)) and sn._flat.numel() == 662537  # (the dummy stays outside)
+    with pytest.raises(RuntimeError):
+        rendering.render_rays({"coarse": sn}, O.default_args(model="s-nerf"), rays, ts)
     with pytest.raises(ValueError):
         load_model(O.default_args(model="bogus"))
 
