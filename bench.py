@@ -257,9 +257,10 @@ def main():
     if world == 1 and not a.no_extras and phase == "train":
         # driver-timed numbers for the other two claims: the >= 40 % forward kernel and the tolerance-passing arithmetic
         n_sub = max(20, min(a.steps, 200))
-        fdt, fk, _ = measure("forward", a.mode, a.rays, a.samples, n_sub, 0, 1, 0, dev)
-        out["forward"] = {"metric": "inference rays/sec (render_rays no_grad)", "value": a.rays * n_sub / fdt, "ms_per_step": fdt / n_sub * 1e3,
-                          "steps": n_sub, "kernel_ms": fk.get("mlp_fwd"),
+        n_fwd = 200  # (a 20-step window of 0.09 ms steps would mostly time the fences around it)
+        fdt, fk, _ = measure("forward", a.mode, a.rays, a.samples, n_fwd, 0, 1, 0, dev)
+        out["forward"] = {"metric": "inference rays/sec (render_rays no_grad)", "value": a.rays * n_fwd / fdt, "ms_per_step": fdt / n_fwd * 1e3,
+                          "steps": n_fwd, "kernel_ms": fk.get("mlp_fwd"),
                           "mlp_tflops": flop / (fk["mlp_fwd"] * 1e-3) / 1e12 if fk.get("mlp_fwd") else None,
                           "mlp_frac_of_mfma_peak": flop / (fk["mlp_fwd"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if fk.get("mlp_fwd") else None}
         if a.mode != "bf16x3":

@@ -534,6 +534,15 @@ def test_bank_walking_renderer_renders_chunk_after_chunk():
     assert not torch.equal(seen[0][1], seen[3][1])  # same chunk, another step: fresh jitter
     with pytest.raises(RuntimeError):
         gr(rays[:n], ts[:n])
+    # replay_chunks: 7 more chunks as 4 (one launch) + 3 single launches, every result equal to the hand-set-counter launch
+    got = []
+    for outs in gr.replay_chunks(7, group=4):
+        got += [{k: v.clone() for k, v in o.items()} for o in outs]
+    assert len(got) == 7 and gr._launches == 13 and int(gr._krng[1][0].item()) == 13
+    for i, o in enumerate(got):
+        ctr = torch.tensor([6 + i, 0, 0, 0], dtype=torch.float32, device=DEV)
+        want = ops.render_fwd(gr.rays, gr.ts, emb, 64, 256, 4, "bf16x3", hi, lo, l0, *sk, seed=5, step_counter=ctr, bank_chunks=chunks, want_z=False)
+        assert torch.equal(o["rgb_coarse"], want["rgb"]) and torch.equal(o["depth_coarse"], want["depth"]), i
 
 
 def test_public_inference_signature_matches_render_rays():
