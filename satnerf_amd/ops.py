@@ -365,6 +365,16 @@ def sample_pdf_merge(z_coarse, weights_coarse, u, eps=1e-5):
 
 
 # ------------------------------------------------------------------------------------------------ backward
+def graph_capture(graph):
+    """``torch.cuda.graph(graph)``; under ``torch.distributed`` the capture is thread-local, so the process group's watchdog
+    thread (which polls events of earlier collectives) cannot invalidate a capture in progress on this thread."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return torch.cuda.graph(graph, capture_error_mode="thread_local")
+    return torch.cuda.graph(graph)
+
+
 def default_fmt(mode):
     """Workspace format of a numeric mode: the throughput mode trains on 8-bit saved state, the parity mode on 16-bit."""
     return 8 if mode == "bf16" else 16

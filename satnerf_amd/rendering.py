@@ -510,7 +510,7 @@ class GraphedRenderer:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with ops.graph_capture(self.graph):
                 self.out = self._run()
         self.graph.replay()
         self._launches += 1
@@ -538,7 +538,7 @@ class GraphedRenderer:
                 if g not in multi:
                     graph = torch.cuda.CUDAGraph()
                     torch.cuda.synchronize()
-                    with torch.cuda.graph(graph):
+                    with ops.graph_capture(graph):
                         outs = [self._run() for _ in range(g)]
                     multi[g] = (graph, outs)
                 multi[g][0].replay()

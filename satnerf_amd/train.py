@@ -387,8 +387,10 @@ class Trainer:
         self.adam_state.copy_(snapshot[3])  # ... and ticked the step counter (the jitter RNG's step) in every configuration
         for b in self._graph_banks or ():    # ... and moved the banks' cursors
             b.graph_reset()
+        from . import ops
+
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        with ops.graph_capture(self._graph):
             self._static_loss = run()
         self.state.zero_grad()  # capture does not execute
 

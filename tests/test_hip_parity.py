@@ -670,8 +670,10 @@ def test_edge_cases_empty_and_ragged_inputs_of_the_newer_entry_points():
         ops.latlonalt_from_depth(rays, torch.zeros(5, device=DEV), np.zeros(3), 1.0)                               # depth count
     with pytest.raises(RuntimeError):
         rendering.render_image_outputs(models, rays.cpu(), ts.cpu(), args)                                         # no CPU path
-    with pytest.raises(NotImplementedError):
-        load_model(O.default_args(model="s-nerf"))
+    with pytest.raises(ValueError):
+        load_model(O.default_args(model="bogus"))
+    with pytest.raises(NotImplementedError):  # s-nerf has no working fine branch in the reference either (rendering.py:133)
+        rendering.render_rays({"coarse": load_model(O.default_args(model="s-nerf")).to(DEV)}, O.default_args(model="s-nerf", n_importance=4), rays, None)
 
 
 def test_width_512_fused_forward_kernel():
