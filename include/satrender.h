@@ -171,12 +171,15 @@ int sr_render_points_per_block(int feat, int mode);
  * 32-point tiles (split-K), one workgroup each, writing slice s to partial + s * (256*256 + 256*32) floats; reduce with
  * sr_unpack_grads.
  * sr_wgrad_plan (host, no GPU work): fills n_slices / first_slice of a HOST copy of the table for n_points points and at
- * most n_wg workgroups (n_wg <= 0: the current device's CU count); *n_slices = total slices. */
+ * most n_wg workgroups (n_wg <= 0: the current device's CU count); *n_slices = total slices.  `fmt` = the workspace format of
+ * the kernel that will run the plan: SR_FMT16 cuts every block into the same number of slices (that kernel's time per tile
+ * does not depend on the block), SR_FMT8 hands the workgroups out by a per-block cost (its decode work grows with the
+ * fragments a block moves), minimising the slowest workgroup's cost x tiles. */
 int sr_satnerf_mlp_bwd(int feat, int tau, int64_t n_points, const uint16_t* bwd_stream, const uint16_t* acts,
                        const float* albedo, const float* sigma, const float* sun_v, const float* beta, const float* g_albedo,
                        const float* g_sigma, const float* g_sun_v, const float* g_beta, uint16_t* dpre, float* d_t, int fmt,
                        void* stream);
-int sr_wgrad_plan(int32_t* blocks, int n_blocks, int64_t n_points, int n_wg, int* n_slices);
+int sr_wgrad_plan(int32_t* blocks, int n_blocks, int64_t n_points, int n_wg, int fmt, int* n_slices);
 int sr_satnerf_wgrad(int feat, int tau, int64_t n_points, const uint16_t* dpre, const uint16_t* acts, const int32_t* blocks,
                      int n_blocks, int n_slices, float* partial, void* stream);
 /* the same contraction from SR_FMT8 workspaces: every wave fetches one 1-KiB double fragment per tile and expands it in LDS

@@ -59,7 +59,7 @@ SIGNATURES = {
     "sr_linear_bwd_weight": (_i, [_vp, _i, _vp, _i, _i, C.POINTER(LinearSrc), _i, _i64, _i, _vp, _vp, _vp]),
     "sr_positional_map": (_i, [_vp, _i, _i, _i64, _i, _vp, _vp]),
     "sr_points_along": (_i, [_vp, _i, _i, _vp, _i64, _i, _vp, _vp]),
-    "sr_wgrad_plan": (_i, [_vp, _i, _i64, _i, _vp]),
+    "sr_wgrad_plan": (_i, [_vp, _i, _i64, _i, _i, _vp]),
     "sr_satnerf_mlp_bwd": (_i, [_i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sr_satnerf_wgrad": (_i, [_i, _i, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "sr_satnerf_wgrad8": (_i, [_i, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),

@@ -235,7 +235,7 @@ using namespace sr;
 // (LDS-DMA landed -> decode -> rendezvous -> transposed reads -> MFMA), 1.0-1.2 us for narrow head blocks and full
 // 256 x 256 blocks alike, so equal slices for every block beat slices in proportion to the fragments moved (195 vs 282 us at
 // 65,536 points), and n_blocks * floor(n_wg / n_blocks) <= n_wg workgroups keeps the launch to one round of workgroups.
-extern "C" int sr_wgrad_plan(int32_t* blocks, int n_blocks, int64_t n_points, int n_wg, int* n_slices) {
+extern "C" int sr_wgrad_plan(int32_t* blocks, int n_blocks, int64_t n_points, int n_wg, int fmt, int* n_slices) {
   SR_REQUIRE(blocks && n_slices, "sr_wgrad_plan: null pointer");
   SR_REQUIRE(n_blocks >= 1 && n_blocks <= 4096 && n_points >= 1, "sr_wgrad_plan: bad sizes (%d blocks, %lld points)", n_blocks, (long long)n_points);
   if (n_wg <= 0) {
@@ -252,13 +252,41 @@ extern "C" int sr_wgrad_plan(int32_t* blocks, int n_blocks, int64_t n_points, in
 #ifdef SR_PLAN_ENV
   if (const char* e = getenv("SR_WGRAD_UNIFORM")) per_block = atoi(e);
 #endif
+  // cost-weighted split (fmt 8): a block's time per tile grows with the fragments it decodes, so slices are handed out greedily
+  // to the block whose workgroups would otherwise finish last: minimises max_b cost_b * ceil(tiles / slices_b)
+  // cost of a tile of a block = ca + cb * row fragments + cc * column fragments (relative; MI355X A/B in profiles/r02_ab_variants.txt)
+  double ca = 0.4, cb = 0.02, cc = 0.0175;
+#ifdef SR_PLAN_ENV
+  if (const char* e = getenv("SR_WGRAD_COST")) sscanf(e, "%lf,%lf,%lf", &ca, &cb, &cc);
+#endif
   int first = 0;
+  static thread_local int sl[4096];
+  const bool weighted = fmt == SR_FMT8 && n_blocks <= n_wg;
+  if (weighted) {
+    double cost[4096];
+    for (int b = 0; b < n_blocks; ++b) {
+      const int32_t* t = blocks + kWgTableInts * b;
+      cost[b] = ca + cb * (t[1] + t[3]) + cc * (t[5] + t[7]);
+      sl[b] = 1;
+    }
+    for (int left = n_wg - n_blocks; left > 0; --left) {
+      int worst = 0;
+      double wt = -1;
+      for (int b = 0; b < n_blocks; ++b) {
+        const double tb = cost[b] * (double)((n_tiles + sl[b] - 1) / sl[b]);
+        if (tb > wt && sl[b] < n_tiles) wt = tb, worst = b;
+      }
+      if (wt < 0) break;
+      ++sl[worst];
+    }
+  }
   for (int b = 0; b < n_blocks; ++b) {
     int32_t* t = blocks + kWgTableInts * b;
     const int nr = t[1] + t[3], nc = t[5] + t[7];
     SR_REQUIRE(t[1] >= 1 && t[3] >= 0 && nr <= 16 && t[5] >= 0 && t[7] >= 0 && nc <= 16,
                "sr_wgrad_plan: block %d has %d row / %d column fragments (1..16 / 0..16)", b, nr, nc);
-    t[kWgSlices] = (int)per_block, t[kWgFirstSlice] = first, first += (int)per_block;
+    const long mine = weighted ? sl[b] : per_block;
+    t[kWgSlices] = (int)mine, t[kWgFirstSlice] = first, first += (int)mine;
   }
   *n_slices = first;
   return 0;

@@ -408,10 +408,11 @@ def satnerf_mlp_bwd(feat, tau, n_points, bwd_stream, acts, albedo, sigma, sun_v,
 _plan_cache = {}
 
 
-def wgrad_plan(blocks, n_points, n_wg=0):
-    """Split-K plan of the weight-gradient job table for ``n_points`` points (sr_wgrad_plan): returns (planned device table,
-    total slices).  Cached per (table, n_points): the copy to the device must not happen inside a graph capture."""
-    key = (blocks.data_ptr(), int(n_points), int(n_wg), str(blocks.device))
+def wgrad_plan(blocks, n_points, n_wg=0, fmt=16):
+    """Split-K plan of the weight-gradient job table for ``n_points`` points (sr_wgrad_plan; ``fmt`` = workspace format of the kernel
+    that will run it): returns (planned device table, total slices).  Cached per (table, n_points, fmt): the copy to the device
+    must not happen inside a graph capture."""
+    key = (blocks.data_ptr(), int(n_points), int(n_wg), str(blocks.device), int(fmt))
     ent = _plan_cache.get(key)
     if ent is None:
         import ctypes
@@ -419,7 +420,7 @@ def wgrad_plan(blocks, n_points, n_wg=0):
         host = _chk(blocks, "blocks", torch.int32).cpu().contiguous().clone()
         n_slices = ctypes.c_int(0)
         with torch.cuda.device(blocks.device):
-            _lib.call("sr_wgrad_plan", host.data_ptr(), host.shape[0], n_points, n_wg, ctypes.addressof(n_slices))
+            _lib.call("sr_wgrad_plan", host.data_ptr(), host.shape[0], n_points, n_wg, int(fmt), ctypes.addressof(n_slices))
         if len(_plan_cache) > 64:
             _plan_cache.clear()
         ent = _plan_cache[key] = (host.to(blocks.device), int(n_slices.value), blocks)  # keeps `blocks` alive: data_ptr stays unique
@@ -429,7 +430,7 @@ def wgrad_plan(blocks, n_points, n_wg=0):
 def wgrad_partials(feat, tau, n_points, dpre, acts, blocks, fmt=16, loads=None):
     """Weight-gradient GEMMs only: returns (fp32 split-K slices, planned job table); reduce with grad_tail / unpack_grads.
     ``fmt`` = format of both workspaces; the 8-bit kernel also needs the per-block load table ``loads`` (packing.wgrad8_loads)."""
-    plan, n_slices = wgrad_plan(blocks, n_points)
+    plan, n_slices = wgrad_plan(blocks, n_points, fmt=fmt)
     block_floats = 256 * 256 + 256 * 32  # csrc/mlp_layout.h kWgBlockFloats
     partial = torch.empty(n_slices * block_floats, dtype=torch.float32, device=dpre.device)
     ev = kernel_timer.span("wgrad") if kernel_timer is not None else None

@@ -72,10 +72,11 @@ def test_wgrad_plan_host_only(handle):
     from satnerf_amd import packing
 
     blocks0 = packing.backward_maps(256, 4)["blocks"]
-    for n_points, n_wg in ((65536, 256), (96 * 64, 256), (32, 256), (65536, 64), (1 << 20, 256), (65536, 3)):
+    cases = ((65536, 256), (96 * 64, 256), (32, 256), (65536, 64), (1 << 20, 256), (65536, 3))
+    for (n_points, n_wg), fmt in [(c, f) for c in cases for f in (16, 8)]:
         blocks = np.ascontiguousarray(blocks0.copy())
         n = ctypes.c_int(0)
-        rc = handle.sr_wgrad_plan(blocks.ctypes.data_as(ctypes.c_void_p), blocks.shape[0], n_points, n_wg, ctypes.byref(n))
+        rc = handle.sr_wgrad_plan(blocks.ctypes.data_as(ctypes.c_void_p), blocks.shape[0], n_points, n_wg, fmt, ctypes.byref(n))
         assert rc == 0
         ns, first = blocks[:, 9], blocks[:, 10]
         tiles = (n_points + 31) // 32
@@ -85,6 +86,11 @@ def test_wgrad_plan_host_only(handle):
         if tiles >= 1024 and n_wg >= 2 * blocks.shape[0]:
             assert n.value > n_wg - blocks.shape[0]  # the launch fills the chip
         assert (blocks[:, :9] == blocks0[:, :9]).all()
+        if fmt == 16:
+            assert (ns == ns[0]).all()  # equal slices
+        elif n_points == 65536 and n_wg == 256:
+            # cost-weighted: every workgroup used, full 256 x 256 blocks get more slices than the one-row head blocks
+            assert n.value == 256 and ns[:8].min() > ns[12] >= ns[13] >= 1 and ns[:8].max() - ns[:8].min() <= 1
     bad = np.ascontiguousarray(blocks0.copy())
     bad[0, 1] = 17
-    assert handle.sr_wgrad_plan(bad.ctypes.data_as(ctypes.c_void_p), bad.shape[0], 65536, 256, ctypes.byref(n)) != 0
+    assert handle.sr_wgrad_plan(bad.ctypes.data_as(ctypes.c_void_p), bad.shape[0], 65536, 256, 16, ctypes.byref(n)) != 0
