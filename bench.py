@@ -167,9 +167,21 @@ def measure(phase, mode, n_rays, n_samples, steps, warmup, world, rank, dev, wan
     for _ in range(PREWARM + warmup):
         step()
     fence()
+    prof = None
+    if os.environ.get("BENCH_PROFILE"):  # diagnostic: where the host spends the enqueue time
+        import cProfile
+
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    measure.host_enqueue_s = time.perf_counter() - t0  # host time to enqueue the steps (the device runs behind)
+    if prof is not None:
+        import pstats
+
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(12)
     fence()
     dt = time.perf_counter() - t0
     kernels = {}
@@ -214,6 +226,7 @@ def main():
 
     phase = a.phase or "train"
     dt, kernel_ms, fmt = measure(phase, a.mode, a.rays, a.samples, a.steps, a.warmup, world, rank, dev)
+    host_enqueue_s = measure.host_enqueue_s
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -246,6 +259,7 @@ def main():
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.mode == "bf16" else "bf16x3",
         "data": "synthetic", "phase": phase, "prewarm_steps": PREWARM,
+        "host_enqueue_ms_per_step": host_enqueue_s / a.steps * 1e3,
         "config": {"workload": f"BASELINE configs[1]: sat-nerf fc_units=256 tau=4, {a.rays} rays x {a.samples} samples per GPU, "
                                f"noise_std=0 sc_lambda=0 n_importance=0, mlp_mode={a.mode}"
                                + (f", saved state {fmt}-bit" if fmt else "") + ", stratified jitter drawn in-kernel (Philox-4x32-10)"

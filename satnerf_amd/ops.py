@@ -6,6 +6,7 @@ torch's current HIP stream and returns torch tensors it allocated.  No arithmeti
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -380,18 +381,27 @@ def default_fmt(mode):
     return 8 if mode == "bf16" else 16
 
 
+def _ws_empty(n, dtype, device, slot):
+    """Workspace allocation; SATNERF_WS_PAD=<bytes> shifts workspace `slot` by slot * pad bytes (placement experiments)."""
+    pad = int(os.environ.get("SATNERF_WS_PAD", "0")) * slot
+    if not pad:
+        return torch.empty(n, dtype=dtype, device=device)
+    item = torch.empty((), dtype=dtype).element_size()
+    return torch.empty(n + pad // item, dtype=dtype, device=device)[pad // item:]
+
+
 def acts_workspace(n_points, feat, device, fmt=16):
     per_tile = _lib.lib().sr_act_elems_per_tile(feat, int(fmt))
     if per_tile <= 0:
         raise ValueError(f"unsupported workspace (feat={feat}, fmt={fmt})")
-    return torch.empty(((n_points + 31) // 32) * per_tile, dtype=torch.int16, device=device)
+    return _ws_empty(((n_points + 31) // 32) * per_tile, torch.int16, device, 1)
 
 
 def satnerf_mlp_bwd(feat, tau, n_points, bwd_stream, acts, albedo, sigma, sun_v, beta, g_albedo, g_sigma, g_sun_v, g_beta, want_dt=True, fmt=16):
     """dX chain: returns (dpre workspace, d_t (P,tau) or None); ``fmt`` = format of ``acts`` and of the returned workspace."""
     dev = albedo.device
     per_tile = _lib.lib().sr_dpre_elems_per_tile(feat, int(fmt))
-    dpre = torch.empty(((n_points + 31) // 32) * per_tile, dtype=torch.int16, device=dev)
+    dpre = _ws_empty(((n_points + 31) // 32) * per_tile, torch.int16, dev, 2)
     d_t = torch.empty(n_points, tau, dtype=torch.float32, device=dev) if want_dt else None
     opt = lambda t, nm: _p(_chk(t, nm, allow_none=True))  # noqa: E731
     ev = kernel_timer.span("mlp_bwd") if kernel_timer is not None else None
@@ -432,7 +442,7 @@ def wgrad_partials(feat, tau, n_points, dpre, acts, blocks, fmt=16, loads=None):
     ``fmt`` = format of both workspaces; the 8-bit kernel also needs the per-block load table ``loads`` (packing.wgrad8_loads)."""
     plan, n_slices = wgrad_plan(blocks, n_points, fmt=fmt)
     block_floats = 256 * 256 + 256 * 32  # csrc/mlp_layout.h kWgBlockFloats
-    partial = torch.empty(n_slices * block_floats, dtype=torch.float32, device=dpre.device)
+    partial = _ws_empty(n_slices * block_floats, torch.float32, dpre.device, 3)
     ev = kernel_timer.span("wgrad") if kernel_timer is not None else None
     if ev:
         ev[0].record()

@@ -455,6 +455,7 @@ class GraphedRenderer:
         self.models, self.args, self.n = models, args, n_rays
         self._krng = (int(seed), torch.zeros(4, dtype=torch.float32, device=device)) if (kernel_rng or bank is not None) else None
         self._chunks, self._launches = 0, 0
+        self.max_inflight = int(os.environ.get("SATNERF_RENDER_MAX_INFLIGHT", "0"))
         if bank is not None:
             # ``bank`` = (rays (M,11), ts (M,)) resident on the GPU: every replay renders the NEXT n_rays rows (wrapping around), as
             # eval_satnerf.batched_inference walks an image chunk by chunk -- the kernel takes its chunk from the device counter,
@@ -512,9 +513,25 @@ class GraphedRenderer:
             self.graph = torch.cuda.CUDAGraph()
             with ops.graph_capture(self.graph):
                 self.out = self._run()
+        self._pace()
         self.graph.replay()
         self._launches += 1
         return self.out
+
+    def _pace(self):
+        """Optional bound on the replays queued ahead of the device (``max_inflight``; 0 = unbounded, the default: the one-kernel
+        forward step does not show the slow submission mode of ``train.Trainer._pace`` and an event per step costs it 5 %)."""
+        k = self.max_inflight // 8
+        if k <= 0 or self._launches % 8:
+            return
+        ring = self.__dict__.get("_pace_ring")
+        if ring is None:
+            ring = self._pace_ring = [torch.cuda.Event() for _ in range(k)]
+            for ev in ring:
+                ev.record()
+        ev = ring[(self._launches // 8) % k]
+        ev.synchronize()
+        ev.record()
 
     @torch.no_grad()
     def replay_chunks(self, k, group=4):

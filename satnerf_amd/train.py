@@ -192,6 +192,7 @@ class Trainer:
                        and hasattr(models["coarse"], "fused_training") and models["coarse"].fused_training(_mode_of(args), _fmt_of(args)))
         self.use_graph = use_graph and self.direct
         self._graph, self._static, self._graph_banks = None, None, None
+        self.max_inflight = int(os.environ.get("SATNERF_MAX_INFLIGHT", "0"))
         self.last_rgb = None
         self.last_loss = None
 
@@ -312,6 +313,24 @@ class Trainer:
         """``NeRF_pl.get_current_epoch`` (train_utils.py:14-15) of the step about to run: main.py:121 counts the step first
         (``self.train_steps += 1``), so step k (0-based) sees epoch (k + 1) // steps_per_epoch."""
         return 0 if not self.steps_per_epoch else (self.n_steps + 1) // int(self.steps_per_epoch)
+
+    def _pace(self):
+        """Optional bound on the graph replays the host keeps in flight (``max_inflight`` / SATNERF_MAX_INFLIGHT, default 0 =
+        unbounded): an event is recorded every 8th step and the host waits for the one recorded ``max_inflight`` steps earlier
+        (events are created up front: creating one costs milliseconds).  Bounded latency for interactive use; it does not change
+        the throughput (profiles/r02_ab_variants.txt: the 0.54 ms episodes seen 50-200 ms into a run are the box's power
+        management, with or without a bound)."""
+        k = self.max_inflight // 8
+        if k <= 0 or self.n_steps % 8:
+            return
+        ring = self.__dict__.get("_pace_ring")
+        if ring is None:
+            ring = self._pace_ring = [torch.cuda.Event() for _ in range(k)]
+            for ev in ring:
+                ev.record()
+        ev = ring[(self.n_steps // 8) % k]
+        ev.synchronize()  # recorded max_inflight steps ago, before that step's replay: every earlier replay has completed
+        ev.record()
 
     def _zero_ts(self, ts):
         n = ts.shape[0]
@@ -457,6 +476,7 @@ class Trainer:
                 if not _inputs_in_place:
                     for dst, src in zip(self._static, inputs):
                         dst.copy_(src)
+                self._pace()
                 self._graph.replay()
                 loss = self._static_loss
             else:
