@@ -193,6 +193,7 @@ class Trainer:
         self.use_graph = use_graph and self.direct
         self._graph, self._static, self._graph_banks = None, None, None
         self.max_inflight = int(os.environ.get("SATNERF_MAX_INFLIGHT", "0"))
+        self.pace_every = max(1, int(os.environ.get("SATNERF_PACE_EVERY", "1")))
         self.last_rgb = None
         self.last_loss = None
 
@@ -316,19 +317,20 @@ class Trainer:
 
     def _pace(self):
         """Optional bound on the graph replays the host keeps in flight (``max_inflight`` / SATNERF_MAX_INFLIGHT, default 0 =
-        unbounded): an event is recorded every 8th step and the host waits for the one recorded ``max_inflight`` steps earlier
+        unbounded): an event is recorded every ``pace_every``-th step and the host waits for the one recorded ``max_inflight`` steps earlier
         (events are created up front: creating one costs milliseconds).  Bounded latency for interactive use; it does not change
         the throughput (profiles/r02_ab_variants.txt: the 0.54 ms episodes seen 50-200 ms into a run are the box's power
         management, with or without a bound)."""
-        k = self.max_inflight // 8
-        if k <= 0 or self.n_steps % 8:
+        every = self.pace_every
+        k = self.max_inflight // every
+        if k <= 0 or self.n_steps % every:
             return
         ring = self.__dict__.get("_pace_ring")
         if ring is None:
             ring = self._pace_ring = [torch.cuda.Event() for _ in range(k)]
             for ev in ring:
                 ev.record()
-        ev = ring[(self.n_steps // 8) % k]
+        ev = ring[(self.n_steps // every) % k]
         ev.synchronize()  # recorded max_inflight steps ago, before that step's replay: every earlier replay has completed
         ev.record()
 
