@@ -1,0 +1,23 @@
+"""Forward MLP kernel time (inference and saving activations) for one library build (SATRENDER_LIB)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from satnerf_amd import ops, data
+from satnerf_amd.models import load_model
+dev = "cuda:0"
+args = data.default_args(mlp_mode="bf16")
+torch.manual_seed(0)
+m = load_model(args).to(dev); emb = torch.nn.Embedding(30, 4).to(dev)
+rays, ts = data.synthetic_rays(1024); rays, ts = rays.to(dev), ts.to(dev)
+hi, lo, l0 = m.packed("bf16")
+z = ops.ray_sample(rays, torch.rand(1024, 64, device=dev), 64)
+def run(acts=None):
+    return ops.satnerf_mlp(rays[:, 0:3], rays[:, 3:6], rays[:, 8:11], z, emb.weight.data, ts, 65536, 64, 256, 4, "bf16", hi, lo, l0, acts=acts, fmt=8)
+out = {}
+for name, acts in (("inference", None), ("save8", ops.acts_workspace(65536, 256, dev, 8))):
+    for _ in range(10): run(acts)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(50): run(acts)
+    e1.record(); torch.cuda.synchronize()
+    out[name] = round(e0.elapsed_time(e1) / 50 * 1e3, 1)
+print(os.path.basename(os.environ.get("SATRENDER_LIB", "default")), out)
