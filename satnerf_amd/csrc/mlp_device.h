@@ -55,6 +55,19 @@ __device__ __forceinline__ void glds16(const char* gsrc, uint32_t lds_addr) {
       : "v"(gsrc), "s"(lds_addr)
       : "memory");
 }
+// the same with the address split into a wave-uniform 64-bit base (SGPR pair: advanced by scalar adds, no VALU address
+// arithmetic per piece) and a 32-bit per-lane byte offset
+__device__ __forceinline__ void glds16_s(const char* sbase, uint32_t voff, uint32_t lds_addr) {
+  const uint64_t b = (uint64_t)(uintptr_t)sbase;  // readfirstlane: tells the compiler the base is uniform (folds away when it already is)
+  const uint64_t ub = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(ub), "s"(lds_addr)
+      : "memory");
+}
 __device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -69,8 +82,12 @@ __device__ __forceinline__ void issue_chunk(const char* hi, const char* lo, long
     const int i = wave + k * NW;  // wave-uniform
     if (i < NT) {
       const int piece = NPASS == 1 ? i : (i >> 1), plane = NPASS == 1 ? 0 : (i & 1);
+#ifdef SR_DMA_VADDR
       const char* src = (plane ? lo : hi) + off + piece * 1024 + lane * 16;
       glds16(src, slot_addr + piece * Mode<NPASS>::PIECE_BYTES + plane * 1024);
+#else
+      glds16_s((plane ? lo : hi) + off + piece * 1024, (uint32_t)lane * 16u, slot_addr + piece * Mode<NPASS>::PIECE_BYTES + plane * 1024);
+#endif
     }
   }
 }

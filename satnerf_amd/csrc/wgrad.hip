@@ -88,12 +88,12 @@ __global__ void __launch_bounds__(1024) wgrad_kernel(const WgradParams prm) {
   const int src_unit = lane < 32 ? lane : 32 + ((lane - 8) & 31);
   const uint32_t ring = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
   auto issue = [&](long tile, int slot) {
-    const char* dp = reinterpret_cast<const char*>(prm.dpre + tile * kDpFrags * 64 + src_unit);
-    const char* ac = reinterpret_cast<const char*>(prm.acts + tile * prm.ak * 64 + src_unit);
-    const uint32_t base = ring + slot * kSlotBytes + wave * kFragStride;
-    if (ld_r) glds16(dp + fr * 1024, base);
-    if (ld_c) glds16(ac + fc * 1024, base + 16 * kFragStride);
-    if (ld_ax) glds16(ac + fa * 1024, base + 32 * kFragStride);
+    const char* dp = reinterpret_cast<const char*>(prm.dpre + tile * kDpFrags * 64);  // wave-uniform bases + the lane's fixed offset
+    const char* ac = reinterpret_cast<const char*>(prm.acts + tile * prm.ak * 64);
+    const uint32_t base = ring + slot * kSlotBytes + wave * kFragStride, voff = (uint32_t)src_unit * 16u;
+    if (ld_r) glds16_s(dp + fr * 1024, voff, base);
+    if (ld_c) glds16_s(ac + fc * 1024, voff, base + 16 * kFragStride);
+    if (ld_ax) glds16_s(ac + fa * 1024, voff, base + 32 * kFragStride);
   };
   auto wait_tiles = [&](int c) {
     switch (c * n_ld) {

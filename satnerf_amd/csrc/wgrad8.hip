@@ -87,13 +87,15 @@ __global__ void __launch_bounds__(1024) wgrad8_kernel(const Wgrad8Params prm) {
   const int src_unit = lane < 32 ? lane : 32 + ((lane - 8) & 31);  // rotated image: position `lane` holds this source lane's 16 B
   const uint32_t ring = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
   const long p_stride = (prim & 3) == kSrcDpre ? prm.dk : prm.ak, s_stride = sec_src == kSrcDpre ? prm.dk : prm.ak;
-  const uint4* p_base = ((prim & 3) == kSrcDpre ? prm.dpre : prm.acts) + p_unit * 64 + src_unit;
-  const uint4* s_base = (sec_src == kSrcDpre ? prm.dpre : prm.acts) + sec_unit * 64 + (sec_is_aux ? src_unit : lane);
+  // DMA addresses = wave-uniform base (SGPR pair, advanced per tile by scalar arithmetic) + a fixed per-lane byte offset
+  const uint4* p_base = ((prim & 3) == kSrcDpre ? prm.dpre : prm.acts) + p_unit * 64;
+  const uint4* s_base = (sec_src == kSrcDpre ? prm.dpre : prm.acts) + sec_unit * 64;
+  const uint32_t p_voff = (uint32_t)src_unit * 16u, s_voff = (uint32_t)(sec_is_aux ? src_unit : lane) * 16u;
   const int p_off = (p_codec == kRaw16 ? p_dst : p_dst + 1) * kFragStride8;  // a DF lands where its second fragment will be
   auto issue = [&](long tile, int slot) {
     const uint32_t base = ring + slot * kSlot8Bytes;
-    if (has_prim) glds16(reinterpret_cast<const char*>(p_base + tile * p_stride * 64), base + p_off);
-    if (has_sec) glds16(reinterpret_cast<const char*>(s_base + tile * s_stride * 64), base + sec_off);
+    if (has_prim) glds16_s(reinterpret_cast<const char*>(p_base + tile * p_stride * 64), p_voff, base + p_off);
+    if (has_sec) glds16_s(reinterpret_cast<const char*>(s_base + tile * s_stride * 64), s_voff, base + sec_off);
   };
   auto wait_outstanding = [&](int tiles_in_flight) {  // all but the newest `tiles_in_flight` tiles of this wave have landed
     switch (tiles_in_flight * n_ld) {
