@@ -68,6 +68,23 @@ __device__ __forceinline__ void glds16_s(const char* sbase, uint32_t voff, uint3
       : "v"(voff), "s"(ub), "s"(lds_addr)
       : "memory");
 }
+// predicated form: `on` is wave-uniform; when it is 0 the request is issued with EXEC = 0 (no memory operation, no vmcnt
+// increment) instead of being branched around -- a branch per potential request costs the in-order wave more than the
+// dead issue slot
+__device__ __forceinline__ void glds16_s_if(bool on, const char* sbase, uint32_t voff, uint32_t lds_addr) {
+  const uint64_t b = (uint64_t)(uintptr_t)sbase;
+  const uint64_t ub = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  const uint32_t pred = __builtin_amdgcn_readfirstlane((int)on);
+  uint32_t keep;
+  uint64_t ex;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_cmp_lg_u32 %5, 0\n\ts_cselect_b64 exec, %1, 0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep), "=&s"(ex)
+      : "v"(voff), "s"(ub), "s"(lds_addr), "s"(pred)
+      : "memory", "scc");
+}
 __device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -80,15 +97,16 @@ __device__ __forceinline__ void issue_chunk(const char* hi, const char* lo, long
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int i = wave + k * NW;  // wave-uniform
-    if (i < NT) {
-      const int piece = NPASS == 1 ? i : (i >> 1), plane = NPASS == 1 ? 0 : (i & 1);
-#ifdef SR_DMA_VADDR
-      const char* src = (plane ? lo : hi) + off + piece * 1024 + lane * 16;
-      glds16(src, slot_addr + piece * Mode<NPASS>::PIECE_BYTES + plane * 1024);
+    const int piece = NPASS == 1 ? i : (i >> 1), plane = NPASS == 1 ? 0 : (i & 1);
+#ifdef SR_DMA_BRANCH
+    if (i < NT) glds16_s((plane ? lo : hi) + off + piece * 1024, (uint32_t)lane * 16u, slot_addr + piece * Mode<NPASS>::PIECE_BYTES + plane * 1024);
 #else
+    if ((k + 1) * NW <= NT) {  // every wave has this piece: unconditional
       glds16_s((plane ? lo : hi) + off + piece * 1024, (uint32_t)lane * 16u, slot_addr + piece * Mode<NPASS>::PIECE_BYTES + plane * 1024);
-#endif
+    } else {                   // the ragged last round: predicated, not branched
+      glds16_s_if(i < NT, (plane ? lo : hi) + off + piece * 1024, (uint32_t)lane * 16u, slot_addr + piece * Mode<NPASS>::PIECE_BYTES + plane * 1024);
     }
+#endif
   }
 }
 
