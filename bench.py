@@ -22,6 +22,7 @@ the committed profiles/*_train_pmc.csv named in `traffic_source`) are the second
 the reference's PyTorch path, on the host cores for a bounded sample of the same workload).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -164,6 +165,11 @@ def measure(phase, mode, n_rays, n_samples, steps, warmup, world, rank, dev, wan
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # nothing of an earlier leg (its graph, its private memory pool, its ray bank) may be released in the middle of the timed
+    # region: collect cyclic garbage now -- BEFORE the warm-up, the device must not idle between warm-up and the timed steps --
+    # and keep the collector off while the clock runs
+    gc.collect()
+    gc.disable()
     for _ in range(PREWARM + warmup):
         step()
     fence()
@@ -184,6 +190,7 @@ def measure(phase, mode, n_rays, n_samples, steps, warmup, world, rank, dev, wan
         pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(12)
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     kernels = {}
     if want_kernels:
         # roofline leg: the same step launched eagerly with HIP events around the hot kernels, same process, same data
@@ -200,6 +207,14 @@ def measure(phase, mode, n_rays, n_samples, steps, warmup, world, rank, dev, wan
         kernels = {k: timer.mean_ms(k) for k in ("mlp_fwd", "mlp_bwd", "wgrad") if timer.mean_ms(k)}
     fmt = train_mod._fmt_of(args) if phase == "train" else None
     return dt, kernels, fmt
+
+
+def release_leg():
+    """Free what the previous leg left behind (graph, pools, bank) BEFORE the next leg starts."""
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
 
 
 def main():
@@ -272,12 +287,14 @@ def main():
         # driver-timed numbers for the other two claims: the >= 40 % forward kernel and the tolerance-passing arithmetic
         n_sub = max(20, min(a.steps, 200))
         n_fwd = 200  # (a 20-step window of 0.09 ms steps would mostly time the fences around it)
+        release_leg()
         fdt, fk, _ = measure("forward", a.mode, a.rays, a.samples, n_fwd, 0, 1, 0, dev)
         out["forward"] = {"metric": "inference rays/sec (render_rays no_grad)", "value": a.rays * n_fwd / fdt, "ms_per_step": fdt / n_fwd * 1e3,
                           "steps": n_fwd, "kernel_ms": fk.get("mlp_fwd"),
                           "mlp_tflops": flop / (fk["mlp_fwd"] * 1e-3) / 1e12 if fk.get("mlp_fwd") else None,
                           "mlp_frac_of_mfma_peak": flop / (fk["mlp_fwd"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if fk.get("mlp_fwd") else None}
         if a.mode != "bf16x3":
+            release_leg()
             pdt, pk, pfmt = measure("train", "bf16x3", a.rays, a.samples, n_sub, 0, 1, 0, dev)
             out["parity_mode"] = {"metric": "training rays/sec, mlp_mode=bf16x3 (outputs <= 1e-4 of the reference), saved state "
                                             f"{pfmt}-bit", "value": a.rays * n_sub / pdt, "ms_per_step": pdt / n_sub * 1e3, "steps": n_sub,
