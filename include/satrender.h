@@ -308,6 +308,13 @@ int sr_satnerf_loss(const float* rgb, const float* weights, const float* beta, c
  * cursor[0] and advances the cursor modulo `batches` -- inside a captured training step the sampler needs no host work */
 int sr_gather_batch(const float* rays, const float* rgbs, const int64_t* ts, const int64_t* idx, int64_t n, float* out_rays,
                     float* out_rgbs, int64_t* out_ts, float* cursor, int64_t batches, void* stream);
+/* sr_gather_batch + sr_ray_setup_rng in ONE launch (one wave per ray) for captured steps that sample for themselves: the rows go to
+ * the static batch tensors, z_vals (n, n_samples) and sky (n,3) are computed from the row just read; the jitter step is
+ * step_counter[0] + step_offset (the launch runs before sr_pack_all ticks that counter: offset 1 reproduces sr_ray_setup_rng's draws) */
+int sr_gather_setup(const float* rays, const float* rgbs, const int64_t* ts, const int64_t* idx, int64_t n, float* out_rays,
+                    float* out_rgbs, int64_t* out_ts, float* cursor, int64_t batches, int n_samples, int hidden, const float* w1,
+                    const float* b1, const float* w2, const float* b2, float* z_vals, float* sky, uint64_t seed,
+                    const float* step_counter, int step_offset, void* stream);
 int sr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                  float beta2, float eps, float grad_scale, int64_t step, int zero_grad, void* stream);
 

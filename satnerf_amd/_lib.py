@@ -73,6 +73,7 @@ SIGNATURES = {
     "sr_render_loss": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sr_satnerf_loss": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sr_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i64, _i, _vp]),
+    "sr_gather_setup": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _i, _vp]),
     "sr_gather_batch": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sr_grad_tail": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
                           _vp, _vp]),

@@ -207,6 +207,39 @@ __global__ void __launch_bounds__(256) gather_batch_kernel(const float* __restri
   else if (c == 14) out_ts[b] = ts[src];
 }
 
+// gather + ray set-up in one launch, one wave per ray (captured steps that sample for themselves): the batch row goes to the static
+// inputs (lanes 0..14), the stratified depths (jitter drawn in the kernel) and the sky colour are computed from the row just read --
+// the same functions as sr_ray_setup_rng, so z and sky are bit-identical to gather followed by ray set-up.
+__global__ void __launch_bounds__(256) gather_setup_kernel(const float* __restrict__ rays, const float* __restrict__ rgbs,
+                                                          const long long* __restrict__ ts, const long long* __restrict__ idx, long n,
+                                                          float* __restrict__ out_rays, float* __restrict__ out_rgbs,
+                                                          long long* __restrict__ out_ts, float* __restrict__ cursor, unsigned batches, int S,
+                                                          int hidden, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                          const float* __restrict__ w2, const float* __restrict__ b2,
+                                                          float* __restrict__ z_out, float* __restrict__ sky, unsigned long long seed,
+                                                          const float* __restrict__ step_counter, int step_offset) {
+  const int lane = threadIdx.x & 63;
+  const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  long first = 0;
+  if (cursor) {
+    const uint32_t k = (uint32_t)cursor[0];
+    tick_when_all_read(cursor, k, batches);
+    first = (long)k * n;
+  }
+  const uint32_t rng_step = (step_counter ? (uint32_t)step_counter[0] : 0u) + (uint32_t)step_offset;
+  if (b >= n) return;
+  const long src = idx[first + b];
+  const float* ray = rays + src * 11;
+  if (lane < 11) out_rays[b * 11 + lane] = ray[lane];
+  else if (lane < 14) out_rgbs[b * 3 + (lane - 11)] = rgbs[src * 3 + (lane - 11)];
+  else if (lane == 14) out_ts[b] = ts[src];
+  const float near = ray[6], far = ray[7];
+  for (int j = lane; j < S; j += 64) z_out[b * S + j] = stratified_z(near, far, j, S, philox_uniform(seed, b, j, rng_step));
+  float k0, k1, k2;
+  sky_ray(ray[8], ray[9], ray[10], hidden, w1, b1, w2, b2, lane, k0, k1, k2);
+  if (lane == 0) sky[b * 3 + 0] = k0, sky[b * 3 + 1] = k1, sky[b * 3 + 2] = k2;
+}
+
 // torch.optim.Adam (main.py:84: lr 5e-4, betas (0.9, 0.999), eps 1e-8, no weight decay), one launch over the flat buffer.
 // The 1-based step count arrives by value (the update is launched eagerly after the gradient all-reduce, outside the
 // captured forward/backward graph); grad is optionally zeroed for the next step.
@@ -351,6 +384,20 @@ extern "C" int sr_gather_batch(const float* rays, const float* rgbs, const int64
   hipLaunchKernelGGL(gather_batch_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rays, rgbs,
                      (const long long*)ts, (const long long*)idx, (long)n, out_rays, out_rgbs, (long long*)out_ts, cursor, (unsigned)batches);
   return check_launch("gather_batch_kernel");
+}
+
+extern "C" int sr_gather_setup(const float* rays, const float* rgbs, const int64_t* ts, const int64_t* idx, int64_t n, float* out_rays,
+                               float* out_rgbs, int64_t* out_ts, float* cursor, int64_t batches, int n_samples, int hidden, const float* w1,
+                               const float* b1, const float* w2, const float* b2, float* z_vals, float* sky, uint64_t seed,
+                               const float* step_counter, int step_offset, void* stream) {
+  SR_REQUIRE(rays && rgbs && ts && idx && out_rays && out_rgbs && out_ts && w1 && b1 && w2 && b2 && z_vals && sky, "sr_gather_setup: null pointer");
+  SR_REQUIRE(cursor == nullptr || (batches >= 1 && batches < (1 << 24)), "sr_gather_setup: a cursor needs 1 <= batches < 2^24");
+  SR_REQUIRE(n_samples >= 2, "sr_gather_setup: n_samples >= 2 required");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(gather_setup_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rays, rgbs, (const long long*)ts,
+                     (const long long*)idx, (long)n, out_rays, out_rgbs, (long long*)out_ts, cursor, (unsigned)batches, n_samples, hidden, w1, b1,
+                     w2, b2, z_vals, sky, (unsigned long long)seed, step_counter, step_offset);
+  return check_launch("gather_setup_kernel");
 }
 
 extern "C" int sr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,

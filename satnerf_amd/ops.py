@@ -570,6 +570,23 @@ def gather_batch(rays, rgbs, ts, idx, out=None, cursor=None, batches=0):
     return out
 
 
+def gather_setup(rays, rgbs, ts, idx, out, n_samples, w1, b1, w2, b2, z, sky_rgb, seed, step_counter, step_offset=1, cursor=None, batches=0):
+    """``gather_batch`` + ``ray_setup`` (in-kernel jitter) in one launch: rows -> ``out`` = (rays, ts, rgbs), depths -> ``z`` (B,S),
+    sky colour -> ``sky_rgb`` (B,3); the jitter step is step_counter[0] + step_offset."""
+    n = idx.numel()
+    if cursor is not None:
+        if batches < 1 or n % batches or cursor.numel() < 4:
+            raise ValueError("cursor mode: idx must hold batches x B indices and cursor 4 floats")
+        n //= batches
+    if out[0].shape[0] != n or tuple(z.shape) != (n, n_samples) or tuple(sky_rgb.shape) != (n, 3):
+        raise ValueError("gather_setup: output shapes do not match the batch")
+    _lib.call("sr_gather_setup", _p(_chk(rays, "rays")), _p(_chk(rgbs, "rgbs")), _p(_chk(ts, "ts", torch.int64)), _p(_chk(idx, "idx", torch.int64)), n,
+              _p(_chk(out[0], "out_rays")), _p(_chk(out[2], "out_rgbs")), _p(_chk(out[1], "out_ts", torch.int64)),
+              _p(_chk(cursor, "cursor", allow_none=True)), int(batches), int(n_samples), w1.shape[0], _p(_chk(w1, "w1")), _p(_chk(b1, "b1")),
+              _p(_chk(w2, "w2")), _p(_chk(b2, "b2")), _p(_chk(z, "z")), _p(_chk(sky_rgb, "sky")), int(seed) & 0xFFFFFFFFFFFFFFFF,
+              _p(_chk(step_counter, "step_counter", allow_none=True)), int(step_offset), _stream())
+
+
 def grad_tail(partial, plan, gidx, gscale, grad_flat, sun, w1, b1, w2, sky_rgb, d_sky, g_w1, g_b1, g_w2, g_b2, d_t, ts, n_rays,
               n_samples, tau, g_emb):
     sun, stride = _rows(sun, "sun", 3)

@@ -203,6 +203,7 @@ class Trainer:
                        and hasattr(models["coarse"], "fused_training") and models["coarse"].fused_training(_mode_of(args), _fmt_of(args)))
         self.use_graph = use_graph and self.direct
         self._graph, self._static, self._graph_banks = None, None, None
+        self._pre_setup, self._pre_bufs = None, None
         self.max_inflight = int(os.environ.get("SATNERF_MAX_INFLIGHT", "0"))
         self.pace_every = max(1, int(os.environ.get("SATNERF_PACE_EVERY", "1")))
         self.last_rgb = None
@@ -234,8 +235,11 @@ class Trainer:
         noise_std = float(args.noise_std)
         # models/satnerf.py:58 draws randn even when noise_std == 0; the draw is skipped then (results are identical)
         nz = torch.randn(n, s, device=rays.device) if noise_std != 0 else None
-        z, sky = ops.ray_setup(rays, u, s, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data, seed=self._seed,
-                               step_counter=self.adam_state)
+        if self._pre_setup is not None:  # a captured step whose gather launch already produced them (_gather_from_banks)
+            (z, sky), self._pre_setup = self._pre_setup, None
+        else:
+            z, sky = ops.ray_setup(rays, u, s, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data, seed=self._seed,
+                                   step_counter=self.adam_state)
         fmt = _fmt_of(args)
         acts = ops.acts_workspace(n * s, feat, rays.device, fmt)
         albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, 3:6], rays[:, 8:11], z, emb.weight.data, ts, n * s, s, feat, tau, mode,
@@ -387,7 +391,20 @@ class Trainer:
 
         for k, b in enumerate(self._graph_banks):
             idx, cursor, batches = b.graph_source()
-            ops.gather_batch(b.rays, b.rgbs, b.ts, idx, out=self._static[3 * k:3 * k + 3], cursor=cursor, batches=batches)
+            out = self._static[3 * k:3 * k + 3]
+            if k == 0 and self._kernel_rng:
+                # the colour batch: gather + stratified depths + sky colour in ONE launch (sr_gather_setup); _forward_backward then
+                # skips its ray set-up launch.  step_offset 1: this runs before sr_pack_all ticks the step counter
+                model, n, s = self.models["coarse"], out[0].shape[0], self.args.n_samples
+                if self._pre_bufs is None or self._pre_bufs[0].shape != (n, s):
+                    dev = out[0].device
+                    self._pre_bufs = (torch.empty(n, s, device=dev), torch.empty(n, 3, device=dev))
+                sk = model.sky_color
+                ops.gather_setup(b.rays, b.rgbs, b.ts, idx, out, s, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data,
+                                 self._pre_bufs[0], self._pre_bufs[1], self._seed, self.adam_state, step_offset=1, cursor=cursor, batches=batches)
+                self._pre_setup = self._pre_bufs
+            else:
+                ops.gather_batch(b.rays, b.rgbs, b.ts, idx, out=out, cursor=cursor, batches=batches)
 
     def _capture(self, inputs, banks=None):
         self._static = tuple(t.clone() for t in inputs)
