@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step")
     ap.add_argument("--samples", type=int, default=64)
-    ap.add_argument("--mode", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--mode", default="bf16", choices=["bf16", "f16", "bf16x3"])
     ap.add_argument("--phase", default=None, choices=["train", "forward"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward / parity_mode sub-records")
@@ -272,7 +272,7 @@ def main():
     out = {
         "metric": "training rays/sec (64 samples/ray)" if phase == "train" else "inference rays/sec (64 samples/ray, render_rays no_grad)",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.mode == "bf16" else "bf16x3",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "f16": "f16", "bf16x3": "bf16x3"}[a.mode],
         "data": "synthetic", "phase": phase, "prewarm_steps": PREWARM,
         "host_enqueue_ms_per_step": host_enqueue_s / a.steps * 1e3,
         "config": {"workload": f"BASELINE configs[1]: sat-nerf fc_units=256 tau=4, {a.rays} rays x {a.samples} samples per GPU, "
@@ -293,6 +293,11 @@ def main():
                           "steps": n_fwd, "kernel_ms": fk.get("mlp_fwd"),
                           "mlp_tflops": flop / (fk["mlp_fwd"] * 1e-3) / 1e12 if fk.get("mlp_fwd") else None,
                           "mlp_frac_of_mfma_peak": flop / (fk["mlp_fwd"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if fk.get("mlp_fwd") else None}
+        if a.mode == "bf16":  # the same forward with fp16 operands (mlp_mode='f16': ~1.3e-4 of the reference instead of ~1.1e-3)
+            release_leg()
+            hdt, _, _ = measure("forward", "f16", a.rays, a.samples, n_fwd, 0, 1, 0, dev, want_kernels=False)
+            out["forward_f16"] = {"metric": "inference rays/sec, mlp_mode=f16 (fp16 MFMA operands, fp32 accumulate)",
+                                  "value": a.rays * n_fwd / hdt, "ms_per_step": hdt / n_fwd * 1e3, "steps": n_fwd}
         if a.mode != "bf16x3":
             release_leg()
             pdt, pk, pfmt = measure("train", "bf16x3", a.rays, a.samples, n_sub, 0, 1, 0, dev)

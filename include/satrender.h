@@ -28,6 +28,9 @@ extern "C" {
 /* numeric modes of the fused MLP (SURVEY.md section 7 "Hard parts") */
 #define SR_MODE_BF16 1   /* single-pass bf16 MFMA, fp32 accumulate -- throughput mode            */
 #define SR_MODE_BF16X3 3 /* hi*hi + lo*hi + hi*lo split on the same MFMA pipe -- parity mode (~2e-6) */
+#define SR_MODE_F16 2    /* single-pass fp16 MFMA, fp32 accumulate: the throughput of SR_MODE_BF16 with 11-bit operands (~1.5e-4);
+                            forward only -- weights and activations are O(1) here; the backward kernels stay bf16 -- width 256,
+                            stream_hi then holds fp16 (sr_pack_stream / sr_pack_all `n_f16`), training saves SR_FMT8 state */
 
 /* formats of the training workspaces the forward / dX / weight-gradient kernels exchange through HBM:
  * 16 = unorm16 phase / bf16 (the parity mode's backward), 8 = one byte per value (PHASE8 / micro-scaled int8): half the
@@ -52,12 +55,14 @@ int64_t sr_dpre_elems_per_tile(int feat, int fmt);  /* pre-activation gradients 
  * out_hi[i] = bf16_rne(src[idx[i]] * scale[i]);  out_lo[i] = bf16_rne(src[idx[i]]*scale[i] - out_hi[i])
  * (out_lo may be NULL).  idx < 0 selects the constant 0. */
 int sr_pack_stream(const float* src, const int32_t* idx, const float* scale, int64_t n,
-                   uint16_t* out_hi, uint16_t* out_lo, void* stream);
+                   uint16_t* out_hi, uint16_t* out_lo, int64_t n_f16, void* stream);
+/* n_f16: the first n_f16 elements of out_hi are written as fp16 instead of bf16 (the forward stream of SR_MODE_F16; even) */
 /* the same plus an fp32 gather (sr_gather_scale_f32) in ONE launch: the forward stream, the backward stream (concatenated
  * maps) and the fc_net.0 table are refreshed together after every optimizer step; `tick` (may be NULL) is a 1-float device
  * counter the launch increments: the step count sr_adam_step_graph reads later in the same captured graph */
 int sr_pack_all(const float* src, const int32_t* idx, const float* scale, int64_t n, uint16_t* out_hi, uint16_t* out_lo,
-                const int32_t* f32_idx, const float* f32_scale, int64_t n_f32, float* out_f32, float* tick, void* stream);
+                const int32_t* f32_idx, const float* f32_scale, int64_t n_f32, float* out_f32, float* tick, int64_t n_f16,
+                void* stream);
 
 /* out[i] = src[idx[i]] * scale[i] in fp32 (idx < 0 -> 0): builds the fc_net.0 table `l0` of sr_satnerf_mlp_fwd */
 int sr_gather_scale_f32(const float* src, const int32_t* idx, const float* scale, int64_t n, float* out, void* stream);

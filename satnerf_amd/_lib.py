@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SATRENDER_LIB") or os.path.join(_HERE, "csrc", "libsatrender.so")  # env override: A/B builds
 
 MODE_BF16 = 1
+MODE_F16 = 2
 MODE_BF16X3 = 3
 FMT16, FMT8 = 16, 8  # training workspace formats (include/satrender.h)
 
@@ -49,7 +50,7 @@ SIGNATURES = {
     "sr_act_elems_per_tile": (_i64, [_i, _i]),
     "sr_satnerf_render_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sr_render_points_per_block": (_i, [_i, _i]),
-    "sr_pack_stream": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "sr_pack_stream": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     "sr_dpre_elems_per_tile": (_i64, [_i, _i]),
     "sr_unpack_grads": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _vp]),
     "sr_composite_image": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp]),
@@ -78,7 +79,7 @@ SIGNATURES = {
     "sr_grad_tail": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
                           _vp, _vp]),
     "sr_adam_step_graph": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp, _i, _vp]),
-    "sr_pack_all": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "sr_pack_all": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     "sr_gather_scale_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "sr_ray_sample_fwd": (_i, [_vp, _i, _vp, _i64, _i, _vp, _vp]),
     "sr_sky_fwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -31,6 +31,13 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
   f32x2 v = {a, b};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
+// Two fp32 -> one dword of two fp16 (RNE): v_cvt_pk_f16_f32.  Operand format of the SR_MODE_F16 forward kernels.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
 __device__ __forceinline__ float bf16_lo_to_f32(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf16_hi_to_f32(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 

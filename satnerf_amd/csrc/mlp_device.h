@@ -123,9 +123,19 @@ __device__ __forceinline__ void wait_then_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// single-pass operand format of this translation unit: bf16 (SR_MODE_BF16, and every backward kernel) or fp16 (SR_F16 builds of the
+// forward kernel = SR_MODE_F16: same MFMA rate, 11 instead of 8 significand bits on weights and activations)
+#ifdef SR_F16
+__device__ __forceinline__ f32x16 mfma(const uint4& a, const uint4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t pack_op2(float a, float b) { return pack_f16x2(a, b); }
+#else
 __device__ __forceinline__ f32x16 mfma(const uint4& a, const uint4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+__device__ __forceinline__ uint32_t pack_op2(float a, float b) { return pack_bf16x2(a, b); }
+#endif
 
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(integral_constant<int, N-1>{})
 template <class F, int... I>

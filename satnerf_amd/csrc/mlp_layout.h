@@ -30,7 +30,11 @@
 #endif
 #define SR_CAT_(a, b) a##b
 #define SR_CAT(a, b) SR_CAT_(a, b)
+#ifdef SR_F16  // the fp16-operand build of the forward kernel (SR_MODE_F16) gets its own namespace too
+#define SR_FEAT_NS SR_CAT(SR_CAT(f, SR_FEAT), h)
+#else
 #define SR_FEAT_NS SR_CAT(f, SR_FEAT)
+#endif
 
 namespace sr {
 inline namespace SR_FEAT_NS {

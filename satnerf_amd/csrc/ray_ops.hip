@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(256) sample_pdf_kernel(const float* __restrict
 // ---- weight stream pack / gradient unpack ---------------------------------------------------------------------
 __global__ void __launch_bounds__(256) pack_stream_kernel(const float* __restrict__ src, const int* __restrict__ idx,
                                                          const float* __restrict__ scale, long n, uint16_t* __restrict__ hi,
-                                                         uint16_t* __restrict__ lo) {
+                                                         uint16_t* __restrict__ lo, long n_f16) {
 #pragma clang fp contract(off)
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
   if (i >= n) return;  // n is even (pieces are 512 elements)
@@ -369,13 +369,14 @@ __global__ void __launch_bounds__(256) pack_stream_kernel(const float* __restric
   const float v1 = i1 >= 0 ? src[i1] * scale[i + 1] : 0.f;
   uint32_t h, l;
   split_bf16x2(v0, v1, h, l);
+  if (i < n_f16) h = pack_f16x2(v0, v1);  // the fp16 forward stream (SR_MODE_F16)
   reinterpret_cast<uint32_t*>(hi)[i >> 1] = h;
   if (lo) reinterpret_cast<uint32_t*>(lo)[i >> 1] = l;
 }
 
 __global__ void __launch_bounds__(256) pack_all_kernel(const float* __restrict__ src, const int* __restrict__ idx, const float* __restrict__ scale,
                                                       long n, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, const int* __restrict__ fidx,
-                                                      const float* __restrict__ fscale, long nf, float* __restrict__ fout, float* tick) {
+                                                      const float* __restrict__ fscale, long nf, float* __restrict__ fout, float* tick, long n_f16) {
 #pragma clang fp contract(off)
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   if (tick != nullptr && t == 0) tick[0] += 1.0f;  // optimizer step counter of the captured training step
@@ -386,6 +387,7 @@ __global__ void __launch_bounds__(256) pack_all_kernel(const float* __restrict__
     const float v1 = i1 >= 0 ? src[i1] * scale[i + 1] : 0.f;
     uint32_t h, l;
     split_bf16x2(v0, v1, h, l);
+    if (i < n_f16) h = pack_f16x2(v0, v1);
     reinterpret_cast<uint32_t*>(hi)[t] = h;
     if (lo) reinterpret_cast<uint32_t*>(lo)[t] = l;
   } else {
@@ -658,23 +660,24 @@ extern "C" int sr_sample_pdf(const float* bins, const float* weights, const floa
 }
 
 extern "C" int sr_pack_stream(const float* src, const int32_t* idx, const float* scale, int64_t n, uint16_t* out_hi, uint16_t* out_lo,
-                              void* stream) {
+                              int64_t n_f16, void* stream) {
   SR_REQUIRE(src && idx && scale && out_hi, "sr_pack_stream: null pointer");
-  SR_REQUIRE(n % 2 == 0, "sr_pack_stream: n must be even");
+  SR_REQUIRE(n % 2 == 0 && n_f16 % 2 == 0 && n_f16 >= 0 && n_f16 <= n, "sr_pack_stream: n and n_f16 must be even, n_f16 <= n");
   if (n <= 0) return 0;
   hipLaunchKernelGGL(pack_stream_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, idx, scale,
-                     (long)n, out_hi, out_lo);
+                     (long)n, out_hi, out_lo, (long)n_f16);
   return check_launch("pack_stream_kernel");
 }
 
 extern "C" int sr_pack_all(const float* src, const int32_t* idx, const float* scale, int64_t n, uint16_t* out_hi, uint16_t* out_lo,
-                           const int32_t* f32_idx, const float* f32_scale, int64_t n_f32, float* out_f32, float* tick, void* stream) {
+                           const int32_t* f32_idx, const float* f32_scale, int64_t n_f32, float* out_f32, float* tick, int64_t n_f16,
+                           void* stream) {
   SR_REQUIRE(src && idx && scale && out_hi && f32_idx && f32_scale && out_f32, "sr_pack_all: null pointer");
-  SR_REQUIRE(n % 2 == 0, "sr_pack_all: n must be even");
+  SR_REQUIRE(n % 2 == 0 && n_f16 % 2 == 0 && n_f16 >= 0 && n_f16 <= n, "sr_pack_all: n and n_f16 must be even, n_f16 <= n");
   const long threads = n / 2 + n_f32;
   if (threads <= 0) return 0;
   hipLaunchKernelGGL(pack_all_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, idx, scale, (long)n, out_hi,
-                     out_lo, f32_idx, f32_scale, (long)n_f32, out_f32, tick);
+                     out_lo, f32_idx, f32_scale, (long)n_f32, out_f32, tick, (long)n_f16);
   return check_launch("pack_all_kernel");
 }
 

@@ -102,6 +102,11 @@ class _FlatParamModule(nn.Module):
         return self._flat
 
 
+def _stream_kind(mode):
+    """Which packed forward stream a numeric mode reads: bf16 hi plane, bf16 hi + lo planes, or fp16."""
+    return {"bf16": "bf16", "bf16x3": "x3", "f16": "f16"}[mode]
+
+
 class SatNeRF(_FlatParamModule):
     number_of_outputs = 9  # rgb 3, sigma 1, sun visibility 1, sky rgb 3, beta 1 (models/satnerf.py:90)
 
@@ -145,11 +150,13 @@ class SatNeRF(_FlatParamModule):
 
     def fused_forward(self, mode):
         """True when a no-grad forward in numeric mode ``mode`` runs in the fused kernel (else: layer by layer, satnerf_amd.generic)."""
-        return self.fused or (self._fused_wide and mode == "bf16")
+        return self.fused or (self._fused_wide and mode == "bf16")  # (256: bf16, f16 and bf16x3; 512: bf16)
 
     def fused_training(self, mode, fmt):
         """True when forward + backward run in the fused kernels (256: every mode / format; 512: bf16 with the 8-bit workspaces)."""
         if int(fmt) == 32:  # parity-grade backward: the layer-by-layer path (train._fmt_of)
+            return False
+        if mode == "f16" and int(fmt) != 8:  # the fp16 forward saves the 8-bit state only (16-bit workspaces hold bf16 operands)
             return False
         return self.fused or (self._fused_wide and mode == "bf16" and int(fmt) == 8)
 
@@ -159,13 +166,13 @@ class SatNeRF(_FlatParamModule):
         flat = self.flat_params()
         if not flat.is_cuda:
             raise RuntimeError("SatNeRF parameters are on the CPU: move the model to the GPU (.cuda()); there is no CPU path")
-        key = (mode == "bf16x3")
+        key = _stream_kind(mode)
         ent = self._pack_cache.get(key)
         version = self.weights_version()
         if ent is not None and ent[0] == version and ent[1] == flat.data_ptr():
             return ent[2]
         maps = self._device_maps()
-        hi, lo = ops.pack_stream(flat, maps["idx"], maps["scale"], want_lo=key)
+        hi, lo = ops.pack_stream(flat, maps["idx"], maps["scale"], want_lo=key == "x3", f16=key == "f16")
         l0 = ops.gather_scale(flat, maps["l0_idx"], maps["l0_scale"])
         self._pack_cache[key] = (version, flat.data_ptr(), (hi, lo, l0))
         return hi, lo, l0
@@ -175,7 +182,7 @@ class SatNeRF(_FlatParamModule):
         version checks on the captured path) and refresh the caches ``packed`` / ``packed_backward`` consult.  With
         ``backward`` the forward stream, the transposed stream and the fc_net.0 table are produced by ONE launch."""
         flat = self.flat_params()
-        key = (mode == "bf16x3")
+        key = _stream_kind(mode)
         maps = self._device_maps()
         if backward and "bmaps" not in self._pack_cache:
             self.packed_backward()
@@ -186,7 +193,7 @@ class SatNeRF(_FlatParamModule):
         if bufs is None or bufs["hi"].device != flat.device:
             dev = flat.device
             bufs = {"hi": torch.empty(n_f + n_b, dtype=torch.int16, device=dev),
-                    "lo": torch.empty(n_f + n_b, dtype=torch.int16, device=dev) if key else None,
+                    "lo": torch.empty(n_f + n_b, dtype=torch.int16, device=dev) if key == "x3" else None,
                     "l0": torch.empty(maps["l0_idx"].numel(), dtype=torch.float32, device=dev)}
             if backward:
                 bm = self._pack_cache["bmaps"]
@@ -194,9 +201,10 @@ class SatNeRF(_FlatParamModule):
             else:
                 bufs["idx"], bufs["scale"] = maps["idx"], maps["scale"]
             self._pack_cache[ck] = bufs
-        ops.pack_all(flat, bufs["idx"], bufs["scale"], bufs["hi"], bufs["lo"], maps["l0_idx"], maps["l0_scale"], bufs["l0"], tick)
+        ops.pack_all(flat, bufs["idx"], bufs["scale"], bufs["hi"], bufs["lo"], maps["l0_idx"], maps["l0_scale"], bufs["l0"], tick,
+                     n_f16=n_f if key == "f16" else 0)  # (the transposed stream behind it stays bf16: the backward kernels' format)
         version = self.weights_version()
-        self._pack_cache[key] = (version, flat.data_ptr(), (bufs["hi"][:n_f], bufs["lo"][:n_f] if key else None, bufs["l0"]))
+        self._pack_cache[key] = (version, flat.data_ptr(), (bufs["hi"][:n_f], bufs["lo"][:n_f] if key == "x3" else None, bufs["l0"]))
         if backward:
             self._pack_cache["bstream"] = (version, flat.data_ptr(), bufs["hi"][n_f:])
 

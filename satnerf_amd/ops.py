@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 
-MODES = {"bf16": _lib.MODE_BF16, "bf16x3": _lib.MODE_BF16X3}
+MODES = {"bf16": _lib.MODE_BF16, "f16": _lib.MODE_F16, "bf16x3": _lib.MODE_BF16X3}
 
 
 class KernelTimer:
@@ -73,18 +73,19 @@ def _rows(t, name, min_cols):
     return t, t.stride(0) if t.shape[0] > 1 else t.shape[1]
 
 
-def pack_stream(flat, idx, scale, want_lo):
+def pack_stream(flat, idx, scale, want_lo, f16=False):
+    """Gather + scale + convert the weight stream: bf16 hi (and lo) planes, or fp16 (``f16``: the SR_MODE_F16 forward stream)."""
     n = idx.numel()
     hi = torch.empty(n, dtype=torch.int16, device=flat.device)
     lo = torch.empty(n, dtype=torch.int16, device=flat.device) if want_lo else None
     _lib.call("sr_pack_stream", _p(_chk(flat, "flat")), _p(_chk(idx, "idx", torch.int32)), _p(_chk(scale, "scale")), n, _p(hi), _p(lo),
-              _stream())
+              n if f16 else 0, _stream())
     return hi, lo
 
 
-def pack_stream_into(flat, idx, scale, hi, lo):
+def pack_stream_into(flat, idx, scale, hi, lo, f16=False):
     _lib.call("sr_pack_stream", _p(_chk(flat, "flat")), _p(_chk(idx, "idx", torch.int32)), _p(_chk(scale, "scale")), idx.numel(), _p(hi), _p(lo),
-              _stream())
+              idx.numel() if f16 else 0, _stream())
 
 
 def gather_scale_into(flat, idx, scale, out):
@@ -378,7 +379,7 @@ def graph_capture(graph):
 
 def default_fmt(mode):
     """Workspace format of a numeric mode: the throughput mode trains on 8-bit saved state, the parity mode on 16-bit."""
-    return 8 if mode == "bf16" else 16
+    return 8 if mode in ("bf16", "f16") else 16
 
 
 def _ws_empty(n, dtype, device, slot):
@@ -493,9 +494,11 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=5e-4, betas=(0.9, 0.9
               params.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), float(grad_scale), int(step), int(zero_grad), _stream())
 
 
-def pack_all(flat, idx, scale, hi, lo, f32_idx, f32_scale, f32_out, tick=None):
+def pack_all(flat, idx, scale, hi, lo, f32_idx, f32_scale, f32_out, tick=None, n_f16=0):
+    """``n_f16``: the first n_f16 stream elements (the forward stream) are written as fp16 (SR_MODE_F16), the rest as bf16."""
     _lib.call("sr_pack_all", _p(_chk(flat, "flat")), _p(_chk(idx, "idx", torch.int32)), _p(_chk(scale, "scale")), idx.numel(), _p(hi), _p(lo),
-              _p(_chk(f32_idx, "f32_idx", torch.int32)), _p(_chk(f32_scale, "f32_scale")), f32_idx.numel(), _p(f32_out), _p(tick), _stream())
+              _p(_chk(f32_idx, "f32_idx", torch.int32)), _p(_chk(f32_scale, "f32_scale")), f32_idx.numel(), _p(f32_out), _p(tick), int(n_f16),
+              _stream())
 
 
 def sc_loss(z, sigma, noise, noise_std, sun_v, lambda_sc):

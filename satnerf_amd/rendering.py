@@ -28,7 +28,8 @@ _MODE = os.environ.get("SATNERF_AMD_MODE", "bf16x3")
 
 
 def set_default_mode(mode: str) -> None:
-    """'bf16x3' (parity mode, ~2e-6 vs fp32) or 'bf16' (single-pass throughput mode, ~1e-3)."""
+    """'bf16x3' (parity mode, ~2e-6 vs fp32), 'bf16' (single-pass throughput mode, ~1e-3) or 'f16' (single-pass fp16 operands:
+    the throughput of 'bf16' at ~1.5e-4; width 256)."""
     global _MODE
     if mode not in ops.MODES:
         raise ValueError(f"mode must be one of {sorted(ops.MODES)}")

@@ -33,8 +33,8 @@ def _fmt_of(args):
         raise ValueError(f"bwd_fmt must be 8, 16 or 32, got {fmt}")
     if fmt == 32 and _mode_of(args) != "bf16x3":
         raise ValueError("bwd_fmt=32 (parity-grade backward) belongs to mlp_mode='bf16x3'")
-    if fmt == 8 and _mode_of(args) != "bf16":
-        raise ValueError("the 8-bit workspace format belongs to mlp_mode='bf16'")
+    if fmt == 8 and _mode_of(args) not in ("bf16", "f16"):
+        raise ValueError("the 8-bit workspace format belongs to mlp_mode='bf16' / 'f16'")
     return fmt
 
 

@@ -349,3 +349,20 @@ def test_captured_step_samples_its_own_batches_from_the_bank():
         assert torch.equal((bank2.rays[idx][:, 6] * 1e6).round().long().cpu(), seen[k])
         losses2.append(tr2.step(*bank2.gather(idx)).item())
     assert max(abs(a - b) for a, b in zip(losses, losses2)) < 1e-5 * max(losses), (losses, losses2)
+
+
+def test_f16_forward_trains_kernel_direct():
+    """mlp_mode='f16': fp16 forward, bf16 backward, 8-bit saved state -- the kernel-direct captured step trains, and the 16-bit
+    workspaces are refused (they hold bf16 operands for the backward kernels)."""
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    torch.manual_seed(0)
+    args = O.default_args(mlp_mode="f16")
+    tr = Trainer({"coarse": load_model(args).to(DEV), "t": torch.nn.Embedding(30, 4).to(DEV)}, args)
+    assert tr.direct
+    rays, ts = O.synthetic_rays(256, seed=3)
+    target = torch.rand(256, 3, generator=torch.Generator().manual_seed(4)) * 0.2 + 0.4
+    losses = [tr.step(rays.to(DEV), ts.to(DEV), target.to(DEV)).item() for _ in range(12)]
+    assert tr._graph is not None and all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
+    assert not Trainer({"coarse": load_model(args).to(DEV), "t": torch.nn.Embedding(30, 4).to(DEV)}, O.default_args(mlp_mode="f16", bwd_fmt=16)).direct
