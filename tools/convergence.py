@@ -10,7 +10,7 @@ normalised by the scene range, datasets/satellite.py:225-226):
   mae_truth_*      altitude-like MAE of the rendered depth against the true surface, per training arithmetic
   delta_mae_m      |mae_truth_hip - mae_truth_ref|                       <- the "within 2 cm of the reference" quantity
   mae_between_m    mean |depth_hip_trained - depth_ref_trained|          (pointwise; training dynamics amplify rounding)
-  mae_infer_bf16_m mean |bf16 inference - fp32 inference| of the fp32-TRAINED weights (and the same for bf16x3)
+  mae_infer_bf16_m mean |bf16 inference - fp32 inference| of the fp32-TRAINED weights (and the same for f16 and bf16x3)
 The oracle is test infrastructure: this script (and tests/test_hip_convergence.py) are the only users here.
 
     python tools/convergence.py [--steps 300] [--batch 256]        # prints one JSON line
@@ -146,12 +146,12 @@ def run(steps=300, batch=256, n_eval=2048, seed=0, verbose=False):
         e2 = torch.nn.Embedding(30, 4)
         e2.load_state_dict({"weight": eo.detach()})
         mods2 = {"coarse": m2.to(dev), "t": e2.to(dev)}
-        d_inf16, d_inf48 = hip_depth(mods2, "bf16"), hip_depth(mods2, "bf16x3")
+        d_inf16, d_inf48, d_infh = hip_depth(mods2, "bf16"), hip_depth(mods2, "bf16x3"), hip_depth(mods2, "f16")
     m = SCENE_RANGE_M
     mae = lambda a, b: float((a - b).abs().mean()) * m  # noqa: E731
     out = {"steps": steps, "batch": batch, "n_eval": n_eval, "scene_range_m": m,
            "mae_truth_hip_m": mae(d_hip, ev_depth), "mae_truth_ref_m": mae(d_ref, ev_depth),
-           "mae_between_m": mae(d_hip, d_ref), "mae_infer_bf16_m": mae(d_inf16, d_ref), "mae_infer_bf16x3_m": mae(d_inf48, d_ref),
+           "mae_between_m": mae(d_hip, d_ref), "mae_infer_bf16_m": mae(d_inf16, d_ref), "mae_infer_f16_m": mae(d_infh, d_ref), "mae_infer_bf16x3_m": mae(d_inf48, d_ref),
            "final_loss_hip": hip_loss, "final_loss_ref": ref_loss, "train_s_hip": t_hip, "train_s_ref_cpu": t_ref}
     out["delta_mae_m"] = abs(out["mae_truth_hip_m"] - out["mae_truth_ref_m"])
     return out
