@@ -12,6 +12,8 @@ int launch_fwd_h1a1(const FwdParams&, int, hipStream_t);  // fp16 operands (mlp_
 int launch_fwd_h1a2(const FwdParams&, int, hipStream_t);
 int launch_fwd512_p1a1(const FwdParams&, int, hipStream_t);  // the 512-wide build (mlp_fwd512_*.hip): inference, bf16
 int launch_fwd512_p1a2(const FwdParams&, int, hipStream_t);
+int launch_fwd512_h1a1(const FwdParams&, int, hipStream_t);  // ... with fp16 operands
+int launch_fwd512_h1a2(const FwdParams&, int, hipStream_t);
 long fwd512_stream_pieces_a1();
 long fwd512_stream_pieces_a2();
 }  // namespace sr
@@ -22,8 +24,8 @@ extern "C" int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, in
   SR_REQUIRE(in != nullptr, "sr_satnerf_mlp_fwd: null inputs");
   SR_REQUIRE(feat == kFeat || feat == 512, "sr_satnerf_mlp_fwd: feat=%d unsupported (this build handles %d and 512)", feat, kFeat);
   SR_REQUIRE(mode == SR_MODE_BF16 || mode == SR_MODE_BF16X3 || mode == SR_MODE_F16, "sr_satnerf_mlp_fwd: bad mode %d", mode);
-  SR_REQUIRE(feat == kFeat || (mode == SR_MODE_BF16 && (acts == nullptr || act_fmt == SR_FMT8)),
-             "sr_satnerf_mlp_fwd: feat=512 runs the fused kernel in SR_MODE_BF16, saving activations in SR_FMT8 only (parity mode: layer by layer)");
+  SR_REQUIRE(feat == kFeat || ((mode == SR_MODE_BF16 || mode == SR_MODE_F16) && (acts == nullptr || act_fmt == SR_FMT8)),
+             "sr_satnerf_mlp_fwd: feat=512 runs the fused kernel in SR_MODE_BF16 / SR_MODE_F16, saving activations in SR_FMT8 only (parity mode: layer by layer)");
   SR_REQUIRE(tau >= 1 && tau <= 24, "sr_satnerf_mlp_fwd: tau=%d unsupported (1..24)", tau);
   SR_REQUIRE(stream_hi && l0 && in->org && in->sun && in->temb, "sr_satnerf_mlp_fwd: null pointer argument");
   SR_REQUIRE(mode != SR_MODE_BF16X3 || stream_lo, "sr_satnerf_mlp_fwd: BF16X3 needs the lo plane");
@@ -42,6 +44,7 @@ extern "C" int sr_satnerf_mlp_fwd(const sr_mlp_inputs* in, int feat, int tau, in
   hipStream_t st = (hipStream_t)stream;
   const int save = acts != nullptr ? act_fmt : 0;
   const int auxs = aux_steps(tau);
+  if (feat == 512 && mode == SR_MODE_F16) return auxs == 1 ? launch_fwd512_h1a1(p, save, st) : launch_fwd512_h1a2(p, save, st);
   if (feat == 512) return auxs == 1 ? launch_fwd512_p1a1(p, save, st) : launch_fwd512_p1a2(p, save, st);
   if (mode == SR_MODE_BF16) return auxs == 1 ? launch_fwd_p1a1(p, save, st) : launch_fwd_p1a2(p, save, st);
   if (mode == SR_MODE_F16) return auxs == 1 ? launch_fwd_h1a1(p, save, st) : launch_fwd_h1a2(p, save, st);
@@ -57,7 +60,7 @@ extern "C" int64_t sr_fwd_stream_elems(int feat, int tau) {
 extern "C" int sr_render_points_per_block(int feat, int mode) {
   if (mode != SR_MODE_BF16 && mode != SR_MODE_BF16X3 && mode != SR_MODE_F16) return -1;
   if (feat == kFeat) return mode == SR_MODE_BF16X3 ? 128 : 256;  // Mode<NPASS>::NW * 32
-  if (feat == 512 && mode == SR_MODE_BF16) return 128;
+  if (feat == 512 && (mode == SR_MODE_BF16 || mode == SR_MODE_F16)) return 128;
   return -1;
 }
 
@@ -65,7 +68,7 @@ extern "C" int sr_satnerf_render_fwd(const sr_render_args* in, int feat, int tau
                                      const float* l0, const sr_render_outputs* out, void* stream) {
   SR_REQUIRE(in != nullptr && out != nullptr, "sr_satnerf_render_fwd: null argument block");
   const int per_block = sr_render_points_per_block(feat, mode);
-  SR_REQUIRE(per_block > 0, "sr_satnerf_render_fwd: no fused kernel for feat=%d mode=%d (256: both modes; 512: SR_MODE_BF16)", feat, mode);
+  SR_REQUIRE(per_block > 0, "sr_satnerf_render_fwd: no fused kernel for feat=%d mode=%d (256: every mode; 512: SR_MODE_BF16 / SR_MODE_F16)", feat, mode);
   SR_REQUIRE(tau >= 1 && tau <= 24, "sr_satnerf_render_fwd: tau=%d unsupported (1..24)", tau);
   SR_REQUIRE(in->n_samples >= 2 && per_block % in->n_samples == 0,
              "sr_satnerf_render_fwd: n_samples=%d must be >= 2 and divide %d (sr_render_points_per_block)", in->n_samples, per_block);
@@ -93,6 +96,7 @@ extern "C" int sr_satnerf_render_fwd(const sr_render_args* in, int feat, int tau
   p.acts = nullptr, p.tau = tau;
   hipStream_t st = (hipStream_t)stream;
   const int auxs = aux_steps(tau);
+  if (feat == 512 && mode == SR_MODE_F16) return auxs == 1 ? launch_fwd512_h1a1(p, 0, st) : launch_fwd512_h1a2(p, 0, st);
   if (feat == 512) return auxs == 1 ? launch_fwd512_p1a1(p, 0, st) : launch_fwd512_p1a2(p, 0, st);
   if (mode == SR_MODE_BF16) return auxs == 1 ? launch_fwd_p1a1(p, 0, st) : launch_fwd_p1a2(p, 0, st);
   if (mode == SR_MODE_F16) return auxs == 1 ? launch_fwd_h1a1(p, 0, st) : launch_fwd_h1a2(p, 0, st);

@@ -150,7 +150,7 @@ class SatNeRF(_FlatParamModule):
 
     def fused_forward(self, mode):
         """True when a no-grad forward in numeric mode ``mode`` runs in the fused kernel (else: layer by layer, satnerf_amd.generic)."""
-        return self.fused or (self._fused_wide and mode == "bf16")  # (256: bf16, f16 and bf16x3; 512: bf16)
+        return self.fused or (self._fused_wide and mode in ("bf16", "f16"))  # (256: bf16, f16 and bf16x3; 512: bf16, f16)
 
     def fused_training(self, mode, fmt):
         """True when forward + backward run in the fused kernels (256: every mode / format; 512: bf16 with the 8-bit workspaces)."""
@@ -158,7 +158,7 @@ class SatNeRF(_FlatParamModule):
             return False
         if mode == "f16" and int(fmt) != 8:  # the fp16 forward saves the 8-bit state only (16-bit workspaces hold bf16 operands)
             return False
-        return self.fused or (self._fused_wide and mode == "bf16" and int(fmt) == 8)
+        return self.fused or (self._fused_wide and mode in ("bf16", "f16") and int(fmt) == 8)
 
     # ---- weight stream ------------------------------------------------------------------------------------
     def packed(self, mode):

@@ -708,7 +708,7 @@ def test_width_512_fused_forward_kernel():
     args.mlp_mode = "bf16"
     models = build_models(args)
     m = models["coarse"]
-    assert not m.fused and m.fused_forward("bf16") and not m.fused_forward("bf16x3")
+    assert not m.fused and m.fused_forward("bf16") and m.fused_forward("f16") and not m.fused_forward("bf16x3")
     draws = [d.to(DEV) for d in golden_draws(g)]
     with torch.no_grad(), rendering.replay_rng(draws):
         res = rendering.render_rays(models, args, g["rays"].to(DEV), g["ts"].to(DEV))
@@ -718,6 +718,14 @@ def test_width_512_fused_forward_kernel():
     print("feat 512 fused bf16", {k: f"{e:.1e}" for k, e in errs.items()})
     assert max(errs[k] for k in ("rgb_coarse", "depth_coarse", "weights_coarse")) < 2e-2, errs
     assert max(errs.values()) < 5e-2, errs
+    # the fp16-operand build of the same kernel: an order of magnitude closer
+    args.mlp_mode = "f16"
+    with torch.no_grad(), rendering.replay_rng(draws):
+        res16 = rendering.render_rays(models, args, g["rays"].to(DEV), g["ts"].to(DEV))
+    errs16 = {k: maxnorm_rel(res16[k].cpu(), v) for k, v in expected.items()}
+    print("feat 512 fused f16", {k: f"{e:.1e}" for k, e in errs16.items()})
+    assert max(errs16[k] for k in ("rgb_coarse", "depth_coarse", "weights_coarse")) < 5e-4 and max(errs16.values()) < 1.5e-3, errs16
+    args.mlp_mode = "bf16"
     # per-point outputs through the reference-signature forward: fused bf16 vs the layer path (3-pass) on random points
     x, sun, t = torch.rand(777, 3, device=DEV) * 2 - 1, torch.nn.functional.normalize(torch.randn(777, 3, device=DEV), dim=1), torch.rand(777, 16, device=DEV)
     with torch.no_grad():

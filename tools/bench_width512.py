@@ -8,7 +8,7 @@ from satnerf_amd.models import load_model
 dev = "cuda:0"
 rays, ts = data.synthetic_rays(1024); rays, ts = rays.to(dev), ts.to(dev)
 for tau in (4, 16):
-    for mode in ("bf16", "bf16x3"):
+    for mode in ("bf16", "f16", "bf16x3"):
         args = data.default_args(fc_units=512, t_embbeding_tau=tau, mlp_mode=mode)
         torch.manual_seed(0)
         m = load_model(args).to(dev); emb = torch.nn.Embedding(30, tau).to(dev)
@@ -42,7 +42,7 @@ for tau in (4, 16):
 from satnerf_amd.train import Trainer  # noqa: E402
 
 target = torch.rand(1024, 3, device=dev) * 0.2 + 0.4
-for mode in ("bf16", "bf16x3"):
+for mode in ("bf16", "f16", "bf16x3"):
     args = data.default_args(fc_units=512, t_embbeding_tau=4, mlp_mode=mode)
     torch.manual_seed(0)
     tr = Trainer({"coarse": load_model(args).to(dev), "t": torch.nn.Embedding(30, 4).to(dev)}, args)
