@@ -98,7 +98,11 @@ __device__ __forceinline__ void issue_chunk(const char* hi, const char* lo, long
   for (int k = 0; k < PER; ++k) {
     const int i = wave + k * NW;  // wave-uniform
     const int piece = NPASS == 1 ? i : (i >> 1), plane = NPASS == 1 ? 0 : (i & 1);
-#ifdef SR_DMA_BRANCH
+#if SR_FEAT == 512
+    // the 512-wide builds have no register to spare (256 VGPR + 256 AGPR): the SGPR-base form made hipcc spill (11-34 VGPRs, the
+    // plain forward kernel 390 -> 837 us); they keep the per-lane 64-bit address
+    if (i < NT) glds16((plane ? lo : hi) + off + piece * 1024 + lane * 16, slot_addr + piece * Mode<NPASS>::PIECE_BYTES + plane * 1024);
+#elif defined(SR_DMA_BRANCH)
     if (i < NT) glds16_s((plane ? lo : hi) + off + piece * 1024, (uint32_t)lane * 16u, slot_addr + piece * Mode<NPASS>::PIECE_BYTES + plane * 1024);
 #else
     if ((k + 1) * NW <= NT) {  // every wave has this piece: unconditional
