@@ -298,6 +298,10 @@ def main():
             hdt, _, _ = measure("forward", "f16", a.rays, a.samples, n_fwd, 0, 1, 0, dev, want_kernels=False)
             out["forward_f16"] = {"metric": "inference rays/sec, mlp_mode=f16 (fp16 MFMA operands, fp32 accumulate)",
                                   "value": a.rays * n_fwd / hdt, "ms_per_step": hdt / n_fwd * 1e3, "steps": n_fwd}
+            release_leg()
+            tdt, _, tfmt = measure("train", "f16", a.rays, a.samples, n_sub, 0, 1, 0, dev, want_kernels=False)
+            out["train_f16"] = {"metric": f"training rays/sec, mlp_mode=f16 (fp16 forward, bf16 backward, saved state {tfmt}-bit)",
+                                "value": a.rays * n_sub / tdt, "ms_per_step": tdt / n_sub * 1e3, "steps": n_sub}
         if a.mode != "bf16x3":
             release_leg()
             pdt, pk, pfmt = measure("train", "bf16x3", a.rays, a.samples, n_sub, 0, 1, 0, dev)
