@@ -18,12 +18,13 @@ def build(args, seed=1):
     return {"coarse": m.to(DEV)}
 
 
-def test_snerf_render_rays_matches_reference_golden():
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-4), ("f16", 4e-4)])
+def test_snerf_render_rays_matches_reference_golden(mode, tol):
     from satnerf_amd import rendering
 
     g = load_golden("snerf_sc")
     args = golden_cfg(g)
-    args.mlp_mode = "bf16x3"
+    args.mlp_mode = mode
     models = build(args)
     assert [k for k in models["coarse"].state_dict()] == [str(k) for k in g["state_keys"]]
     assert models["coarse"].number_of_outputs == 8
@@ -34,13 +35,13 @@ def test_snerf_render_rays_matches_reference_golden():
     assert set(res) == set(expected)  # no beta_* keys
     for k, v in expected.items():
         assert res[k].shape == v.shape, k
-        assert maxnorm_rel(res[k].cpu(), v) < 1e-4, (k, maxnorm_rel(res[k].cpu(), v))
+        assert maxnorm_rel(res[k].cpu(), v) < tol, (k, maxnorm_rel(res[k].cpu(), v))
     # ShadowNeRF.forward with the reference's signature: (B,8), sigma_only (B,1)
     with torch.no_grad():
-        out = models["coarse"](g["fwd_xyz"].to(DEV), input_sun_dir=g["fwd_sun"].to(DEV), mlp_mode="bf16x3")
-        sig = models["coarse"](g["fwd_xyz"].to(DEV), input_sun_dir=g["fwd_sun"].to(DEV), sigma_only=True, mlp_mode="bf16x3")
-    assert out.shape == (131, 8) and maxnorm_rel(out.cpu(), g["fwd_out"]) < 1e-4
-    assert sig.shape == (131, 1) and maxnorm_rel(sig.cpu(), g["fwd_sigma_only"]) < 1e-4
+        out = models["coarse"](g["fwd_xyz"].to(DEV), input_sun_dir=g["fwd_sun"].to(DEV), mlp_mode=mode)
+        sig = models["coarse"](g["fwd_xyz"].to(DEV), input_sun_dir=g["fwd_sun"].to(DEV), sigma_only=True, mlp_mode=mode)
+    assert out.shape == (131, 8) and maxnorm_rel(out.cpu(), g["fwd_out"]) < 2 * tol
+    assert sig.shape == (131, 1) and maxnorm_rel(sig.cpu(), g["fwd_sigma_only"]) < 2 * tol
     with pytest.raises(NotImplementedError):  # the reference's own fine branch cannot run
         rendering.render_rays({**models, "fine": models["coarse"]}, O.default_args(model="s-nerf", n_importance=8), g["rays"].to(DEV), None)
 
