@@ -69,7 +69,7 @@ def make_scene(n_rays, seed):
     return rays, ts, rgbs.float(), t.float()
 
 
-def run(steps=300, batch=256, n_eval=2048, seed=0, verbose=False):
+def run(steps=300, batch=256, n_eval=2048, seed=0, verbose=False, mode="bf16"):
     from oracle import satnerf_oracle as O
     from satnerf_amd import rendering
     from satnerf_amd.models import load_model
@@ -87,7 +87,7 @@ def run(steps=300, batch=256, n_eval=2048, seed=0, verbose=False):
 
     # identical init for both trainings
     torch.manual_seed(seed)
-    args_hip = O.default_args(mlp_mode="bf16", ds_lambda=ds_lambda)
+    args_hip = O.default_args(mlp_mode=mode, ds_lambda=ds_lambda)
     model = load_model(args_hip)
     emb = torch.nn.Embedding(30, 4)
     init = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -139,7 +139,7 @@ def run(steps=300, batch=256, n_eval=2048, seed=0, verbose=False):
             with rendering.replay_rng([ev_u.to(dev), ev_noise.to(dev)]):
                 return rendering.render_rays(mods, a, ev_rays.to(dev), ev_ts.to(dev))["depth_coarse"].cpu()
 
-        d_hip = hip_depth(models, "bf16")
+        d_hip = hip_depth(models, mode)
         # the fp32-trained weights through the HIP inference path in both arithmetic modes
         m2 = load_model(args_hip)
         m2.load_state_dict(ref_trained)
@@ -149,7 +149,7 @@ def run(steps=300, batch=256, n_eval=2048, seed=0, verbose=False):
         d_inf16, d_inf48, d_infh = hip_depth(mods2, "bf16"), hip_depth(mods2, "bf16x3"), hip_depth(mods2, "f16")
     m = SCENE_RANGE_M
     mae = lambda a, b: float((a - b).abs().mean()) * m  # noqa: E731
-    out = {"steps": steps, "batch": batch, "n_eval": n_eval, "scene_range_m": m,
+    out = {"train_mode": mode, "steps": steps, "batch": batch, "n_eval": n_eval, "scene_range_m": m,
            "mae_truth_hip_m": mae(d_hip, ev_depth), "mae_truth_ref_m": mae(d_ref, ev_depth),
            "mae_between_m": mae(d_hip, d_ref), "mae_infer_bf16_m": mae(d_inf16, d_ref), "mae_infer_f16_m": mae(d_infh, d_ref), "mae_infer_bf16x3_m": mae(d_inf48, d_ref),
            "final_loss_hip": hip_loss, "final_loss_ref": ref_loss, "train_s_hip": t_hip, "train_s_ref_cpu": t_ref}
@@ -162,5 +162,6 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--eval", type=int, default=2048)
+    ap.add_argument("--mode", default="bf16", choices=["bf16", "f16"], help="arithmetic of the HIP training run")
     a = ap.parse_args()
-    print(json.dumps(run(a.steps, a.batch, a.eval, verbose=True)))
+    print(json.dumps(run(a.steps, a.batch, a.eval, verbose=True, mode=a.mode)))
