@@ -30,7 +30,7 @@ extern "C" {
 #define SR_MODE_BF16X3 3 /* hi*hi + lo*hi + hi*lo split on the same MFMA pipe -- parity mode (~2e-6) */
 #define SR_MODE_F16 2    /* single-pass fp16 MFMA, fp32 accumulate: the throughput of SR_MODE_BF16 with 11-bit operands (~1.5e-4);
                             forward only -- weights and activations are O(1) here; the backward kernels stay bf16 -- widths 256 and 512,
-                            stream_hi then holds fp16 (sr_pack_stream / sr_pack_all `n_f16`), training saves SR_FMT8 state */
+                            stream_hi then holds fp16 (sr_pack_stream / sr_pack_all `n_f16`); the training workspaces keep their (bf16 / 8-bit) formats */
 
 /* formats of the training workspaces the forward / dX / weight-gradient kernels exchange through HBM:
  * 16 = unorm16 phase / bf16 (the parity mode's backward), 8 = one byte per value (PHASE8 / micro-scaled int8): half the

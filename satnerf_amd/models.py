@@ -156,8 +156,6 @@ class SatNeRF(_FlatParamModule):
         """True when forward + backward run in the fused kernels (256: every mode / format; 512: bf16 with the 8-bit workspaces)."""
         if int(fmt) == 32:  # parity-grade backward: the layer-by-layer path (train._fmt_of)
             return False
-        if mode == "f16" and int(fmt) != 8:  # the fp16 forward saves the 8-bit state only (16-bit workspaces hold bf16 operands)
-            return False
         return self.fused or (self._fused_wide and mode in ("bf16", "f16") and int(fmt) == 8)
 
     # ---- weight stream ------------------------------------------------------------------------------------
