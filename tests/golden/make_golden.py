@@ -176,9 +176,57 @@ def latlonalt_case():
     save("latlonalt", rays=rays, depth=depth, center=ds.center, range=ds.range, lats=lats, lons=lons, alts=alts)
 
 
+def rpc_rays_case():
+    """datasets/satellite.py:18-65 (``get_rays``), :218-227 (``normalize_rays``), :229-244 (``get_sun_dirs``) and sat_utils.py:44-57
+    (``rescale_rpc``) RUN FROM THE REFERENCE on a synthetic RPC00B camera.  The one third-party call on the path,
+    ``rpcm.RPCModel.localization`` (rpcm is absent offline), is supplied by a duck-typed rpc object whose ``localization`` is the
+    oracle's Newton iteration: everything the reference itself computes -- ECEF conversion, near / far / direction, the float32 cast,
+    the in-place scene normalisation, the sun direction, the RPC rescaling -- is pinned by this fixture; only rpcm's own iteration
+    (checked by round trip through the published projection, tests/test_rpc.py) stays unpinned."""
+    from types import SimpleNamespace
+
+    import sat_utils as ref_sat_utils
+    from datasets.satellite import SatelliteDataset
+    from datasets.satellite import get_rays as ref_get_rays
+
+    from oracle import rpc_oracle as R
+
+    class DuckRPC:  # the attributes sat_utils.rescale_rpc touches + the method get_rays calls
+        def __init__(self, d):
+            self.d = dict(d)
+            for k in ("row_scale", "col_scale", "row_offset", "col_offset"):
+                setattr(self, k, float(d[k]))
+
+        def _dict(self):
+            return dict(self.d, row_scale=self.row_scale, col_scale=self.col_scale, row_offset=self.row_offset, col_offset=self.col_offset)
+
+        def localization(self, cols, rows, alts):
+            return R.localization(self._dict(), cols, rows, alts)
+
+    arrays = {}
+    for tag, (seed, h, w, down, min_alt, max_alt, el, az) in {"a": (0, 48, 64, 1.0, -25.0, 60.0, 52.0, 141.0),
+                                                              "b": (4, 90, 70, 2.0, -31.5, 77.25, 38.5, 203.25)}.items():
+        rpc_d = R.synthetic_rpc(seed, height=h, width=w)
+        rpc = ref_sat_utils.rescale_rpc(DuckRPC(rpc_d), 1.0 / down)                      # sat_utils.py:44-57
+        hh, ww = int(h // down), int(w // down)
+        cols, rows = np.meshgrid(np.arange(ww), np.arange(hh))                            # datasets/satellite.py:193
+        rays8 = ref_get_rays(cols.flatten(), rows.flatten(), rpc, min_alt, max_alt)       # :18-65
+        cx, cy, cz = ref_sat_utils.latlon_to_ecef_custom(rpc_d["lat_offset"], rpc_d["lon_offset"], 10.0)
+        ds = SimpleNamespace(center=torch.tensor([cx, cy, cz], dtype=torch.float32), range=torch.tensor(310.0 + 7 * seed))  # :160-163 loads them as float tensors
+        rays_n = SatelliteDataset.normalize_rays(ds, rays8.clone())                       # :218-227
+        sun = SatelliteDataset.get_sun_dirs(ds, el, az, rays_n.shape[0])                  # :229-244
+        rays11 = torch.hstack([rays_n, sun]).type(torch.FloatTensor)                      # :213-214
+        arrays.update({f"{tag}_seed": np.int64(seed), f"{tag}_hw": np.array([h, w]), f"{tag}_down": np.float64(down),
+                       f"{tag}_alts": np.array([min_alt, max_alt]), f"{tag}_sun": np.array([el, az]),
+                       f"{tag}_center": ds.center.numpy().astype(np.float64), f"{tag}_range": np.float64(ds.range.item()),
+                       f"{tag}_rescaled": np.array([rpc.row_scale, rpc.col_scale, rpc.row_offset, rpc.col_offset]),
+                       f"{tag}_rays8": rays8, f"{tag}_rays11": rays11})
+    save("rpc_rays", **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__)
-    ap.add_argument("--only", default=None, help="regenerate one fixture group (latlonalt | snerf)")
+    ap.add_argument("--only", default=None, help="regenerate one fixture group (latlonalt | snerf | rpc)")
     only = ap.parse_args().only
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -186,7 +234,10 @@ def main():
         return latlonalt_case()
     if only == "snerf":
         return snerf_case()
+    if only == "rpc":
+        return rpc_rays_case()
     latlonalt_case()
+    rpc_rays_case()
     snerf_case()
 
     # full render_rays variants
