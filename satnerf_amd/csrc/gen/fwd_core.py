@@ -1,0 +1,516 @@
+#!/usr/bin/env python3
+"""Generator of the hand-placed gfx950 instruction stream of the fused Sat-NeRF forward MLP core (csrc/mlp_fwd2.inc).
+
+Why a generator: profiles/r03_coissue.txt shows that v_mfma_f32_32x32x16_bf16 and the SIREN epilogue's VALU work (v_sin_f32,
+v_cvt_pk_bf16_f32) overlap completely on one SIMD when the stream is placed by hand -- 32.3-32.8 cycles per MFMA with the A fragment
+read from LDS -- while hipcc's schedule of the same work (csrc/mlp_fwd.inc) runs at ~75.  The stream is long (1,406 MFMAs per 32-point
+tile, every register named) and regular, so it is emitted by this script: ``python fwd_core.py`` writes csrc/mlp_fwd_core_a{1,2}.inc
+(string literals #included into one ``asm volatile`` statement).  tests/test_fwd_core.py re-generates the files (they must match what
+is committed) and EXECUTES the instruction list on a lane-accurate numpy model of the register file / LDS ring / MFMA against the
+packed weight stream, so register allocation, piece addressing, operand order and the DMA ring protocol are validated on the CPU.
+
+Structure of the core (one wave = 32 points, 8 waves per workgroup, 2 per SIMD, <= 256 VGPRs; mlp_layout.h for the stream format):
+  * MFMA i of the wave consumes piece i of the stream (1 KiB A fragment = one k-step of one 32-row output tile).  Pieces reach LDS by
+    LDS-DMA "rows" of 8 pieces (one 1-KiB request per wave and row) into a flat ring of R pieces; ``sync`` points (counted vmcnt +
+    s_barrier) every GROUP chunks make a group's pieces visible, after which the rows whose ring slots are free are requested.
+  * A fragments are fetched PF MFMAs ahead (ds_read_b128 into a ring of PF + 1 register quads, counted lgkmcnt before each MFMA).
+  * the epilogue of tile t-1 (16 v_sin in place on its accumulator, 8 v_cvt_pk into the next stage's B fragments) is spread over the
+    gaps of tile t's MFMAs, starting two MFMAs after the tile's last one (XDL write -> VALU read needs 12 wait states).
+  * hazards the assembler does not pad inside inline asm are checked here: trans -> VALU use (1 state), VALU write -> MFMA operand
+    (2 states), MFMA D -> VALU read (>= 2 MFMAs later), M0 write -> LDS-DMA (1 state).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+# ---- register map (VGPR numbers) ------------------------------------------------------------------------------------------------
+X, Y = 0, 64            # the two 64-register activation vectors (16 B fragments of 4 registers)
+ACC = (128, 144)        # double-buffered tile accumulators
+AR0, NA = 160, 6        # ring of A-fragment register quads (PF + 1 entries)
+AUX = 184               # aux B fragment(s): 184..187 (and 188..191 when AUXS = 2)
+HEAD = 192              # 16 registers: the 5-row output head accumulator
+SIG = 208               # sigma pre-activation
+VL0, VL1, VOFF = 209, 210, 211  # LDS read bases (ring, ring + 64 KiB) + lane * 16; DMA source offset wave * 1024 + lane * 16 (advanced per row)
+N_VGPR = 212
+H0, H1 = 64, 96         # the two 32-register head hidden vectors (in Y once the trunk is done)
+
+KS, HS = 16, 8          # k-steps of a 256-wide / 128-wide input
+NW = 8                  # waves per workgroup = pieces per DMA row
+
+
+def aux_steps(tau):
+    return (8 + ((tau + 7) // 8) * 8 + 15) // 16
+
+
+class Tile:
+    """One chunk of the stream = one output tile: pieces [p0, p0 + n), the MFMA order, the B register of every MFMA, what happens to
+    the accumulator afterwards."""
+
+    def __init__(self, p0, bregs, n_aux, acc, c0, epi, out, name):
+        self.p0, self.n = p0, len(bregs)
+        # MFMA order: aux k-steps first (their B operand is always ready: one more gap for the producing epilogue)
+        order = list(range(self.n - n_aux, self.n)) + list(range(self.n - n_aux))
+        self.pieces = [p0 + k for k in order]
+        self.bregs = [bregs[k] for k in order]
+        self.acc, self.c0, self.epi, self.out, self.name = acc, c0, epi, out, name
+
+
+def stage_list(auxs):
+    """The chunk list of FwdStream<AUXS> (mlp_layout.h) with the register assignment of this kernel."""
+    tiles, p, tno = [], 0, 0
+    auxb = [AUX + 4 * a for a in range(auxs)]
+
+    def dense(inp, ks, ntiles, epi, outbase, name):
+        nonlocal p, tno
+        for t in range(ntiles):
+            b = [inp + 4 * k for k in range(ks)] + auxb
+            out = [outbase + 8 * t + q for q in range(8)] if outbase is not None else None
+            tiles.append(Tile(p, b, auxs, ACC[tno & 1], True, epi, out, f"{name}.{t}"))
+            p += len(b)
+            tno += 1
+
+    head_started = [False]
+
+    def head(inp, with_aux, name):
+        nonlocal p
+        b = [inp + 4 * k for k in range(HS)] + (auxb if with_aux else [])
+        tiles.append(Tile(p, b, auxs if with_aux else 0, HEAD, not head_started[0], None, None, name))
+        head_started[0] = True
+        p += len(b)
+
+    for l in range(7):
+        dense(X if l % 2 == 0 else Y, KS, 8, "sin", Y if l % 2 == 0 else X, f"L{l + 1}")
+    dense(Y, KS, 8, "id", X, "feats")          # a7 (in Y) -> feats (in X)
+    dense(Y, KS, 1, "sigma", None, "sigma")
+    dense(X, KS, 4, "sin", H0, "rgbh")
+    head(H0, False, "Hr")
+    dense(X, KS, 4, "sin", H1, "s1")
+    dense(H1, HS, 4, "sin", H0, "s2")
+    dense(H0, HS, 4, "sin", H1, "s3")
+    head(H1, False, "Hs")
+    dense(X, KS, 4, "sin", H0, "e1")
+    head(H0, True, "Hb")
+    return tiles, p
+
+
+class Ins:
+    __slots__ = ("op", "a", "text")
+
+    def __init__(self, op, a, text):
+        self.op, self.a, self.text = op, a, text
+
+
+class Core:
+    def __init__(self, auxs, R=128, PF=5, GROUP=2, FILL=2, ablate=()):
+        assert R % NW == 0 and PF + 1 <= NA
+        self.auxs, self.R, self.PF, self.GROUP, self.FILL = auxs, R, PF, GROUP, FILL
+        self.ablate = set(ablate)  # timing experiments only (results are wrong): nodma, nobarrier, noepi, noread, nowaitl
+        self.tiles, self.n_pieces = stage_list(auxs)
+        self.ins = []
+        self.stats = {}
+        self._build()
+
+    # ---- emission helpers ------------------------------------------------------------------------------------------------------
+    def _e(self, op, a, text):
+        self.ins.append(Ins(op, a, text))
+
+    def mfma(self, acc, areg, breg, c0):
+        c = "0" if c0 else f"v[{acc}:{acc + 15}]"
+        self._e("mfma", (acc, areg, breg, c0), f"MF v[{acc}:{acc + 15}], v[{areg}:{areg + 3}], v[{breg}:{breg + 3}], {c}")
+
+    def dsread(self, dst, slot):
+        base, off = (VL0, slot * 1024) if slot < 64 else (VL1, (slot - 64) * 1024)
+        self._e("dsread", (dst, slot), f"ds_read_b128 v[{dst}:{dst + 3}], v{base} offset:{off}")
+
+    def waitl(self, n):
+        self._e("waitl", (n,), f"s_waitcnt lgkmcnt({n})")
+
+    def sync(self, vm, need_rows):
+        self._e("sync", (vm, need_rows), f"s_waitcnt vmcnt({vm})")
+        self._e("barrier", (), "s_barrier")
+
+    def dma_row(self, j, partial):
+        # row j: wave w fetches piece 8 j + w into ring slot (8 j + w) % R; VOFF already holds w * 1024 + lane * 16 + j * 8192
+        imm = ((NW * j) % self.R) * 1024
+        if partial is not None:  # ragged last row: waves >= partial skip it (s_cbranch around the request; SCC from s_cmp)
+            self._e("dma_pred", (j, partial), f"s_cmp_lt_u32 %[wave], {partial}")
+            self._e("dma_br", (j,), f"s_cbranch_scc0 .Lskip_row{j}_%=")
+        self._e("m0", (j,), f"s_add_u32 m0, %[wb], {imm}")
+        self._e("nop", (0,), "s_nop 0")
+        self._e("dma", (j, partial), f"global_load_lds_dwordx4 v{VOFF}, %[sb]")
+        if partial is not None:
+            self._e("label", (j,), f".Lskip_row{j}_%=:")
+        self._e("voff", (), f"v_add_u32 v{VOFF}, 0x2000, v{VOFF}")
+
+    # ---- the schedule ----------------------------------------------------------------------------------------------------------
+    def _build(self):
+        T, R, PF, G = self.tiles, self.R, self.PF, self.GROUP
+        # global MFMA list
+        mf = []  # (tile index, k in tile)
+        for ti, t in enumerate(T):
+            for k in range(t.n):
+                mf.append((ti, k))
+        N = len(mf)
+        assert N == self.n_pieces
+        first_of_tile = {}
+        last_of_tile = {}
+        for i, (ti, k) in enumerate(mf):
+            first_of_tile.setdefault(ti, i)
+            last_of_tile[ti] = i
+        n_rows = (self.n_pieces + NW - 1) // NW
+        partial_row = n_rows - 1 if self.n_pieces % NW else None
+        partial_n = self.n_pieces % NW
+
+        self.rows_issued = 0
+        pending_rows = []  # rows allowed but not yet emitted
+
+        def allow_rows(free_below):
+            # ring slots of pieces < free_below may be overwritten: row j writes pieces [8 j, 8 j + 8) over pieces 8 j - R ...
+            j = self.rows_issued + len(pending_rows)
+            while j < n_rows and NW * (j + 1) - R <= free_below:
+                pending_rows.append(j)
+                j += 1
+
+        def emit_row():
+            j = pending_rows.pop(0)
+            self.dma_row(j, partial_n if j == partial_row else None)
+            self.rows_issued += 1
+
+        def sync_for(first_tile):
+            last = min(first_tile + G, len(T)) - 1
+            need = (T[last].p0 + T[last].n + NW - 1) // NW  # rows 0 .. need-1 must have landed
+            # every row allowed so far is emitted before the wait (program order = count order)
+            while pending_rows:
+                emit_row()
+            issued = self.rows_issued
+            assert issued >= need, (first_tile, issued, need)
+            vm = issued - need
+            if partial_row is not None and issued > partial_row and need <= partial_row:
+                vm -= 1  # waves that skipped the ragged row have one request fewer in flight
+            vm = max(vm, 0)
+            assert vm <= 63
+            self.sync(vm, need)
+
+        # epilogue queue: entries (earliest gap, kind, args)
+        epi_q = []
+
+        def queue_epilogue(ti):
+            t = T[ti]
+            g0 = last_of_tile[ti] + 2
+            a = t.acc
+            if t.epi == "sin":
+                seq = []
+                # s0 s1 s2 c0 s3 s4 c1 ...: every cvt_pk is separated from its second sin by one instruction (trans -> VALU use)
+                order = [("sin", 0), ("sin", 1)]
+                for q in range(8):
+                    if q < 7:
+                        order.append(("sin", 2 * q + 2))
+                    order.append(("pk", q))
+                    if q < 7:
+                        order.append(("sin", 2 * q + 3))
+                for kind, v in order:
+                    seq.append((kind, v))
+                for kind, v in seq:
+                    epi_q.append([g0, kind, (a, v, t.out)])
+            elif t.epi == "id":
+                for q in range(8):
+                    epi_q.append([g0, "pk", (a, q, t.out)])
+            elif t.epi == "sigma":
+                epi_q.append([g0, "mov", (SIG, a)])
+
+        written_at = {}   # VGPR -> index in self.ins of the VALU instruction that last wrote it
+        trans_at = {}     # VGPR -> index of a v_sin that wrote it
+
+        def emit_epi(item):
+            _, kind, args = item
+            if kind == "sin":
+                a, g, _ = args
+                self._e("sin", (a + g,), f"v_sin_f32 v{a + g}, v{a + g}")
+                trans_at[a + g] = len(self.ins) - 1
+                written_at[a + g] = len(self.ins) - 1
+            elif kind == "pk":
+                a, q, out = args
+                for src in (a + 2 * q, a + 2 * q + 1):  # trans -> VALU use: one instruction in between
+                    if src in trans_at and len(self.ins) - trans_at[src] < 2:
+                        self._e("nop", (0,), "s_nop 0")
+                self._e("pk", (out[q], a + 2 * q, a + 2 * q + 1), f"PK v{out[q]}, v{a + 2 * q}, v{a + 2 * q + 1}")
+                written_at[out[q]] = len(self.ins) - 1
+            elif kind == "mov":
+                d, s = args
+                self._e("mov", (d, s), f"v_mov_b32 v{d}, v{s}")
+                written_at[d] = len(self.ins) - 1
+
+        def flush_producers(regs, gap):
+            """everything in the queue up to the last instruction that writes one of `regs` must be emitted now"""
+            last = -1
+            for qi, it in enumerate(epi_q):
+                if it[1] == "pk" and it[2][2][it[2][1]] in regs:
+                    last = qi
+            forced = 0
+            for _ in range(last + 1):
+                it = epi_q.pop(0)
+                assert it[0] <= gap + 1, ("epilogue needed before its accumulator is ready", it, gap)
+                emit_epi(it)
+                forced += 1
+            return forced
+
+        def flush_acc(acc):
+            """a tile is about to start on accumulator `acc`: the epilogue that still reads it must be out first"""
+            last = -1
+            for qi, it in enumerate(epi_q):
+                if (it[1] in ("sin", "pk") and it[2][0] == acc) or (it[1] == "mov" and it[2][1] == acc):
+                    last = qi
+            for _ in range(last + 1):
+                emit_epi(epi_q.pop(0))
+            return last + 1
+
+        # ---- preamble: request the first rows, make the first group visible, start the A-fragment pipeline
+        self._e("savem0", (), "s_mov_b32 %[m0save], m0")
+        allow_rows(0)
+        sync_done_for = -1
+        forced_total = 0
+
+        def read_for(i):
+            ti, k = mf[i]
+            t = T[ti]
+            nonlocal sync_done_for
+            if ti > sync_done_for and ti % G == 0 and k == 0:
+                sync_for(ti)
+                sync_done_for = ti + G - 1
+                return True
+            return False
+
+        for i in range(min(PF, N)):
+            read_for(i)
+            ti, k = mf[i]
+            self.dsread(AR0 + 4 * (i % NA), T[ti].pieces[k] % R)
+        for i in range(N):
+            ti, k = mf[i]
+            t = T[ti]
+            # B operand ready?  (VALU write -> MFMA read: 2 wait states)
+            breg = t.bregs[k]
+            if k == 0 and t.c0:
+                forced_total += flush_acc(t.acc)
+            forced_total += flush_producers(set(range(breg, breg + 4)), i - 1)
+            recent = [written_at.get(r, -10) for r in range(breg, breg + 4)]
+            dist = len(self.ins) - max(recent)
+            if dist < 3:
+                self._e("nop", (2 - dist + 1,), f"s_nop {2 - dist + 1}")
+            self.waitl(min(PF - 1, N - 1 - i))
+            self.mfma(t.acc, AR0 + 4 * (i % NA), breg, t.c0 and k == 0)
+            if k == t.n - 1 and t.epi is not None:
+                queue_epilogue(ti)
+            # ---- gap(i)
+            if i + PF < N:
+                did_sync = read_for(i + PF)
+                if did_sync:
+                    # the barrier proves every wave has issued MFMA i: all tiles before the current one are consumed
+                    allow_rows(T[ti].p0)
+                tj, kj = mf[i + PF]
+                self.dsread(AR0 + 4 * ((i + PF) % NA), T[tj].pieces[kj] % R)
+            if pending_rows:
+                emit_row()
+            n = 0
+            while epi_q and n < self.FILL and epi_q[0][0] <= i:
+                emit_epi(epi_q.pop(0))
+                n += 1
+        assert not epi_q and not pending_rows and self.rows_issued == n_rows
+        self._e("nop", (15,), "s_nop 15")  # the head accumulator is read by compiler code right after the statement
+        self._e("restm0", (), "s_mov_b32 m0, %[m0save]")
+        self.stats = dict(mfma=N, instructions=len(self.ins), forced_epilogue=forced_total, rows=n_rows,
+                          barriers=sum(1 for x in self.ins if x.op == "barrier"), nops=sum(1 for x in self.ins if x.op == "nop"))
+
+    # ---- text --------------------------------------------------------------------------------------------------------------------
+    def text(self):
+        ab = self.ablate
+        drop = set()
+        if "nodma" in ab:
+            drop |= {"m0", "dma", "voff", "dma_pred", "dma_br", "label"}
+        if "nobarrier" in ab:
+            drop |= {"barrier"}
+        if "nosync" in ab:
+            drop |= {"barrier", "sync"}
+        if "noepi" in ab:
+            drop |= {"sin", "pk"}
+        if "noread" in ab:
+            drop |= {"dsread", "waitl"}
+        if "nowaitl" in ab:
+            drop |= {"waitl"}
+        if "nonop" in ab:
+            drop |= {"nop"}
+        out = []
+        seen_first_sync = False
+        for x in self.ins:
+            if x.op == "sync":
+                seen_first_sync = True
+            if x.op in drop and (seen_first_sync or x.op not in ("m0", "dma", "voff")):
+                continue
+            out.append(x.text)
+        return out
+
+    def inc_file(self):
+        lines = ["// GENERATED by csrc/gen/fwd_core.py -- do not edit (tests/test_fwd_core.py checks it is current).",
+                 f"// fused forward core, AUXS = {self.auxs}: {self.stats['mfma']} MFMAs, {self.stats['instructions']} instructions, "
+                 f"{self.stats['barriers']} rendezvous, {self.stats['rows']} LDS-DMA rows, ring of {self.R} pieces, A fragments {self.PF} ahead.",
+                 "// Operands: %[sb] stream base (SGPR pair), %[wb] LDS ring address + wave * 1024, %[wave] wave index, %[m0save] scratch SGPR."]
+        lines += ['"' + t + '\\n"' for t in self.text()]
+        return "\n".join(lines) + "\n"
+
+    @staticmethod
+    def clobber_file():
+        """registers the statement writes besides its operands (X = v[0:63], the aux fragments, v[192:211] are operands)"""
+        regs = ", ".join(f'"v{r}"' for r in range(Y, AUX))
+        return "// GENERATED by csrc/gen/fwd_core.py: clobber list of the forward core\n" + regs + ', "memory", "scc"\n'
+
+
+# =================================================================================================================================
+# Lane-accurate interpreter (CPU validation)
+# =================================================================================================================================
+LANE = np.arange(64)
+ROW_OF = (np.arange(16)[None, :] & 3) + 8 * (np.arange(16)[None, :] >> 2) + 4 * (LANE[:, None] >> 5)  # [lane, g]
+
+
+def bf16_bits(x):
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint32)
+
+
+def bf16_to_f32(b):
+    return (np.asarray(b, np.uint32) << 16).view(np.float32)
+
+
+def frag_to_f32(regs4):
+    """4 registers [4, 64] of packed bf16 pairs -> [64 lanes, 8] fp32"""
+    lo = bf16_to_f32(regs4 & 0xFFFF)
+    hi = bf16_to_f32(regs4 >> 16)
+    out = np.empty((64, 8), np.float32)
+    out[:, 0::2] = lo.T
+    out[:, 1::2] = hi.T
+    return out
+
+
+def f32_to_frag(v):
+    """[64, 8] fp32 -> 4 registers [4, 64] uint32 (bf16 RNE, element 0 in the low half)"""
+    b = bf16_bits(v)
+    return (b[:, 0::2] | (b[:, 1::2] << 16)).T.astype(np.uint32)
+
+
+class Machine:
+    """Executes the instruction list of one wave.  The ring is shared by the 8 waves of the workgroup: a DMA row copies the 8 pieces
+    all waves fetch.  Protocol checks: a piece may only be read after a sync that covers its row, and a ring slot may only be
+    overwritten once the MFMA that consumes its previous content has been issued (by this wave; the barrier in the sync extends that to
+    all waves because a row is only requested after a barrier that follows that MFMA -- checked through `barrier_seen_after`)."""
+
+    def __init__(self, core, stream_bits):
+        self.c = core
+        self.stream = stream_bits  # [n_pieces, 64 lanes, 4] uint32
+        self.v = np.zeros((256, 64), np.uint32)
+        self.ring_piece = [-1] * core.R
+        self.ring = np.zeros((core.R, 64, 4), np.uint32)
+        self.synced_rows = 0
+        self.consumed = np.zeros(core.n_pieces, bool)   # piece's MFMA issued
+        self.consumed_before_barrier = np.zeros(core.n_pieces, bool)
+        self.pending_reads = []  # (dst, slot, piece)
+        self.ar_piece = {}
+        self.issued = {"full": [], "skip": []}  # DMA rows requested by a wave that takes / skips the ragged last row
+
+    def f(self, r):
+        return self.v[r].view(np.float32)
+
+    def run(self):
+        c = self.c
+        for ins in c.ins:
+            op, a = ins.op, ins.a
+            if op == "mfma":
+                acc, areg, breg, c0 = a
+                assert not any(d == areg for d, _, _ in self.pending_reads), "MFMA reads an A fragment still in flight"
+                piece = self.ar_piece[areg]
+                assert not self.consumed[piece]
+                self.consumed[piece] = True
+                A = frag_to_f32(self.v[areg:areg + 4]).astype(np.float64)  # [lane, j] : row = lane & 31, k = 8 h + j
+                B = frag_to_f32(self.v[breg:breg + 4]).astype(np.float64)
+                Am = np.zeros((32, 16))
+                Bm = np.zeros((16, 32))
+                for h in range(2):
+                    Am[:, 8 * h:8 * h + 8] = A[32 * h:32 * h + 32]
+                    Bm[8 * h:8 * h + 8, :] = B[32 * h:32 * h + 32].T
+                D = Am @ Bm
+                d = D[ROW_OF, (LANE & 31)[:, None]]  # [lane, g]
+                for g in range(16):
+                    prev = np.zeros(64, np.float32) if c0 else self.f(acc + g).copy()
+                    self.v[acc + g] = (prev.astype(np.float64) + d[:, g]).astype(np.float32).view(np.uint32)
+            elif op == "dsread":
+                dst, slot = a
+                piece = self.ring_piece[slot]
+                assert piece >= 0, ("read of an empty ring slot", slot)
+                assert piece // NW < self.synced_rows, ("piece read before the sync that covers its DMA row", piece, self.synced_rows)
+                self.pending_reads.append((dst, slot, piece))
+            elif op == "waitl":
+                keep = a[0]
+                while len(self.pending_reads) > keep:
+                    dst, slot, piece = self.pending_reads.pop(0)
+                    assert self.ring_piece[slot] == piece, "ring slot overwritten while a read of it was in flight"
+                    self.v[dst:dst + 4] = self.ring[slot].T
+                    self.ar_piece[dst] = piece
+            elif op == "sync":
+                vm, need = a
+                for cls, rows in self.issued.items():  # loads return in order: all but the vm newest requests have landed
+                    landed = set(rows[:max(len(rows) - vm, 0)])
+                    missing = [r for r in range(need) if r in rows and r not in landed]
+                    assert not missing, ("vmcnt lets a needed row stay in flight", cls, vm, need, missing)
+                self.synced_rows = max(self.synced_rows, need)
+            elif op == "barrier":
+                self.consumed_before_barrier = self.consumed.copy()
+            elif op == "dma":
+                j, partial = a
+                self.issued["full"].append(j)
+                if partial is None:
+                    self.issued["skip"].append(j)
+                for w in range(NW if partial is None else partial):
+                    p = NW * j + w
+                    slot = p % c.R
+                    old = self.ring_piece[slot]
+                    assert old < 0 or self.consumed_before_barrier[old], ("DMA overwrites a piece not yet consumed by every wave", old, p)
+                    self.ring_piece[slot] = p
+                    self.ring[slot] = self.stream[p]
+            elif op == "sin":
+                r = a[0]
+                self.v[r] = np.sin(2 * np.pi * self.f(r).astype(np.float64)).astype(np.float32).view(np.uint32)
+            elif op == "pk":
+                d, s0, s1 = a
+                self.v[d] = (bf16_bits(self.f(s0)) | (bf16_bits(self.f(s1)) << 16)).astype(np.uint32)
+            elif op == "mov":
+                d, s = a
+                self.v[d] = self.v[s]
+        assert self.consumed.all()
+
+
+def main():
+    import argparse
+
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("--out", default=None, help="output directory (default: csrc/)")
+    ap.add_argument("--ablate", default="", help="comma list of timing ablations: nodma,nobarrier,nosync,noepi,noread,nowaitl,nonop")
+    ap.add_argument("--R", type=int, default=128)
+    ap.add_argument("--PF", type=int, default=5)
+    ap.add_argument("--GROUP", type=int, default=2)
+    ap.add_argument("--FILL", type=int, default=2)
+    a = ap.parse_args()
+    here = os.path.dirname(os.path.abspath(__file__))
+    out_dir = a.out or os.path.dirname(here)
+    os.makedirs(out_dir, exist_ok=True)
+    for auxs in (1, 2):
+        c = Core(auxs, R=a.R, PF=a.PF, GROUP=a.GROUP, FILL=a.FILL, ablate=[x for x in a.ablate.split(",") if x])
+        path = os.path.join(out_dir, f"mlp_fwd_core_a{auxs}.inc")
+        with open(path, "w") as f:
+            f.write(c.inc_file())
+        print(path, c.stats)
+    with open(os.path.join(out_dir, "mlp_fwd_core_clobbers.inc"), "w") as f:
+        f.write(Core.clobber_file())
+
+
+if __name__ == "__main__":
+    sys.exit(main())
