@@ -341,6 +341,8 @@ class Core:
             drop |= {"waitl"}
         if "nonop" in ab:
             drop |= {"nop"}
+        if "empty" in ab:
+            return ["s_mov_b32 %[m0save], m0", "v_mov_b32 v208, 0"] + [f"v_mov_b32 v{HEAD + g}, 0" for g in range(16)]
         out = []
         seen_first_sync = False
         for x in self.ins:

@@ -21,3 +21,10 @@ for name, acts in (("inference", None), ("save8", ops.acts_workspace(65536, 256,
     e1.record(); torch.cuda.synchronize()
     out[name] = round(e0.elapsed_time(e1) / 50 * 1e3, 1)
 print(os.path.basename(os.environ.get("SATRENDER_LIB", "default")), out)
+if os.environ.get("SR_CORE_TIMING"):  # libraries built with -DSR_CORE_TIMING return shader cycles per wave in sigma / sun_v
+    a, sg, sv, b = run(None)
+    torch.cuda.synchronize()
+    c, p = sg[:2048].cpu(), sv[:2048].cpu()
+    rt = b[:2048].cpu()
+    print(f"  core: {rt.mean() / 100:.1f} us of the 100 MHz clock -> shader clock {c.mean() / rt.mean() * 0.1:.3f} GHz")
+    print(f"  core cycles per wave: mean {c.mean():.0f} min {c.min():.0f} max {c.max():.0f}  per MFMA {c.mean() / 1406:.1f} (max {c.max() / 1406:.1f}) | prologue cycles: mean {p.mean():.0f} max {p.max():.0f}")
