@@ -76,7 +76,9 @@ class _InferenceFn(torch.autograd.Function):
 
 
 def render_rays_train(models, args, rays, ts, rng):
-    """``render_rays`` with grad (the NeRF_pl.forward path, main.py:60-75): same draws, same dict, differentiable."""
+    """``render_rays`` with grad (the NeRF_pl.forward path, main.py:60-75): same draws, same dict, differentiable.
+    The backward's saved state follows ``train._fmt_of(args)``: 8-bit workspaces by default in the 'bf16' / 'f16' modes (gradients
+    ~2e-2 of the reference's), ``args.bwd_fmt = 16`` for the 16-bit state (~1e-2 / 7e-3), 'bf16x3' + ``bwd_fmt = 32`` for 2e-4."""
     from .rendering import _mode_of
 
     n_samples, n_importance = args.n_samples, args.n_importance

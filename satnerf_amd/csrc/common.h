@@ -38,6 +38,10 @@ __device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {
   f32x2 v = {a, b};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
 }
+// the same with saturation to +-65504 (the fp16 weight stream: a scaled weight beyond the fp16 range must not become inf; NaN stays NaN)
+__device__ __forceinline__ uint32_t pack_f16x2_sat(float a, float b) {
+  return pack_f16x2(__builtin_fminf(__builtin_fmaxf(a, -65504.f), 65504.f), __builtin_fminf(__builtin_fmaxf(b, -65504.f), 65504.f));
+}
 __device__ __forceinline__ float bf16_lo_to_f32(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf16_hi_to_f32(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 

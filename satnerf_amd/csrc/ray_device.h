@@ -85,14 +85,23 @@ __device__ __forceinline__ float philox_uniform(unsigned long long seed, long r,
 // check in -- every other workgroup has read by then -- stores step + 1 and resets the arrival counter for the next launch.
 // Contains a workgroup barrier: call it from uniform control flow.
 // modulo > 0: the counter wraps (a cursor over the batches of an epoch).
-__device__ __forceinline__ void tick_when_all_read(float* counter, uint32_t step_read, uint32_t modulo = 0u) {
+// The counter is a float (the block also carries the learning rate): integers are exact up to 2^24 only, where += 1 would stop
+// advancing (jitter, bank chunk and Adam step would freeze after ~25 minutes of 90-us replays).  next_step() wraps into
+// [2^23, 2^24) instead, keeping the value's residue modulo `keep_mod` (the bank's chunk count): chunk order is unbroken, the
+// jitter stream repeats after 2^23 steps, and Adam's bias corrections are 1 to fp32 precision from ~10^4 steps on.
+__device__ __forceinline__ uint32_t next_step(uint32_t step, uint32_t keep_mod = 1u) {
+  uint32_t next = step + 1u;
+  if (next >= (1u << 24)) next = (1u << 23) + (next - (1u << 23)) % (keep_mod ? keep_mod : 1u);
+  return next;
+}
+__device__ __forceinline__ void tick_when_all_read(float* counter, uint32_t step_read, uint32_t modulo = 0u, uint32_t keep_mod = 1u) {
   asm volatile("" ::"v"(step_read));  // the value has arrived
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned* arrive = reinterpret_cast<unsigned*>(counter + 3);
     __threadfence();
     if (atomicAdd(arrive, 1u) == gridDim.x - 1) {
-      counter[0] = (float)(modulo != 0u && step_read + 1u >= modulo ? 0u : step_read + 1u);
+      counter[0] = (float)(modulo != 0u ? (step_read + 1u >= modulo ? 0u : step_read + 1u) : next_step(step_read, keep_mod));
       atomicExch(arrive, 0u);
     }
   }

@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(256) pack_stream_kernel(const float* __restric
   const float v1 = i1 >= 0 ? src[i1] * scale[i + 1] : 0.f;
   uint32_t h, l;
   split_bf16x2(v0, v1, h, l);
-  if (i < n_f16) h = pack_f16x2(v0, v1);  // the fp16 forward stream (SR_MODE_F16)
+  if (i < n_f16) h = pack_f16x2_sat(v0, v1);  // the fp16 forward stream (SR_MODE_F16), saturating
   reinterpret_cast<uint32_t*>(hi)[i >> 1] = h;
   if (lo) reinterpret_cast<uint32_t*>(lo)[i >> 1] = l;
 }
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(256) pack_all_kernel(const float* __restrict__
                                                       const float* __restrict__ fscale, long nf, float* __restrict__ fout, float* tick, long n_f16) {
 #pragma clang fp contract(off)
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (tick != nullptr && t == 0) tick[0] += 1.0f;  // optimizer step counter of the captured training step
+  if (tick != nullptr && t == 0) tick[0] = (float)next_step((uint32_t)tick[0]);  // optimizer step counter of the captured training step (exact past 2^24: ray_device.h)
   const long i = t * 2;
   if (i < n) {
     const int i0 = idx[i], i1 = idx[i + 1];
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(256) pack_all_kernel(const float* __restrict__
     const float v1 = i1 >= 0 ? src[i1] * scale[i + 1] : 0.f;
     uint32_t h, l;
     split_bf16x2(v0, v1, h, l);
-    if (i < n_f16) h = pack_f16x2(v0, v1);
+    if (i < n_f16) h = pack_f16x2_sat(v0, v1);
     reinterpret_cast<uint32_t*>(hi)[t] = h;
     if (lo) reinterpret_cast<uint32_t*>(lo)[t] = l;
   } else {

@@ -162,24 +162,20 @@ def inference(model, args, rays_xyz, z_vals, rays_d=None, sun_d=None, rays_t=Non
             "sky": sky, "beta": beta}
 
 
-_ts_checked = {}
-
-
 def validate_ts(ts, models):
     """``nn.Embedding`` raises IndexError on an out-of-range index (rendering.py:100); the fused kernels index the table
-    directly, so the range is checked here -- once per distinct ``ts`` tensor (it costs a device sync), never inside a hipGraph
-    capture.  Returns ``ts``."""
+    directly, so the range is checked here with one fused min/max reduction and a device sync -- on EVERY call with a caller-owned
+    tensor (a pointer / version key cannot identify a tensor's contents: the caching allocator hands a fresh per-step ``ts`` the
+    previous one's address), never inside a hipGraph capture.  Objects that own their indices (``RayBank``, a ``GraphedRenderer``
+    bank) are checked once by their owners.  Returns ``ts``."""
     emb = models.get("t") if isinstance(models, dict) else None
     if ts is None or emb is None or torch.cuda.is_current_stream_capturing():
         return ts
     vocab = (emb.weight if hasattr(emb, "weight") else emb).shape[0]
-    key = (ts.data_ptr(), ts.numel(), getattr(ts, "_version", 0), vocab)
-    if _ts_checked.get("key") != key:
-        if ts.numel():
-            lo, hi = int(ts.min()), int(ts.max())
-            if lo < 0 or hi >= vocab:
-                raise IndexError(f"ts holds image indices in [{lo}, {hi}] but the embedding has {vocab} rows (t_embbeding_vocab)")
-        _ts_checked["key"] = key
+    if ts.numel():
+        lo, hi = (int(v) for v in torch.aminmax(ts))
+        if lo < 0 or hi >= vocab:
+            raise IndexError(f"ts holds image indices in [{lo}, {hi}] but the embedding has {vocab} rows (t_embbeding_vocab)")
     return ts
 
 
@@ -507,8 +503,10 @@ class GraphedRenderer:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
+                keep = self._krng[1].clone() if self._krng is not None else None
                 self._run()  # warm-up outside capture: lazy initialisation (LDS attributes, index maps)
-                self._launches += 1
+                if keep is not None:  # the warm-up ticked the device counter: put it back, so the first replay renders chunk 0 / draws step 0
+                    self._krng[1].copy_(keep)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()

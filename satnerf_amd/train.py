@@ -163,6 +163,12 @@ class Trainer:
     graph, fused loss+gradient kernel, fused Adam over the flat buffer -- and, when ``noise_std == 0``, replays the whole
     forward+backward from ONE hipGraph (the step is ~25 launches of 5-350 us; eager launch gaps would dominate).
     Anything else goes through ``render_rays`` + autograd + the same flat buffers.
+
+    Saved state: ``mlp_mode`` 'bf16' and 'f16' keep the activations / pre-activation gradients between the forward, dX and
+    weight-gradient kernels in the 8-BIT workspaces (PHASE8 / MX8, csrc/mlp_layout.h) by default -- gradients within 2.1e-2 /
+    1.8e-2 of the reference's instead of 1.4e-2 / 7.3e-3 with the 16-bit state; pass ``args.bwd_fmt = 16`` for the latter
+    (~0.53 instead of ~0.42 ms per step), ``mlp_mode='bf16x3'`` (16-bit state) for outputs within 1e-4, ``bwd_fmt = 32`` for
+    gradients within 2e-4 (``_fmt_of``).
     """
 
     def __init__(self, models, args, world_size=1, lr=5e-4, loss_fn=None, use_graph=True, steps_per_epoch=None, lr_gamma=0.9,
@@ -172,11 +178,21 @@ class Trainer:
         of ``SatNerfLoss`` while epoch < ``warmup_epochs`` (main.py:128-131 hard-codes 2).  None = constant rate, SatNerfLoss
         from the first step (what bench.py measures)."""
         self._snerf = args.model == "s-nerf"
+        self._caller_args = args  # main.py:132 decays args.noise_std in place: the caller's object follows, also for s-nerf's private copy
+        if args.model == "sat-nerf" and steps_per_epoch is None:
+            import warnings
+
+            warnings.warn("Trainer(steps_per_epoch=None): constant learning rate and SatNerfLoss from the first step; main.py decays the rate "
+                          "by 0.9 per epoch and trains sat-nerf with SNerfLoss for 2 epochs -- pass steps_per_epoch = len(dataset) // batch_size",
+                          stacklevel=2)
         if self._snerf:  # s-nerf trains on the Sat-NeRF kernels: dead uncertainty head, 1-row zero embedding, SNerfLoss throughout
             from .rendering import _as_satnerf
 
             models, args = _as_satnerf(models, args)
         self.models, self.args, self.world, self.lr = models, args, world_size, lr
+        # the gradient all-reduce runs when there is more than one rank -- or, with SATNERF_FORCE_ALLREDUCE=1, also on a 1-rank
+        # process group (how the single-GPU test box exercises the captured RCCL path)
+        self._collective = world_size > 1 or (os.environ.get("SATNERF_FORCE_ALLREDUCE", "0") == "1" and dist.is_available() and dist.is_initialized())
         self.lr0, self.lr_gamma, self.steps_per_epoch, self.warmup_epochs = lr, lr_gamma, steps_per_epoch, warmup_epochs
         if args.model == "sat-nerf" and args.n_importance > 0 and loss_fn is None:
             # metrics.py:22 multiplies weights_fine (N,S+I,1) with beta_coarse (N,S,1): the reference cannot train this combination
@@ -263,8 +279,8 @@ class Trainer:
             loss = torch.cat([loss.view(-1), self._sc_pass(rays, ts, z, noise_std).view(-1)])
         if depth is not None:
             loss = torch.cat([loss.view(-1), self._depth_pass(*depth, noise_std * 0.9).view(-1)])  # main.py:132 decays the noise first
-        if self._adam_in_graph:  # the update rides in the same graph (single GPU, or RCCL captured: SATNERF_GRAPH_ALLREDUCE=1)
-            if self.world > 1:
+        if self._adam_in_graph:  # the update rides in the same graph (single GPU, or the RCCL all-reduce captured with it)
+            if self._collective:
                 dist.all_reduce(self.state.grads, op=dist.ReduceOp.SUM)
             # lr < 0: the kernel reads the current rate from sched[1], so a scheduler can change it under graph replay
             ops.adam_step_graph(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.adam_state, lr=-1.0,
@@ -365,7 +381,9 @@ class Trainer:
     def _apply_schedule(self):
         """Write [lr, warm-up flag] of the step about to run into the device-side schedule block when they changed (once per epoch)."""
         if self.steps_per_epoch:
-            self.lr = self.lr0 * self.lr_gamma ** self.current_epoch()  # StepLR(step_size=1, gamma)
+            # StepLR(step_size=1, gamma) is stepped by Lightning AFTER an epoch's last batch: step k (0-based) trains at
+            # gamma ** (k // steps_per_epoch); main.py:121's += 1 only shifts the SNerfLoss test (current_epoch / warming_up)
+            self.lr = self.lr0 * self.lr_gamma ** (self.n_steps // int(self.steps_per_epoch))
         host = (float(self.lr), 1.0 if self.warming_up() else 0.0)
         if host != self._sched_host:
             self.adam_state[1:3].copy_(torch.tensor(host, dtype=torch.float32))
@@ -409,13 +427,13 @@ class Trainer:
     def _capture(self, inputs, banks=None):
         self._static = tuple(t.clone() for t in inputs)
         self._graph_banks = tuple(banks) if banks else None
-        # data parallel: by default the gradient all-reduce and Adam are issued eagerly after the replay (works with every backend;
-        # ~2 launches + the collective's own latency per step).  SATNERF_GRAPH_ALLREDUCE=1 captures the RCCL all-reduce and the
-        # update into the step's graph (NCCL/RCCL collectives are capturable; gloo is not) -- opt-in because it cannot be exercised
-        # on the single-GPU development box.
-        capture_collective = (self.world > 1 and os.environ.get("SATNERF_GRAPH_ALLREDUCE", "0") == "1" and dist.is_initialized()
-                              and dist.get_backend() == "nccl")
-        self._adam_in_graph = self.world == 1 or capture_collective
+        # data parallel: with the RCCL backend ("nccl") the gradient all-reduce and the Adam update are captured INTO the step's graph
+        # (NCCL / RCCL collectives are capturable): a step is one replay, no eager launches between steps.  Other backends (gloo
+        # cannot be captured) -- or SATNERF_GRAPH_ALLREDUCE=0, or a capture that fails -- fall back to the eager all-reduce + Adam
+        # issued after the replay.
+        capture_collective = (self._collective and os.environ.get("SATNERF_GRAPH_ALLREDUCE", "1") != "0" and dist.is_initialized()
+                              and dist.get_backend() == "nccl" and not getattr(self, "_collective_capture_failed", False))
+        self._adam_in_graph = (not self._collective) or capture_collective
         self._kernel_rng = float(self.args.noise_std) == 0.0  # (a noisy step still draws randn from torch's generator)
         snapshot = (self.state.params.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.adam_state.clone())
         def run():
@@ -439,8 +457,18 @@ class Trainer:
         from . import ops
 
         self._graph = torch.cuda.CUDAGraph()
-        with ops.graph_capture(self._graph):
-            self._static_loss = run()
+        try:
+            with ops.graph_capture(self._graph):
+                self._static_loss = run()
+        except RuntimeError:
+            if not capture_collective:
+                raise
+            # the collective could not be captured on this stack: eager all-reduce + Adam after the replay instead
+            self._collective_capture_failed = True
+            self._graph = None
+            torch.cuda.synchronize()
+            self.state.zero_grad()
+            return self._capture(inputs, banks=banks)
         self.state.zero_grad()  # capture does not execute
 
     def step_from_bank(self, bank, depth_bank=None):
@@ -513,7 +541,7 @@ class Trainer:
                 inputs = tuple(t.contiguous() for t in inputs)
                 loss = self._forward_backward(*inputs[:3], depth=inputs[3:] or None)
             in_graph = self._adam_in_graph and self._graph is not None and self.use_graph and float(self.args.noise_std) == 0.0
-            if self.world > 1 and not self._adam_in_graph:
+            if self._collective and not self._adam_in_graph:
                 dist.all_reduce(self.state.grads, op=dist.ReduceOp.SUM)
             self.n_steps += 1
             if not in_graph and not self._adam_in_graph:  # (an eager direct step after a capture already stepped Adam)
@@ -544,7 +572,7 @@ class Trainer:
                 w = 1.0 if getattr(self.args, "ds_noweights", False) else d_depths[:, 1]
                 loss = loss + depth_loss(res_d, d_depths[:, 0], w, float(self.args.ds_lambda))
             loss.backward()
-            if self.world > 1:
+            if self._collective:
                 dist.all_reduce(self.state.grads, op=dist.ReduceOp.SUM)
             if self.state.params.is_cuda:
                 self.n_steps += 1
@@ -556,5 +584,7 @@ class Trainer:
             if hasattr(m, "mark_weights_changed"):
                 m.mark_weights_changed()
         self.args.noise_std *= 0.9  # main.py:132
+        if self._caller_args is not self.args:
+            self._caller_args.noise_std = self.args.noise_std
         self.last_loss = loss if isinstance(loss, _LazyLoss) else loss.detach()
         return self.last_loss

@@ -81,10 +81,11 @@ def test_schedule_lr_decay_and_snerf_warmup_under_graph_replay():
     for k in range(9):
         before = tr.state.params.clone()
         loss = tr.step(rays, ts, target).item()
-        epoch = (k + 1) // 3
+        epoch = (k + 1) // 3  # what main.py:121-128 tests for the SNerfLoss warm-up (train_steps is incremented first)
+        lr_epoch = k // 3     # StepLR is stepped after an epoch's LAST batch: step k trains at gamma ** (k // steps_per_epoch)
         assert tr._graph is not None  # one capture serves every epoch
-        assert abs(tr.lr - 5e-4 * 0.9 ** epoch) < 1e-12
-        assert float(tr.sched[1]) == pytest.approx(5e-4 * 0.9 ** epoch, rel=1e-6) and float(tr.sched[2]) == (1.0 if epoch < 2 else 0.0)
+        assert abs(tr.lr - 5e-4 * 0.9 ** lr_epoch) < 1e-12
+        assert float(tr.sched[1]) == pytest.approx(5e-4 * 0.9 ** lr_epoch, rel=1e-6) and float(tr.sched[2]) == (1.0 if epoch < 2 else 0.0)
         rgb = tr.last_rgb
         mse = torch.mean((rgb - target) ** 2).item()
         if epoch < 2:  # metrics.SNerfLoss (lambda_sc = 0): plain MSE
@@ -92,7 +93,7 @@ def test_schedule_lr_decay_and_snerf_warmup_under_graph_replay():
         else:          # metrics.SatNerfLoss: > the MSE (log-beta term + 3/2)
             assert loss > 1.0 > mse
         step_size = (tr.state.params - before).abs().max().item()
-        seen.append((epoch, step_size))
+        seen.append((lr_epoch, step_size))
     # Adam's first updates are ~lr per coordinate: the largest update of an epoch's first step tracks the decayed rate
     assert seen[0][1] == pytest.approx(5e-4, rel=0.05)
     assert all(s <= 5e-4 * 0.9 ** e * 1.2 for e, s in seen)
@@ -249,6 +250,47 @@ def test_two_rank_trainer_step_on_one_gpu(tmp_path):
     upd = maxnorm_rel(tr.state.params.cpu() - _initial_params(args), r0["params"] - _initial_params(args))
     print(f"2-rank vs accumulated single process: params {err:.1e}, update {upd:.1e}")
     assert err < 1e-6 and upd < 1e-3
+
+
+def _nccl_one_rank_worker(rank, port, out_path, force):
+    import torch.distributed as dist
+
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", SATNERF_FORCE_ALLREDUCE="1" if force else "0")
+    torch.cuda.set_device(0)
+    if force:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    torch.manual_seed(0)
+    args = O.default_args(mlp_mode="bf16")
+    models = {"coarse": load_model(args).to(DEV), "t": torch.nn.Embedding(30, 4).to(DEV)}
+    tr = Trainer(models, args, world_size=1)
+    rays, ts = O.synthetic_rays(256, seed=33)
+    target = torch.rand(256, 3, generator=torch.Generator().manual_seed(34))
+    losses = [tr.step(rays.cuda(), ts.cuda(), target.cuda()).item() for _ in range(4)]
+    torch.cuda.synchronize()
+    torch.save({"params": tr.state.params.cpu(), "losses": losses, "graphed": tr._graph is not None, "collective": tr._collective,
+                "adam_in_graph": tr._adam_in_graph, "capture_failed": getattr(tr, "_collective_capture_failed", False)}, out_path)
+    if force:
+        dist.destroy_process_group()
+
+
+def test_rccl_allreduce_is_captured_into_the_step_graph(tmp_path):
+    """The data-parallel step's default with the RCCL backend: the all-reduce of the flat gradient and the Adam update are captured
+    into the step's hipGraph.  Exercised on the single GPU with a 1-rank "nccl" process group (SATNERF_FORCE_ALLREDUCE=1 makes the
+    1-rank trainer issue the collective): the capture succeeds, replays run, and the result equals the plain single-GPU trainer's
+    (an all-reduce over one rank is the identity, grad_scale 1)."""
+    import torch.multiprocessing as mp
+
+    a, b = str(tmp_path / "rccl.pt"), str(tmp_path / "plain.pt")
+    mp.spawn(_nccl_one_rank_worker, args=(_free_port(), a, True), nprocs=1, join=True)
+    mp.spawn(_nccl_one_rank_worker, args=(_free_port(), b, False), nprocs=1, join=True)
+    ra, rb = torch.load(a), torch.load(b)
+    assert ra["graphed"] and ra["collective"] and ra["adam_in_graph"] and not ra["capture_failed"]
+    assert rb["graphed"] and not rb["collective"]
+    # (two runs of the step are equal to rounding, not bit for bit: the embedding / loss reductions use atomics)
+    assert maxnorm_rel(ra["params"], rb["params"]) < 1e-6 and ra["losses"] == pytest.approx(rb["losses"], rel=1e-5)
 
 
 def _initial_params(args):

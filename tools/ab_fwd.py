@@ -8,6 +8,9 @@ args = data.default_args(mlp_mode="bf16")
 torch.manual_seed(0)
 m = load_model(args).to(dev); emb = torch.nn.Embedding(30, 4).to(dev)
 rays, ts = data.synthetic_rays(1024); rays, ts = rays.to(dev), ts.to(dev)
+if os.environ.get("ZERO_WEIGHTS"):  # DVFS experiment: all-zero operands draw less power
+    with torch.no_grad():
+        for p_ in m.parameters(): p_.zero_()
 hi, lo, l0 = m.packed("bf16")
 z = ops.ray_sample(rays, torch.rand(1024, 64, device=dev), 64)
 def run(acts=None):

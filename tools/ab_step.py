@@ -9,7 +9,11 @@ args = data.default_args(mlp_mode=os.environ.get("AB_MODE", "bf16"))
 if os.environ.get("AB_FMT"): args.bwd_fmt = int(os.environ["AB_FMT"])
 torch.manual_seed(0)
 models = {"coarse": load_model(args).to(dev), "t": torch.nn.Embedding(30, 4).to(dev)}
-tr = Trainer(models, args, use_graph=False)
+if os.environ.get("ZERO_WEIGHTS"):  # DVFS experiment: zero operands draw far less power (lr = 0 keeps them zero)
+    with torch.no_grad():
+        for p_ in models["coarse"].parameters(): p_.zero_()
+    models["coarse"].mark_weights_changed()
+tr = Trainer(models, args, use_graph=False, lr=0.0 if os.environ.get("ZERO_WEIGHTS") else 5e-4)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 rays, ts = data.synthetic_rays(n); rays, ts = rays.to(dev), ts.to(dev); tgt = torch.rand(n, 3, device=dev)
 for _ in range(10): tr.step(rays, ts, tgt)
