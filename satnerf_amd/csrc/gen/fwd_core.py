@@ -35,6 +35,11 @@ HEAD = 192              # 16 registers: the 5-row output head accumulator
 SIG = 208               # sigma pre-activation
 VL0, VL1, VOFF = 209, 210, 211  # LDS read bases (ring, ring + 64 KiB) + lane * 16; DMA source offset wave * 1024 + lane * 16 (advanced per row)
 N_VGPR = 212
+# SAVE8 (training forward, 8-bit workspaces of mlp_layout.h): two quads of store data, the PHASE8 magic constant, the workspace offset
+# of this lane (tile base + lane * 16, advanced to the unit being stored), the feats scale bytes, MX8 temporaries
+SV = (212, 216)
+KMAGIC, SOFF, EB, MXT, K128 = 220, 221, 222, 224, 228   # EB: 2 registers, MXT: 4 (max, exponent, 1/scale, scaled value); K128 = 128.0f
+N_VGPR_SAVE = 229
 H0, H1 = 64, 96         # the two 32-register head hidden vectors (in Y once the trunk is done)
 
 KS, HS = 16, 8          # k-steps of a 256-wide / 128-wide input
@@ -49,7 +54,8 @@ class Tile:
     """One chunk of the stream = one output tile: pieces [p0, p0 + n), the MFMA order, the B register of every MFMA, what happens to
     the accumulator afterwards."""
 
-    def __init__(self, p0, bregs, n_aux, acc, c0, epi, out, name):
+    def __init__(self, p0, bregs, n_aux, acc, c0, epi, out, name, save_unit=None):
+        self.save_unit = save_unit  # SAVE8: workspace unit (1 KiB per tile of 32 points) of this tile's 16 values per lane, or None
         self.p0, self.n = p0, len(bregs)
         # MFMA order: aux k-steps first (their B operand is always ready: one more gap for the producing epilogue)
         order = list(range(self.n - n_aux, self.n)) + list(range(self.n - n_aux))
@@ -63,12 +69,12 @@ def stage_list(auxs):
     tiles, p, tno = [], 0, 0
     auxb = [AUX + 4 * a for a in range(auxs)]
 
-    def dense(inp, ks, ntiles, epi, outbase, name):
+    def dense(inp, ks, ntiles, epi, outbase, name, unit0=None):
         nonlocal p, tno
         for t in range(ntiles):
             b = [inp + 4 * k for k in range(ks)] + auxb
             out = [outbase + 8 * t + q for q in range(8)] if outbase is not None else None
-            tiles.append(Tile(p, b, auxs, ACC[tno & 1], True, epi, out, f"{name}.{t}"))
+            tiles.append(Tile(p, b, auxs, ACC[tno & 1], True, epi, out, f"{name}.{t}", None if unit0 is None else auxs + unit0 + t))
             p += len(b)
             tno += 1
 
@@ -81,17 +87,18 @@ def stage_list(auxs):
         head_started[0] = True
         p += len(b)
 
+    # workspace units (mlp_layout.h SR_FMT8, after the aux fragments): a_l at 8 l + t, feats 64 + t, rgbh 72, s1 76, e1 80, s2 84, s3 88
     for l in range(7):
-        dense(X if l % 2 == 0 else Y, KS, 8, "sin", Y if l % 2 == 0 else X, f"L{l + 1}")
-    dense(Y, KS, 8, "id", X, "feats")          # a7 (in Y) -> feats (in X)
+        dense(X if l % 2 == 0 else Y, KS, 8, "sin", Y if l % 2 == 0 else X, f"L{l + 1}", 8 * (l + 1))
+    dense(Y, KS, 8, "id", X, "feats", 64)      # a7 (in Y) -> feats (in X)
     dense(Y, KS, 1, "sigma", None, "sigma")
-    dense(X, KS, 4, "sin", H0, "rgbh")
+    dense(X, KS, 4, "sin", H0, "rgbh", 72)
     head(H0, False, "Hr")
-    dense(X, KS, 4, "sin", H1, "s1")
-    dense(H1, HS, 4, "sin", H0, "s2")
-    dense(H0, HS, 4, "sin", H1, "s3")
+    dense(X, KS, 4, "sin", H1, "s1", 76)
+    dense(H1, HS, 4, "sin", H0, "s2", 84)
+    dense(H0, HS, 4, "sin", H1, "s3", 88)
     head(H1, False, "Hs")
-    dense(X, KS, 4, "sin", H0, "e1")
+    dense(X, KS, 4, "sin", H0, "e1", 80)
     head(H0, True, "Hb")
     return tiles, p
 
@@ -104,8 +111,11 @@ class Ins:
 
 
 class Core:
-    def __init__(self, auxs, R=128, PF=5, GROUP=2, FILL=2, ablate=()):
-        assert R % NW == 0 and PF + 1 <= NA
+    def __init__(self, auxs, R=128, PF=5, GROUP=2, FILL=None, ablate=(), save=0):
+        assert R % NW == 0 and PF + 1 <= NA and save in (0, 8)
+        if FILL is None:
+            FILL = 3 if save else 2  # epilogue instructions per MFMA gap (a saving tile's epilogue has 42 instead of 24)
+        self.save = save
         self.auxs, self.R, self.PF, self.GROUP, self.FILL = auxs, R, PF, GROUP, FILL
         self.ablate = set(ablate)  # timing experiments only (results are wrong): nodma, nobarrier, noepi, noread, nowaitl
         self.tiles, self.n_pieces = stage_list(auxs)
@@ -201,7 +211,36 @@ class Core:
             t = T[ti]
             g0 = last_of_tile[ti] + 2
             a = t.acc
-            if t.epi == "sin":
+            if self.save and t.save_unit is not None and t.epi == "sin":
+                # PHASE8: byte = low mantissa byte of (pre-activation + 1.5 * 2^15), written straight into its place of the store
+                # quad by an SDWA add BEFORE the value's sin overwrites the accumulator; cvt_pk one pair behind (trans -> VALU use)
+                sv = SV[self.n_saves & 1]
+                self.n_saves += 1
+                for q in range(8):
+                    for g in (2 * q, 2 * q + 1):
+                        epi_q.append([g0, "phase", (sv + (g >> 2), g & 3, a + g)])
+                        epi_q.append([g0, "sin", (a, g, t.out)])
+                    if q > 0:
+                        epi_q.append([g0, "pk", (a, q - 1, t.out)])
+                epi_q.append([g0, "store", (sv, t.save_unit)])
+                epi_q.append([g0, "pk", (a, 7, t.out)])
+            elif self.save and t.save_unit is not None and t.epi == "id":
+                # MX8: E = exponent of 1.0079 max|v| clamped to [6, 254]; u = cvt_pk_u8(v * 2^(133 - E) + 128); byte t of EB = E
+                sv = SV[self.n_saves & 1]
+                self.n_saves += 1
+                tt = t.save_unit - (self.auxs + 64)
+                epi_q.append([g0, "mx_max", (a, 0, True)])
+                for g in range(2, 16, 2):
+                    epi_q.append([g0, "mx_max", (a, g, False)])
+                epi_q.append([g0, "mx_exp", (tt,)])
+                for g in range(16):
+                    epi_q.append([g0, "mx_q", (sv + (g >> 2), g & 3, a + g)])
+                epi_q.append([g0, "store", (sv, t.save_unit)])
+                for q in range(8):
+                    epi_q.append([g0, "pk", (a, q, t.out)])
+                if tt == 7:
+                    epi_q.append([g0, "store_scale", (self.auxs + 92,)])
+            elif t.epi == "sin":
                 seq = []
                 # s0 s1 s2 c0 s3 s4 c1 ...: every cvt_pk is separated from its second sin by one instruction (trans -> VALU use)
                 order = [("sin", 0), ("sin", 1)]
@@ -221,6 +260,7 @@ class Core:
             elif t.epi == "sigma":
                 epi_q.append([g0, "mov", (SIG, a)])
 
+        self.n_saves, self.cur_unit = 0, 0
         written_at = {}   # VGPR -> index in self.ins of the VALU instruction that last wrote it
         trans_at = {}     # VGPR -> index of a v_sin that wrote it
 
@@ -242,6 +282,46 @@ class Core:
                 d, s = args
                 self._e("mov", (d, s), f"v_mov_b32 v{d}, v{s}")
                 written_at[d] = len(self.ins) - 1
+            elif kind == "phase":
+                d, byte, src = args
+                self._e("phase", (d, byte, src), f"v_add_f32_sdwa v{d}, v{src}, v{KMAGIC} dst_sel:BYTE_{byte} dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD")
+            elif kind == "store":
+                sv, unit = args
+                delta = (unit - self.cur_unit) * 1024
+                self.cur_unit = unit
+                self._e("soff", (delta,), f"v_add_u32 v{SOFF}, 0x{delta & 0xffffffff:x}, v{SOFF}")
+                self._e("store", (sv, unit), f"global_store_dwordx4 v{SOFF}, v[{sv}:{sv + 3}], %[ab] nt")
+            elif kind == "store_scale":
+                (unit,) = args
+                delta = (unit - self.cur_unit) * 1024
+                self.cur_unit = unit
+                self._e("soff", (delta,), f"v_add_u32 v{SOFF}, 0x{delta & 0xffffffff:x}, v{SOFF}")
+                self._e("store2", (EB, unit), f"global_store_dwordx2 v{SOFF}, v[{EB}:{EB + 1}], %[ab]")
+            elif kind == "mx_max":
+                a, g, first = args
+                m = MXT
+                if first:
+                    self._e("mx_max", (m, a + g, a + g + 1, None), f"v_max_f32 v{m}, |v{a + g}|, |v{a + g + 1}|")
+                else:
+                    self._e("mx_max", (m, a + g, a + g + 1, m), f"v_max3_f32 v{m}, |v{a + g}|, |v{a + g + 1}|, v{m}")
+            elif kind == "mx_exp":
+                (tt,) = args
+                m, e, inv = MXT, MXT + 1, MXT + 2
+                self._e("mx_e1", (m,), f"v_fmac_f32 v{m}, 0x3c000000, v{m}")                 # m = 2^-7 m + m (one rounding; VOP2 takes the literal)
+                self._e("mx_e2", (e, m), f"v_lshrrev_b32 v{e}, 23, v{m}")
+                self._e("mx_e3a", (e,), f"v_max_u32 v{e}, 6, v{e}")                          # clamp to [6, 254]
+                self._e("mx_e3", (e,), f"v_min_u32 v{e}, 0xfe, v{e}")
+                self._e("mx_e4", (inv, e), f"v_sub_u32 v{inv}, 0x104, v{e}")                 # 260 - E
+                self._e("mx_e5", (inv,), f"v_lshlrev_b32 v{inv}, 23, v{inv}")                # 2^(133 - E)
+                if tt & 3:
+                    self._e("mx_e6", (EB + (tt >> 2), e, 8 * (tt & 3), False), f"v_lshl_or_b32 v{EB + (tt >> 2)}, v{e}, {8 * (tt & 3)}, v{EB + (tt >> 2)}")
+                else:
+                    self._e("mx_e6", (EB + (tt >> 2), e, 0, True), f"v_mov_b32 v{EB + (tt >> 2)}, v{e}")
+            elif kind == "mx_q":
+                d, byte, src = args
+                tmp, inv = MXT + 3, MXT + 2
+                self._e("mx_q1", (tmp, src, inv), f"v_fma_f32 v{tmp}, v{src}, v{inv}, v{K128}")   # v * 2^(133 - E) + 128
+                self._e("mx_q2", (d, tmp, byte), f"v_cvt_pk_u8_f32 v{d}, v{tmp}, {byte}, v{d}")
 
         def flush_producers(regs, gap):
             """everything in the queue up to the last instruction that writes one of `regs` must be emitted now"""
@@ -261,7 +341,8 @@ class Core:
             """a tile is about to start on accumulator `acc`: the epilogue that still reads it must be out first"""
             last = -1
             for qi, it in enumerate(epi_q):
-                if (it[1] in ("sin", "pk") and it[2][0] == acc) or (it[1] == "mov" and it[2][1] == acc):
+                if ((it[1] in ("sin", "pk", "mx_max") and it[2][0] == acc) or (it[1] == "mov" and it[2][1] == acc)
+                        or (it[1] in ("phase", "mx_q") and acc <= it[2][2] < acc + 16)):
                     last = qi
             for _ in range(last + 1):
                 emit_epi(epi_q.pop(0))
@@ -357,15 +438,19 @@ class Core:
         lines = ["// GENERATED by csrc/gen/fwd_core.py -- do not edit (tests/test_fwd_core.py checks it is current).",
                  f"// fused forward core, AUXS = {self.auxs}: {self.stats['mfma']} MFMAs, {self.stats['instructions']} instructions, "
                  f"{self.stats['barriers']} rendezvous, {self.stats['rows']} LDS-DMA rows, ring of {self.R} pieces, A fragments {self.PF} ahead.",
-                 "// Operands: %[sb] stream base (SGPR pair), %[wb] LDS ring address + wave * 1024, %[wave] wave index, %[m0save] scratch SGPR."]
+                 "// Operands: %[sb] stream base (SGPR pair), %[wb] LDS ring address + wave * 1024, %[wave] wave index, %[m0save] scratch SGPR"
+                 + (", %[ab] activation workspace (SGPR pair)." if self.save else ".")]
         lines += ['"' + t + '\\n"' for t in self.text()]
         return "\n".join(lines) + "\n"
 
     @staticmethod
-    def clobber_file():
-        """registers the statement writes besides its operands (X = v[0:63], the aux fragments, v[192:211] are operands)"""
-        regs = ", ".join(f'"v{r}"' for r in range(Y, AUX))
-        return "// GENERATED by csrc/gen/fwd_core.py: clobber list of the forward core\n" + regs + ', "memory", "scc"\n'
+    def clobber_file(save=0):
+        """registers the statement writes besides its operands (X = v[0:63], the aux fragments, v[192:211], KMAGIC, K128 and SOFF are operands)"""
+        regs = list(range(Y, AUX))
+        if save:
+            regs += [r for r in range(SV[0], N_VGPR_SAVE) if r not in (KMAGIC, SOFF, K128)]
+        return ("// GENERATED by csrc/gen/fwd_core.py: clobber list of the forward core\n" + ", ".join(f'"v{r}"' for r in regs)
+                + ', "memory", "scc"\n')
 
 
 # =================================================================================================================================
@@ -418,6 +503,8 @@ class Machine:
         self.pending_reads = []  # (dst, slot, piece)
         self.ar_piece = {}
         self.issued = {"full": [], "skip": []}  # DMA rows requested by a wave that takes / skips the ragged last row
+        self.soff = 0        # SAVE8: byte offset of SOFF relative to the tile's workspace base
+        self.stores = {}     # unit -> [4, 64] uint32 (or [2, 64] for the scale unit)
 
     def f(self, r):
         return self.v[r].view(np.float32)
@@ -487,6 +574,46 @@ class Machine:
             elif op == "mov":
                 d, s = a
                 self.v[d] = self.v[s]
+            elif op == "phase":  # v_add_f32_sdwa dst_sel:BYTE_k UNUSED_PRESERVE: the low byte of the fp32 sum
+                d, byte, src = a
+                ssum = (self.f(src) + self.f(KMAGIC)).astype(np.float32)
+                b = ssum.view(np.uint32) & np.uint32(0xFF)
+                self.v[d] = (self.v[d] & np.uint32(~(0xFF << (8 * byte)) & 0xFFFFFFFF)) | (b << np.uint32(8 * byte))
+            elif op == "soff":
+                self.soff += a[0]
+            elif op in ("store", "store2"):
+                reg, unit = a
+                assert self.soff == unit * 1024 and unit not in self.stores, (self.soff, unit)
+                self.stores[unit] = self.v[reg:reg + (4 if op == "store" else 2)].copy()
+            elif op == "mx_max":
+                m, x, y, z = a
+                r = np.maximum(np.abs(self.f(x)), np.abs(self.f(y)))
+                if z is not None:
+                    r = np.maximum(r, self.f(z))
+                self.v[m] = r.astype(np.float32).view(np.uint32)
+            elif op == "mx_e1":
+                m = a[0]
+                self.v[m] = (self.f(m).astype(np.float64) * 0.0078125 + self.f(m).astype(np.float64)).astype(np.float32).view(np.uint32)
+            elif op == "mx_e2":
+                self.v[a[0]] = self.v[a[1]] >> np.uint32(23)
+            elif op == "mx_e3":
+                self.v[a[0]] = np.clip(self.v[a[0]], 6, 254).astype(np.uint32)
+            elif op == "mx_e4":
+                self.v[a[0]] = (np.uint32(260) - self.v[a[1]]).astype(np.uint32)
+            elif op == "mx_e5":
+                self.v[a[0]] = (self.v[a[0]] << np.uint32(23)).astype(np.uint32)
+            elif op == "mx_e6":
+                d, e, sh, first = a
+                self.v[d] = self.v[e].copy() if first else ((self.v[e] << np.uint32(sh)) | self.v[d]).astype(np.uint32)
+            elif op == "mx_q1":
+                t, src, inv = a
+                self.v[t] = (self.f(src).astype(np.float64) * self.f(inv).astype(np.float64) + self.f(K128).astype(np.float64)).astype(np.float32).view(np.uint32)
+            elif op == "mx_e3a":
+                pass  # (the clamp is applied by mx_e3)
+            elif op == "mx_q2":  # v_cvt_pk_u8_f32: round to nearest even, saturate to [0, 255]
+                d, t, byte = a
+                b = np.clip(np.rint(self.f(t).astype(np.float64)), 0, 255).astype(np.uint32)
+                self.v[d] = (self.v[d] & np.uint32(~(0xFF << (8 * byte)) & 0xFFFFFFFF)) | (b << np.uint32(8 * byte))
         assert self.consumed.all()
 
 
@@ -499,19 +626,21 @@ def main():
     ap.add_argument("--R", type=int, default=128)
     ap.add_argument("--PF", type=int, default=5)
     ap.add_argument("--GROUP", type=int, default=2)
-    ap.add_argument("--FILL", type=int, default=2)
+    ap.add_argument("--FILL", type=int, default=None)
     a = ap.parse_args()
     here = os.path.dirname(os.path.abspath(__file__))
     out_dir = a.out or os.path.dirname(here)
     os.makedirs(out_dir, exist_ok=True)
     for auxs in (1, 2):
-        c = Core(auxs, R=a.R, PF=a.PF, GROUP=a.GROUP, FILL=a.FILL, ablate=[x for x in a.ablate.split(",") if x])
-        path = os.path.join(out_dir, f"mlp_fwd_core_a{auxs}.inc")
-        with open(path, "w") as f:
-            f.write(c.inc_file())
-        print(path, c.stats)
-    with open(os.path.join(out_dir, "mlp_fwd_core_clobbers.inc"), "w") as f:
-        f.write(Core.clobber_file())
+        for save in (0, 8):
+            c = Core(auxs, R=a.R, PF=a.PF, GROUP=a.GROUP, FILL=a.FILL, ablate=[x for x in a.ablate.split(",") if x], save=save)
+            path = os.path.join(out_dir, f"mlp_fwd_core_a{auxs}{'s8' if save else ''}.inc")
+            with open(path, "w") as f:
+                f.write(c.inc_file())
+            print(path, c.stats)
+    for save, name in ((0, "mlp_fwd_core_clobbers.inc"), (8, "mlp_fwd_core_clobbers_s8.inc")):
+        with open(os.path.join(out_dir, name), "w") as f:
+            f.write(Core.clobber_file(save))
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 // one (mode, aux-size) instantiation of the fused forward kernel per translation unit (parallel builds)
 #include "mlp_fwd2.inc"
 namespace sr {
-int launch_fwd_p1a2(const FwdParams& p, int save_fmt, hipStream_t st) { return save_fmt == 0 ? launch_fwd_infer<2>(p, st) : launch_fwd<1, 2>(p, save_fmt, st); }
+int launch_fwd_p1a2(const FwdParams& p, int save_fmt, hipStream_t st) { return launch_fwd_any<2>(p, save_fmt, st); }
 }  // namespace sr

@@ -24,18 +24,21 @@ def _gen():
 
 
 @pytest.mark.parametrize("auxs", [1, 2])
-def test_generated_files_are_current(auxs):
+@pytest.mark.parametrize("save", [0, 8])
+def test_generated_files_are_current(auxs, save):
     g = _gen()
-    want = g.Core(auxs).inc_file()
-    with open(os.path.join(ROOT, "satnerf_amd", "csrc", f"mlp_fwd_core_a{auxs}.inc")) as f:
+    want = g.Core(auxs, save=save).inc_file()
+    with open(os.path.join(ROOT, "satnerf_amd", "csrc", f"mlp_fwd_core_a{auxs}{'s8' if save else ''}.inc")) as f:
         assert f.read() == want, "re-run satnerf_amd/csrc/gen/fwd_core.py"
+    with open(os.path.join(ROOT, "satnerf_amd", "csrc", "mlp_fwd_core_clobbers_s8.inc" if save else "mlp_fwd_core_clobbers.inc")) as f:
+        assert f.read() == g.Core.clobber_file(save)
 
 
-@pytest.mark.parametrize("tau", [4, 16])
-def test_instruction_stream_computes_the_forward_pass(tau):
+@pytest.mark.parametrize("tau,save", [(4, 0), (16, 0), (4, 8), (16, 8)])
+def test_instruction_stream_computes_the_forward_pass(tau, save):
     g = _gen()
     auxs = g.aux_steps(tau)
-    core = g.Core(auxs)
+    core = g.Core(auxs, save=save)
     params = O.procedural_satnerf_params(256, tau, seed=3)
     flat = np.concatenate([v.numpy().reshape(-1) for v in params.values()]).astype(np.float32)
     em = E.Emulator(flat, 256, tau, bf16=True)
@@ -57,7 +60,30 @@ def test_instruction_stream_computes_the_forward_pass(tau):
         m.v[g.X + 4 * k:g.X + 4 * k + 4] = g.f32_to_frag(em.saved["a"][0][k])
     for a in range(auxs):
         m.v[g.AUX + 4 * a:g.AUX + 4 * a + 4] = g.f32_to_frag(em.saved["aux"][a])
+    m.v[g.KMAGIC] = np.full(64, 49152.0, np.float32).view(np.uint32)
+    m.v[g.K128] = np.full(64, 128.0, np.float32).view(np.uint32)
     m.run()
+    if save:
+        # PHASE8 units: byte g of the lane's 16 = round(frac(pre-activation) * 256) mod 256 of fragment pair (2t, 2t+1)
+        def unit_bytes(u):
+            w = m.stores[u]  # [4, 64]
+            return np.stack([(w[q] >> np.uint32(8 * j)) & 0xFF for q in range(4) for j in range(4)], 1).astype(np.int64)  # [64, 16]
+        stages = [(f"a{l}", 8 * l, 8) for l in range(1, 8)] + [("rgbh", 72, 4), ("s1", 76, 4), ("e1", 80, 4), ("s2", 84, 4), ("s3", 88, 4)]
+        for tag, u0, nt in stages:
+            pre = em.saved["pre"][tag]
+            for t in range(nt):
+                want = np.rint((np.concatenate([pre[2 * t], pre[2 * t + 1]], 1) % 1.0) * 256).astype(np.int64) % 256
+                d = (unit_bytes(auxs + u0 + t) - want) % 256
+                assert np.minimum(d, 256 - d).max() <= 1, (tag, t)
+        # MX8 feats: (u - 128) * 2^(E - 133) within one quantum of the value, E in byte t of the scale unit
+        sc = m.stores[auxs + 92]
+        for t in range(8):
+            e = ((sc[t >> 2] >> np.uint32(8 * (t & 3))) & 0xFF).astype(np.int64)  # [64]
+            val = (unit_bytes(auxs + 64 + t) - 128) * np.exp2(e - 133.0)[:, None]
+            ref = np.concatenate([em.saved["feats"][2 * t], em.saved["feats"][2 * t + 1]], 1)
+            assert (np.abs(val - ref) <= 1.01 * np.exp2(e - 133.0)[:, None] + 2.0 ** -8 * np.abs(ref)).all(), t
+            assert (np.abs(ref).max(1) <= 127.01 * np.exp2(e - 133.0)).all() and (e >= 6).all()
+        assert sorted(m.stores) == sorted([auxs + u for u in list(range(8, 92)) + [92]])
 
     head = np.stack([m.f(g.HEAD + r) for r in range(5)], 1).astype(np.float64)  # [lane, row]
     sig = m.f(g.SIG).astype(np.float64)
