@@ -233,6 +233,10 @@ __global__ void __launch_bounds__(1024) wgrad8_kernel(const Wgrad8Params prm) {
 
 }  // namespace sr
 
+namespace sr {
+int launch_wgrad8f(const uint4* dpre, const uint4* acts, const int* blocks, const int* loads, float* partial, long n_tiles, int n_blocks,
+                   int ak, int auxs, int dk, int n_slices, hipStream_t st);  // wgrad8f.hip
+}
 using namespace sr;
 
 extern "C" int sr_satnerf_wgrad8(int feat, int tau, int64_t n_points, const uint16_t* dpre, const uint16_t* acts, const int32_t* blocks,
@@ -247,6 +251,11 @@ extern "C" int sr_satnerf_wgrad8(int feat, int tau, int64_t n_points, const uint
   p.auxs = aux_steps(tau);
   p.ak = (int)(sr_act_elems_per_tile(feat, SR_FMT8) / 512) - (2 - p.auxs);  // the size query assumes the 2-step aux layout
   p.dk = (int)(sr_dpre_elems_per_tile(feat, SR_FMT8) / 512);
+  // width 256: SATNERF_WGRAD_V2=1 selects the fat-wave kernel with the hand-placed per-tile stream (wgrad8f.hip; experimental: correct,
+  // not yet faster -- profiles/r03_ab_variants.txt)
+  static const bool v2 = [] { const char* e = getenv("SATNERF_WGRAD_V2"); return e && e[0] == '1'; }();
+  if (feat == 256 && v2)
+    return launch_wgrad8f(p.dpre, p.acts, blocks, loads, partial, p.n_tiles, n_blocks, p.ak, p.auxs, p.dk, n_slices, (hipStream_t)stream);
   const size_t lds = (size_t)kSlots8 * kSlot8Bytes;
   static bool attr_set = false;
   if (!attr_set) {
