@@ -31,6 +31,7 @@ struct Wgrad8Params {  // (as wgrad8.hip)
   int ak;
   int auxs;
   int dk;
+  long long* dbg;  // SR_W8_TIMING builds: s_memtime stamps of workgroup 0 ([wave][iteration < 32][8])
 };
 
 typedef short s16x4f __attribute__((ext_vector_type(4)));
@@ -187,8 +188,15 @@ __global__ void __launch_bounds__(512) wgrad8f_kernel(const Wgrad8Params prm) {
       f32x32 c0 = {}, c1 = {}, c2 = {}, c3 = {};  // acc[a][c] at 16 (2 a + c)
       f32x16 cx = {};
       for (int i = 0; i < nt; ++i) {
+#ifdef SR_W8_TIMING
+        long long* stamp = (prm.dbg && blockIdx.x == 0 && i < 32 && lane == 0) ? prm.dbg + (wave * 32 + i) * 8 : nullptr;
+        if (stamp) stamp[0] = (long long)__builtin_amdgcn_s_memtime();
+#endif
         const bool more = i + kSlotsF - 1 < nt;
         if (more) issue(t_begin + i + kSlotsF - 1, (i + kSlotsF - 1) & (kSlotsF - 1));
+#ifdef SR_W8_TIMING
+        if (stamp) stamp[1] = (long long)__builtin_amdgcn_s_memtime();
+#endif
         const uint32_t cur = ring + (uint32_t)(i & (kSlotsF - 1)) * kSlotBytes;
         // the last tile decodes nothing useful: the statement still decodes the next slot in place (stale bytes, never read again)
         const uint32_t nxt = ring + (uint32_t)((i + 1) & (kSlotsF - 1)) * kSlotBytes;
@@ -211,9 +219,18 @@ __global__ void __launch_bounds__(512) wgrad8f_kernel(const Wgrad8Params prm) {
           );
         }
 #undef SR_TILE_OPERANDS
+#ifdef SR_W8_TIMING
+        if (stamp) stamp[2] = (long long)__builtin_amdgcn_s_memtime();
+#endif
         wait_outstanding(more ? 1 : 0);  // tile i+2 (if any) has landed; only tile i+3 may still be in flight
+#ifdef SR_W8_TIMING
+        if (stamp) stamp[3] = (long long)__builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifdef SR_W8_TIMING
+        if (stamp) stamp[4] = (long long)__builtin_amdgcn_s_memtime();
+#endif
       }
       asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA results -> VALU reads (the statement's last MFMAs are not padded by hipcc)
       const f32x32* cc[4] = {&c0, &c1, &c2, &c3};
@@ -320,6 +337,8 @@ int launch_wgrad8f(const uint4* dpre, const uint4* acts, const int* blocks, cons
   Wgrad8Params p;
   p.dpre = dpre, p.acts = acts, p.blocks = blocks, p.loads = loads, p.partial = partial;
   p.n_tiles = n_tiles, p.n_blocks = n_blocks, p.ak = ak, p.auxs = auxs, p.dk = dk;
+  const char* dbg = getenv("SR_W8_DBG");
+  p.dbg = dbg ? (long long*)strtoull(dbg, nullptr, 10) : nullptr;
   const size_t lds = (size_t)kSlotsF * kSlotBytes;
   static bool attr_set = false;
   if (!attr_set) {

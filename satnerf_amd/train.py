@@ -224,6 +224,9 @@ class Trainer:
         self.pace_every = max(1, int(os.environ.get("SATNERF_PACE_EVERY", "1")))
         self.last_rgb = None
         self.last_loss = None
+        # stratified jitter of the eager step (rendering.py:77): torch's generator by default; tools/convergence.py substitutes the
+        # reference run's draws so that two trainings differ by their arithmetic only
+        self.jitter = lambda n, s, device: torch.rand(n, s, device=device)
 
     # ---- forward + loss + backward on the current stream, gradients accumulate into the flat buffer -------------------
     def _forward_backward(self, rays, ts, rgbs, depth=None):
@@ -247,7 +250,7 @@ class Trainer:
         sk = model.sky_color
         # stratified jitter (rendering.py:77): torch's generator when run eagerly; inside a captured step the kernel draws it
         # itself (Philox keyed by the seed, stepping with the device counter) -- one launch and the graph's RNG bookkeeping less
-        u = None if self._kernel_rng else torch.rand(n, s, device=rays.device)
+        u = None if self._kernel_rng else self.jitter(n, s, rays.device)
         noise_std = float(args.noise_std)
         # models/satnerf.py:58 draws randn even when noise_std == 0; the draw is skipped then (results are identical)
         nz = torch.randn(n, s, device=rays.device) if noise_std != 0 else None
@@ -323,7 +326,7 @@ class Trainer:
         hi, lo, l0 = model.packed(mode)
         bstream, maps = model.packed_backward()
         sk = model.sky_color
-        u = None if self._kernel_rng else torch.rand(n, s, device=rays.device)
+        u = None if self._kernel_rng else self.jitter(n, s, rays.device)
         nz = torch.randn(n, s, device=rays.device) if noise_std != 0 else None
         z, sky = ops.ray_setup(rays, u, s, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data, seed=self._seed + 1,
                                step_counter=self.adam_state)

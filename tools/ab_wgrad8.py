@@ -43,11 +43,11 @@ for n_wg in n_wgs:
 if dbg is not None:
     torch.cuda.synchronize()
     d = dbg.cpu().view(16, 32, 8)
-    names = ["start", "issued", "decA", "k0", "k1", "decB", "vmwait", "barrier"]
+    names = ["start", "issued", "tile", "vmwait", "barrier"]
     for w in (0, 1, 3, 4, 5, 7):
-        print(f"wave {w}: per-iteration deltas (100 MHz ticks x ? -> raw counts) iterations 8..15")
+        print(f"wave {w}: per-iteration deltas (shader cycles) iterations 8..15")
         for i in range(8, 16):
             row = d[w, i]
-            deltas = [int(row[k] - row[k - 1]) for k in range(1, 8)]
+            deltas = [int(row[k] - row[k - 1]) for k in range(1, 5)]
             nxt = int(d[w, i + 1, 0] - row[0])
             print(f"  it {i:2d}: " + " ".join(f"{n}={v:5d}" for n, v in zip(names[1:], deltas)) + f"  | iter={nxt}")
