@@ -38,10 +38,10 @@ MFMA_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA, /opt/skills/guides/MI355X_M
 HBM_PEAK_GBPS = 8000.0            # HBM3E spec, same guide (6.29 TB/s measured achievable)
 WS_UNITS = {16: (185, 186), 8: (94, 101)}  # 1-KiB units per 32-point tile: activations saved / gradients written (tau <= 8)
 PREWARM = 50                      # untimed steps before --warmup: graph capture, clocks, caches
-KERNEL_NAMES = {"mlp_fwd": "satnerf_fwd_kernel (fused MLP forward, saving activations in training)",
+KERNEL_NAMES = {"mlp_fwd": "satnerf_fwd2_kernel (fused MLP forward on the generated core, saving activations in training)",
                 "mlp_bwd": "satnerf_bwd_kernel (fused dX chain)", "wgrad": "wgrad kernel (weight-gradient GEMMs)"}
-PMC_ROWS = {"mlp_fwd": "satnerf_fwd_kernel", "mlp_bwd": "satnerf_bwd_kernel", "wgrad": "wgrad"}
-PMC_FILE = os.path.join("profiles", "r02_train_pmc.csv")
+PMC_ROWS = {"mlp_fwd": "satnerf_fwd", "mlp_bwd": "satnerf_bwd_kernel", "wgrad": "wgrad"}
+PMC_FILE = os.path.join("profiles", "r03_train_pmc.csv")
 
 
 def pmc_traffic(kernel_key):

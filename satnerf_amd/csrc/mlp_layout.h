@@ -184,19 +184,28 @@ __device__ __forceinline__ float wg_sum_slices(const float* __restrict__ partial
   const int b = k / kWgBlockFloats, w = k - b * kWgBlockFloats;
   const int ns = blocks[kWgTableInts * b + kWgSlices];
   const float* p = partial + (long)blocks[kWgTableInts * b + kWgFirstSlice] * kWgBlockFloats + w;
-  // ten independent loads in flight per thread (slices beyond ns are clamped to the last one and masked): with a plain loop
-  // every 295-KiB-strided load waited for the previous add and the reduction ran at 2.6 TB/s (23.6 us, PMC r02a); six in
-  // flight: 20.5 us
-  float acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int sp = 0; sp < ns; sp += 10) {
+  // SR_TAIL_INFLIGHT independent loads in flight per thread (slices beyond ns are clamped to the last one and masked): with a plain
+  // loop every 295-KiB-strided load waited for the previous add and the reduction ran at 2.6 TB/s (23.6 us, PMC r02a); six in flight:
+  // 20.5 us; ten: 20.0 us
+#ifndef SR_TAIL_INFLIGHT
+#define SR_TAIL_INFLIGHT 10
+#endif
+  constexpr int NF = SR_TAIL_INFLIGHT;
+  float acc[NF];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
+  for (int i = 0; i < NF; ++i) acc[i] = 0.f;
+  for (int sp = 0; sp < ns; sp += NF) {
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
       const int sl = sp + i;
       const float v = p[(long)(sl < ns ? sl : ns - 1) * kWgBlockFloats];
       acc[i] += sl < ns ? v : 0.f;
     }
   }
-  return (((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]))) + (acc[8] + acc[9]);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NF; ++i) sum += acc[i];
+  return sum;
 }
 #endif
 
