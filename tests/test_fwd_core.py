@@ -93,3 +93,72 @@ def test_instruction_stream_computes_the_forward_pass(tau, save):
     for name, a, b in zip(("albedo", "sigma", "sun_v", "beta"), got, (albedo, sigma, sun_v, beta)):
         err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
         assert err < 2e-5, (name, err)  # same bf16 operands; fp32 vs fp64 accumulation and sin
+
+
+# ---- the parity-mode (bf16x3) core: csrc/gen/fwd_core3.py -> csrc/mlp_fwd3_core_a*.inc ---------------------------------------------------
+GEN3 = os.path.join(ROOT, "satnerf_amd", "csrc", "gen", "fwd_core3.py")
+
+
+def _gen3():
+    spec = importlib.util.spec_from_file_location("fwd_core3_gen", GEN3)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("auxs", [1, 2])
+def test_generated_parity_core_is_current(auxs):
+    g = _gen3()
+    with open(os.path.join(ROOT, "satnerf_amd", "csrc", f"mlp_fwd3_core_a{auxs}.inc")) as f:
+        assert f.read() == g.Core3(auxs).inc_file(), "re-run satnerf_amd/csrc/gen/fwd_core3.py"
+    with open(os.path.join(ROOT, "satnerf_amd", "csrc", "mlp_fwd3_core_clobbers.inc")) as f:
+        assert f.read() == g.Core3.clobber_file()
+
+
+@pytest.mark.parametrize("tau", [4, 16])
+def test_parity_core_stream_computes_the_forward_pass(tau):
+    """hi / lo planes everywhere, three MFMAs per k-step: the instruction list on the unified 512-register model against the fp64
+    emulator (exact operands) -- the split representation carries ~16 bits, so 1e-5 of the outputs"""
+    g = _gen3()
+    auxs = g.aux_steps(tau)
+    core = g.Core3(auxs)
+    params = O.procedural_satnerf_params(256, tau, seed=3)
+    flat = np.concatenate([v.numpy().reshape(-1) for v in params.values()]).astype(np.float32)
+    em = E.Emulator(flat, 256, tau, bf16=False)
+    rng = np.random.default_rng(5)
+    xyz = rng.uniform(-1, 1, (32, 3))
+    sun = rng.normal(size=(32, 3))
+    sun /= np.linalg.norm(sun, axis=1, keepdims=True)
+    t = rng.uniform(-1, 1, (32, tau))
+    albedo, sigma, sun_v, beta = em.forward_tile(xyz, sun, t)
+
+    def planes(v):  # fp32 values -> (hi, lo) bf16 bit planes, hi = RNE(v), lo = RNE(v - hi)
+        v = np.asarray(v, np.float32)
+        hb = g.bf16_bits(v)
+        lb = g.bf16_bits((v - g.bf16_to_f32(hb)).astype(np.float32))
+        return hb, lb
+
+    def words(b):  # [..., 8] bf16 bits -> [..., 4] dwords (element 0 in the low half)
+        return (b[..., 0::2] | (b[..., 1::2] << 16)).astype(np.uint32)
+
+    st = em.stream.reshape(-1, 64, 8).astype(np.float32)
+    sh, sl = planes(st)
+    assert st.shape[0] == core.n_units
+    m = g.Machine3(core, words(sh), words(sl))
+    for k in range(16):  # the C++ prologue's outputs: fc_net.0 activations (hi plane in v[0:63], lo plane arrives in v[64:127])
+        hb, lb = planes(em.saved["a"][0][k])
+        m.v[g.XH + 4 * k:g.XH + 4 * k + 4] = words(hb).T
+        m.v[g.IN_XL + 4 * k:g.IN_XL + 4 * k + 4] = words(lb).T
+    for a in range(auxs):
+        hb, lb = planes(em.saved["aux"][a])
+        m.v[g.IN_AUXH + 4 * a:g.IN_AUXH + 4 * a + 4] = words(hb).T
+        m.v[g.IN_AUXL + 4 * a:g.IN_AUXL + 4 * a + 4] = words(lb).T
+    m.run()
+    head = np.stack([m.f(g.OUT_HEAD + r) for r in range(5)], 1).astype(np.float64)
+    sig = m.f(g.SIG).astype(np.float64)
+    sigmoid = lambda v: 1 / (1 + np.exp(-v))  # noqa: E731
+    softplus = lambda v: np.where(v > 20, v, np.log1p(np.exp(np.minimum(v, 20))))  # noqa: E731
+    got = (sigmoid(head[:32, 0:3]) * 1.002 - 0.001, softplus(sig[:32]), sigmoid(head[:32, 3]), softplus(head[32:, 0]))
+    for name, a, b in zip(("albedo", "sigma", "sun_v", "beta"), got, (albedo, sigma, sun_v, beta)):
+        err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+        assert err < 3e-5, (name, err)  # hi + lo planes carry 16-17 bits of every operand

@@ -1,0 +1,19 @@
+import os, sys, torch
+sys.path.insert(0, "/root/repo")
+from satnerf_amd import ops, data
+from satnerf_amd.models import load_model
+dev = "cuda:0"
+args = data.default_args(mlp_mode="bf16x3")
+torch.manual_seed(0)
+m = load_model(args).to(dev); emb = torch.nn.Embedding(30, 4).to(dev)
+rays, ts = data.synthetic_rays(1024); rays, ts = rays.to(dev), ts.to(dev)
+hi, lo, l0 = m.packed("bf16x3")
+z = ops.ray_sample(rays, torch.rand(1024, 64, device=dev), 64)
+def run():
+    return ops.satnerf_mlp(rays[:, 0:3], rays[:, 3:6], rays[:, 8:11], z, emb.weight.data, ts, 65536, 64, 256, 4, "bf16x3", hi, lo, l0, acts=None, fmt=8)
+for _ in range(10): run()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize(); e0.record()
+for _ in range(50): run()
+e1.record(); torch.cuda.synchronize()
+print(os.path.basename(os.environ.get("SATRENDER_LIB", "default")), "bf16x3 mlp us", round(e0.elapsed_time(e1) / 50 * 1e3, 1))
