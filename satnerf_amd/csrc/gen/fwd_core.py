@@ -16,6 +16,9 @@ Structure of the core (one wave = 32 points, 8 waves per workgroup, 2 per SIMD, 
   * A fragments are fetched PF MFMAs ahead (ds_read_b128 into a ring of PF + 1 register quads, counted lgkmcnt before each MFMA).
   * the epilogue of tile t-1 (16 v_sin in place on its accumulator, 8 v_cvt_pk into the next stage's B fragments) is spread over the
     gaps of tile t's MFMAs, starting two MFMAs after the tile's last one (XDL write -> VALU read needs 12 wait states).
+  * fc_net.0 (K = 3, fp32 inputs) rides the matrix pipe too: the kernel prologue splits x, y, z and the fc_net.0 rows three ways into
+    bf16 (h + m + l = 24 bits) and lays the 21 significant cross products over two k-steps (``l0_terms``), so pieces 0..15 of the ring
+    are written by the prologue (not by LDS-DMA) and the stream starts with 8 two-MFMA tiles (always the bf16 opcode, MF0).
   * hazards the assembler does not pad inside inline asm are checked here: trans -> VALU use (1 state), VALU write -> MFMA operand
     (2 states), MFMA D -> VALU read (>= 2 MFMAs later), M0 write -> LDS-DMA (1 state).
 """
@@ -40,6 +43,8 @@ N_VGPR = 212
 SV = (212, 216)
 KMAGIC, SOFF, EB, MXT, K128 = 220, 221, 222, 224, 228   # EB: 2 registers, MXT: 4 (max, exponent, 1/scale, scaled value); K128 = 128.0f
 N_VGPR_SAVE = 229
+L0B = 232               # two quads: the B fragments of fc_net.0's two k-steps (split coordinates, l0_terms)
+L0_PIECES = 16          # ring pieces 0..15: fc_net.0's A fragments, written by the kernel prologue
 H0, H1 = 64, 96         # the two 32-register head hidden vectors (in Y once the trunk is done)
 
 KS, HS = 16, 8          # k-steps of a 256-wide / 128-wide input
@@ -54,7 +59,8 @@ class Tile:
     """One chunk of the stream = one output tile: pieces [p0, p0 + n), the MFMA order, the B register of every MFMA, what happens to
     the accumulator afterwards."""
 
-    def __init__(self, p0, bregs, n_aux, acc, c0, epi, out, name, save_unit=None):
+    def __init__(self, p0, bregs, n_aux, acc, c0, epi, out, name, save_unit=None, op="MF"):
+        self.op = op  # MF = the mode's MFMA (bf16 / f16 operands), MF0 = always bf16 (fc_net.0's split operands)
         self.save_unit = save_unit  # SAVE8: workspace unit (1 KiB per tile of 32 points) of this tile's 16 values per lane, or None
         self.p0, self.n = p0, len(bregs)
         # MFMA order: aux k-steps first (their B operand is always ready: one more gap for the producing epilogue)
@@ -69,12 +75,14 @@ def stage_list(auxs):
     tiles, p, tno = [], 0, 0
     auxb = [AUX + 4 * a for a in range(auxs)]
 
-    def dense(inp, ks, ntiles, epi, outbase, name, unit0=None):
+    def dense(inp, ks, ntiles, epi, outbase, name, unit0=None, first=False):
         nonlocal p, tno
         for t in range(ntiles):
-            b = [inp + 4 * k for k in range(ks)] + auxb
+            # fc_net.0 (first): two k-steps of split operands, no aux k-step; the small cross terms (k-step 1) go first
+            b = [inp + 4 * k for k in range(ks)] + ([] if first else auxb)
             out = [outbase + 8 * t + q for q in range(8)] if outbase is not None else None
-            tiles.append(Tile(p, b, auxs, ACC[tno & 1], True, epi, out, f"{name}.{t}", None if unit0 is None else auxs + unit0 + t))
+            tiles.append(Tile(p, b, 1 if first else auxs, ACC[tno & 1], True, epi, out, f"{name}.{t}", None if unit0 is None else auxs + unit0 + t,
+                              "MF0" if first else "MF"))
             p += len(b)
             tno += 1
 
@@ -88,6 +96,8 @@ def stage_list(auxs):
         p += len(b)
 
     # workspace units (mlp_layout.h SR_FMT8, after the aux fragments): a_l at 8 l + t, feats 64 + t, rgbh 72, s1 76, e1 80, s2 84, s3 88
+    dense(L0B, 2, 8, "sin", X, "L0", 0, first=True)
+    assert p == L0_PIECES
     for l in range(7):
         dense(X if l % 2 == 0 else Y, KS, 8, "sin", Y if l % 2 == 0 else X, f"L{l + 1}", 8 * (l + 1))
     dense(Y, KS, 8, "id", X, "feats", 64)      # a7 (in Y) -> feats (in X)
@@ -127,9 +137,9 @@ class Core:
     def _e(self, op, a, text):
         self.ins.append(Ins(op, a, text))
 
-    def mfma(self, acc, areg, breg, c0):
+    def mfma(self, acc, areg, breg, c0, op="MF"):
         c = "0" if c0 else f"v[{acc}:{acc + 15}]"
-        self._e("mfma", (acc, areg, breg, c0), f"MF v[{acc}:{acc + 15}], v[{areg}:{areg + 3}], v[{breg}:{breg + 3}], {c}")
+        self._e("mfma", (acc, areg, breg, c0), f"{op} v[{acc}:{acc + 15}], v[{areg}:{areg + 3}], v[{breg}:{breg + 3}], {c}")
 
     def dsread(self, dst, slot):
         base, off = (VL0, slot * 1024) if slot < 64 else (VL1, (slot - 64) * 1024)
@@ -143,7 +153,8 @@ class Core:
         self._e("barrier", (), "s_barrier")
 
     def dma_row(self, j, partial):
-        # row j: wave w fetches piece 8 j + w into ring slot (8 j + w) % R; VOFF already holds w * 1024 + lane * 16 + j * 8192
+        # row j: wave w fetches piece 8 j + w into ring slot (8 j + w) % R from stream offset (8 j + w - 16) * 1024: VOFF holds
+        # w * 1024 + lane * 16 + (j - 2) * 8192 (rows 0, 1 are fc_net.0's pieces, never requested)
         imm = ((NW * j) % self.R) * 1024
         if partial is not None:  # ragged last row: waves >= partial skip it (s_cbranch around the request; SCC from s_cmp)
             self._e("dma_pred", (j, partial), f"s_cmp_lt_u32 %[wave], {partial}")
@@ -174,7 +185,8 @@ class Core:
         partial_row = n_rows - 1 if self.n_pieces % NW else None
         partial_n = self.n_pieces % NW
 
-        self.rows_issued = 0
+        PRE = L0_PIECES // NW  # rows 0, 1 = fc_net.0's pieces: in the ring before the stream starts, never requested
+        self.rows_issued = PRE
         pending_rows = []  # rows allowed but not yet emitted
 
         def allow_rows(free_below):
@@ -197,7 +209,7 @@ class Core:
                 emit_row()
             issued = self.rows_issued
             assert issued >= need, (first_tile, issued, need)
-            vm = issued - need
+            vm = issued - max(need, PRE)
             if partial_row is not None and issued > partial_row and need <= partial_row:
                 vm -= 1  # waves that skipped the ragged row have one request fewer in flight
             vm = max(vm, 0)
@@ -359,8 +371,11 @@ class Core:
             t = T[ti]
             nonlocal sync_done_for
             if ti > sync_done_for and ti % G == 0 and k == 0:
-                sync_for(ti)
                 sync_done_for = ti + G - 1
+                last = min(ti + G, len(T)) - 1
+                if T[last].p0 + T[last].n <= L0_PIECES:
+                    return False  # fc_net.0's tiles: their pieces are in the ring already
+                sync_for(ti)
                 return True
             return False
 
@@ -381,7 +396,7 @@ class Core:
             if dist < 3:
                 self._e("nop", (2 - dist + 1,), f"s_nop {2 - dist + 1}")
             self.waitl(min(PF - 1, N - 1 - i))
-            self.mfma(t.acc, AR0 + 4 * (i % NA), breg, t.c0 and k == 0)
+            self.mfma(t.acc, AR0 + 4 * (i % NA), breg, t.c0 and k == 0, t.op)
             if k == t.n - 1 and t.epi is not None:
                 queue_epilogue(ti)
             # ---- gap(i)
@@ -438,6 +453,7 @@ class Core:
         lines = ["// GENERATED by csrc/gen/fwd_core.py -- do not edit (tests/test_fwd_core.py checks it is current).",
                  f"// fused forward core, AUXS = {self.auxs}: {self.stats['mfma']} MFMAs, {self.stats['instructions']} instructions, "
                  f"{self.stats['barriers']} rendezvous, {self.stats['rows']} LDS-DMA rows, ring of {self.R} pieces, A fragments {self.PF} ahead.",
+                 f"// Ring pieces 0..{L0_PIECES - 1} (fc_net.0) are written by the kernel prologue; stream piece p is ring piece p + {L0_PIECES}.",
                  "// Operands: %[sb] stream base (SGPR pair), %[wb] LDS ring address + wave * 1024, %[wave] wave index, %[m0save] scratch SGPR"
                  + (", %[ab] activation workspace (SGPR pair)." if self.save else ".")]
         lines += ['"' + t + '\\n"' for t in self.text()]
@@ -445,8 +461,8 @@ class Core:
 
     @staticmethod
     def clobber_file(save=0):
-        """registers the statement writes besides its operands (X = v[0:63], the aux fragments, v[192:211], KMAGIC, K128 and SOFF are operands)"""
-        regs = list(range(Y, AUX))
+        """registers the statement writes besides its operands (the aux and fc_net.0 fragments, v[192:211], KMAGIC, K128 and SOFF are operands)"""
+        regs = list(range(X, AUX))
         if save:
             regs += [r for r in range(SV[0], N_VGPR_SAVE) if r not in (KMAGIC, SOFF, K128)]
         return ("// GENERATED by csrc/gen/fwd_core.py: clobber list of the forward core\n" + ", ".join(f'"v{r}"' for r in regs)
@@ -485,6 +501,64 @@ def f32_to_frag(v):
     return (b[:, 0::2] | (b[:, 1::2] << 16)).T.astype(np.uint32)
 
 
+def split3(v):
+    """fp32 -> three bf16-representable fp32 terms h + m + l = v to 24 bits (each RNE of the remainder; the remainders are exact)"""
+    v = np.asarray(v, np.float32)
+    h = bf16_to_f32(bf16_bits(v))
+    r = (v - h).astype(np.float32)
+    m = bf16_to_f32(bf16_bits(r))
+    l = bf16_to_f32(bf16_bits((r - m).astype(np.float32)))
+    return h, m, l
+
+
+def l0_terms():
+    """fc_net.0 as two bf16 k-steps: slot k of k-step s multiplies part A[s][k] of a table entry with part B[s][k] of a coordinate.
+    Entries (column of the (w_x, w_y, w_z, b) table row, part of it, coordinate or None = 1.0, part of it); part 0 / 1 / 2 = h / m / l.
+    k-step 0 carries w_h (x_h + x_m + x_l) + w_m x_h per coordinate and the bias, k-step 1 the remaining 2^-16 terms w_m x_m + w_l x_h."""
+    Z = None
+    s0 = []
+    for c in range(3):
+        s0 += [(c, 0, c, 0), (c, 0, c, 1), (c, 1, c, 0), (c, 0, c, 2)]
+    s0 += [(3, 0, Z, 0), (3, 1, Z, 0), (3, 2, Z, 0), Z]
+    s1 = []
+    for c in range(3):
+        s1 += [(c, 1, c, 1), (c, 2, c, 0)]
+    s1 += [Z] * 10
+    return s0, s1
+
+
+def l0_b_frags(xyz):
+    """B fragments of the two k-steps for 32 points: [2][64 lanes, 8] fp32 (lane = 32 h + point holds slots 8 h .. 8 h + 7)"""
+    parts = [split3(xyz[:, c]) for c in range(3)]
+    out = []
+    for terms in l0_terms():
+        f = np.zeros((64, 8), np.float32)
+        for k, t in enumerate(terms):
+            if t is None:
+                continue
+            _, _, c, xp = t
+            f[32 * (k >> 3):32 * (k >> 3) + 32, k & 7] = 1.0 if c is None else parts[c][xp]
+        out.append(f)
+    return out
+
+
+def l0_pieces(l0_table):
+    """A fragments of fc_net.0: [16 pieces = (tile t, k-step s)][64 lanes = 32 (k >> 3) + row][8] fp32 from the (slot-ordered, scaled)
+    table [256, 4]; row r of tile t is slot 16 (2 t + (g >> 3)) + 8 hh + (g & 7) with g = (r & 3) + 4 (r >> 3), hh = (r >> 2) & 1 -- the
+    accumulator layout that makes tile t the B fragments 2 t, 2 t + 1 of the next layer (what the VALU prologue of r02 produced)."""
+    r = np.arange(32)
+    g, hh = (r & 3) + 4 * (r >> 3), (r >> 2) & 1
+    out = np.zeros((16, 64, 8), np.float32)
+    for t in range(8):
+        slot = 16 * (2 * t + (g >> 3)) + 8 * hh + (g & 7)
+        parts = [split3(l0_table[slot, c]) for c in range(4)]
+        for s, terms in enumerate(l0_terms()):
+            for k, tm in enumerate(terms):
+                if tm is not None:
+                    out[2 * t + s, 32 * (k >> 3):32 * (k >> 3) + 32, k & 7] = parts[tm[0]][tm[1]]
+    return out
+
+
 class Machine:
     """Executes the instruction list of one wave.  The ring is shared by the 8 waves of the workgroup: a DMA row copies the 8 pieces
     all waves fetch.  Protocol checks: a piece may only be read after a sync that covers its row, and a ring slot may only be
@@ -497,12 +571,17 @@ class Machine:
         self.v = np.zeros((256, 64), np.uint32)
         self.ring_piece = [-1] * core.R
         self.ring = np.zeros((core.R, 64, 4), np.uint32)
-        self.synced_rows = 0
+        self.synced_rows = L0_PIECES // NW
         self.consumed = np.zeros(core.n_pieces, bool)   # piece's MFMA issued
         self.consumed_before_barrier = np.zeros(core.n_pieces, bool)
         self.pending_reads = []  # (dst, slot, piece)
         self.ar_piece = {}
         self.issued = {"full": [], "skip": []}  # DMA rows requested by a wave that takes / skips the ragged last row
+        for p in range(L0_PIECES):  # fc_net.0's pieces are in the ring when the stream starts (the prologue wrote them, then a barrier)
+            self.ring_piece[p], self.ring[p] = p, stream_bits[p]
+        for rows in self.issued.values():
+            rows += list(range(L0_PIECES // NW))
+        self.voff_rows = 0   # rows VOFF has been advanced by: the source of the next request is stream piece 8 * voff_rows + wave
         self.soff = 0        # SAVE8: byte offset of SOFF relative to the tile's workspace base
         self.stores = {}     # unit -> [4, 64] uint32 (or [2, 64] for the scale unit)
 
@@ -558,6 +637,7 @@ class Machine:
                 self.issued["full"].append(j)
                 if partial is None:
                     self.issued["skip"].append(j)
+                assert L0_PIECES + NW * self.voff_rows == NW * j, ("VOFF does not address row j of the stream", j, self.voff_rows)
                 for w in range(NW if partial is None else partial):
                     p = NW * j + w
                     slot = p % c.R
@@ -565,6 +645,8 @@ class Machine:
                     assert old < 0 or self.consumed_before_barrier[old], ("DMA overwrites a piece not yet consumed by every wave", old, p)
                     self.ring_piece[slot] = p
                     self.ring[slot] = self.stream[p]
+            elif op == "voff":
+                self.voff_rows += 1
             elif op == "sin":
                 r = a[0]
                 self.v[r] = np.sin(2 * np.pi * self.f(r).astype(np.float64)).astype(np.float32).view(np.uint32)

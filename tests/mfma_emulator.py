@@ -22,7 +22,8 @@ def bf16_round(x):
 
 
 class Emulator:
-    def __init__(self, flat, feat=256, tau=4, bf16=False):
+    def __init__(self, flat, feat=256, tau=4, bf16=False, l0_split=False):
+        self.l0_split = l0_split  # fc_net.0 as the generated core computes it: two k-steps of three-way bf16 splits (gen/fwd_core.py l0_terms)
         m = packing.forward_maps(feat, tau)
         self.m, self.tau, self.auxs, self.bf16 = m, tau, m["auxs"], bf16
         flat = np.asarray(flat, np.float32)
@@ -55,6 +56,27 @@ class Emulator:
             self.saved["pre"][tag] = pres  # pre-activations in revolutions, fragment layout
         return out
 
+    @staticmethod
+    def _split3(v):
+        v = np.asarray(v, np.float32)
+        h = bf16_round(v).astype(np.float32)
+        m = bf16_round((v - h).astype(np.float32)).astype(np.float32)
+        lo = bf16_round((v - h - m).astype(np.float32)).astype(np.float32)
+        return h.astype(np.float64), m.astype(np.float64), lo.astype(np.float64)
+
+    def _l0_split_pre(self, w, x):
+        """w [64, 8, 4] table rows, x [64, 3] -> pre-activation: the small cross terms w_m x_m + w_l x_h accumulated first (one MFMA,
+        rounded to fp32), then w_h (x_h + x_m + x_l) + w_m x_h and the three bias parts (second MFMA)"""
+        small, big = np.zeros(w.shape[:2]), np.zeros(w.shape[:2])
+        for c in range(3):
+            wh, wm, wl = self._split3(w[..., c])
+            xh, xm, xl = (v[:, None] for v in self._split3(x[:, c]))
+            small += wm * xm + wl * xh
+            big += wh * xh + wh * xm + wm * xh + wh * xl
+        bh, bm, bl = self._split3(w[..., 3])
+        big += bh + bm + bl
+        return (small.astype(np.float32).astype(np.float64) + big).astype(np.float32).astype(np.float64)
+
     def forward_tile(self, xyz, sun, t):
         """xyz, sun (32,3), t (32,tau) -> albedo (32,3), sigma, sun_v, beta (32,)"""
         self.cur = 0
@@ -80,6 +102,8 @@ class Emulator:
             sig = 16 * s + 8 * h[:, None] + np.arange(8)[None, :]
             w = self.l0[sig]  # [64, 8, 4]
             pre = w[..., 0] * xyz[p, 0:1] + w[..., 1] * xyz[p, 1:2] + w[..., 2] * xyz[p, 2:3] + w[..., 3]
+            if self.l0_split:
+                pre = self._l0_split_pre(w, xyz[p])
             cur.append(self._q(sin_rev(pre)))
             pre0.append(pre)
         sv["a"].append(cur)

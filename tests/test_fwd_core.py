@@ -41,7 +41,7 @@ def test_instruction_stream_computes_the_forward_pass(tau, save):
     core = g.Core(auxs, save=save)
     params = O.procedural_satnerf_params(256, tau, seed=3)
     flat = np.concatenate([v.numpy().reshape(-1) for v in params.values()]).astype(np.float32)
-    em = E.Emulator(flat, 256, tau, bf16=True)
+    em = E.Emulator(flat, 256, tau, bf16=True, l0_split=True)
     rng = np.random.default_rng(5)
     xyz = rng.uniform(-1, 1, (32, 3))
     sun = rng.normal(size=(32, 3))
@@ -52,12 +52,14 @@ def test_instruction_stream_computes_the_forward_pass(tau, save):
     # packed stream as the kernel sees it: [piece, lane = h * 32 + row, 8 bf16] -> 4 dwords per lane
     st = em.stream.reshape(-1, 64, 8).astype(np.float32)
     bits = g.bf16_bits(st)
+    l0b = g.bf16_bits(g.l0_pieces(em.l0.astype(np.float32)))  # fc_net.0's 16 pieces: the kernel prologue writes them into the ring
+    bits = np.concatenate([l0b, bits])
     stream_bits = (bits[:, :, 0::2] | (bits[:, :, 1::2] << 16)).astype(np.uint32)
     assert stream_bits.shape[0] == core.n_pieces
 
     m = g.Machine(core, stream_bits)
-    for k in range(16):  # fc_net.0 output (the C++ prologue's job) and the aux fragment(s)
-        m.v[g.X + 4 * k:g.X + 4 * k + 4] = g.f32_to_frag(em.saved["a"][0][k])
+    for s, frag in enumerate(g.l0_b_frags(xyz.astype(np.float32))):  # the split coordinates (the C++ prologue's job) and the aux fragment(s)
+        m.v[g.L0B + 4 * s:g.L0B + 4 * s + 4] = g.f32_to_frag(frag)
     for a in range(auxs):
         m.v[g.AUX + 4 * a:g.AUX + 4 * a + 4] = g.f32_to_frag(em.saved["aux"][a])
     m.v[g.KMAGIC] = np.full(64, 49152.0, np.float32).view(np.uint32)
@@ -68,7 +70,7 @@ def test_instruction_stream_computes_the_forward_pass(tau, save):
         def unit_bytes(u):
             w = m.stores[u]  # [4, 64]
             return np.stack([(w[q] >> np.uint32(8 * j)) & 0xFF for q in range(4) for j in range(4)], 1).astype(np.int64)  # [64, 16]
-        stages = [(f"a{l}", 8 * l, 8) for l in range(1, 8)] + [("rgbh", 72, 4), ("s1", 76, 4), ("e1", 80, 4), ("s2", 84, 4), ("s3", 88, 4)]
+        stages = [(f"a{l}", 8 * l, 8) for l in range(0, 8)] + [("rgbh", 72, 4), ("s1", 76, 4), ("e1", 80, 4), ("s2", 84, 4), ("s3", 88, 4)]
         for tag, u0, nt in stages:
             pre = em.saved["pre"][tag]
             for t in range(nt):
@@ -83,7 +85,7 @@ def test_instruction_stream_computes_the_forward_pass(tau, save):
             ref = np.concatenate([em.saved["feats"][2 * t], em.saved["feats"][2 * t + 1]], 1)
             assert (np.abs(val - ref) <= 1.01 * np.exp2(e - 133.0)[:, None] + 2.0 ** -8 * np.abs(ref)).all(), t
             assert (np.abs(ref).max(1) <= 127.01 * np.exp2(e - 133.0)).all() and (e >= 6).all()
-        assert sorted(m.stores) == sorted([auxs + u for u in list(range(8, 92)) + [92]])
+        assert sorted(m.stores) == sorted([auxs + u for u in list(range(0, 92)) + [92]])
 
     head = np.stack([m.f(g.HEAD + r) for r in range(5)], 1).astype(np.float64)  # [lane, row]
     sig = m.f(g.SIG).astype(np.float64)
