@@ -13,6 +13,9 @@ so a wave's activations are 4 x 64 registers.  The wave therefore runs alone on 
     wave and row; one rendezvous per output tile (51 MFMAs), placed PF k-steps before the first read that needs it.
   * epilogue of tile t-1 in the gaps of tile t: v_fract + v_sin (the hardware sine on the exact fraction: 1.6e-6 of the reference end
     to end, profiles/r03_ab_variants.txt), hi = cvt_pk, lo = cvt_pk(v - float(hi)) -> v_accvgpr_write: 88 VALU per 51 MFMAs.
+  * save = 16 (training in the parity mode, SR_FMT16 workspaces of mlp_layout.h): the phase of every sin stage's pre-activation as
+    unorm16 (v_cvt_pknorm_u16 of the exact fractions, before the in-place sine) and the bf16 hi plane of feats, two non-temporal
+    1-KiB-per-wave stores per tile in the MFMA gaps.
 ``python fwd_core3.py`` writes csrc/mlp_fwd3_core_a{1,2}.inc and mlp_fwd3_core_clobbers.inc; tests/test_fwd_core.py checks they are
 current and executes the list on the lane-accurate model below against the fp64 emulator.
 """
@@ -33,6 +36,9 @@ TMP = (160, 164)              # two sets of epilogue temporaries (3 used of each
 SIG = 168
 VL0, VL1, VOFF = 169, 170, 171
 N_VGPR = 172
+SV = (172, 180)               # save = 16: two sets of two store quads (unorm16 phases of a tile)
+SOFF = 188                    # this lane's workspace offset (tile base + lane * 16, advanced fragment by fragment)
+N_VGPR_SAVE = 189
 XL, YL = A0 + 0, A0 + 64      # lo planes (AGPR)
 AR0, NA = A0 + 128, 4         # A-fragment ring: NA k-steps x (lo quad, hi quad)
 AUXH, AUXL = A0 + 160, A0 + 168
@@ -50,7 +56,8 @@ def rn(r, n=1):
 
 
 class Tile:
-    def __init__(self, p0, bh, bl, n_aux, acc, c0, epi, out_h, out_l, name):
+    def __init__(self, p0, bh, bl, n_aux, acc, c0, epi, out_h, out_l, name, save_frag=None):
+        self.save_frag = save_frag  # SR_FMT16 workspace fragment (1 KiB per tile of 32 points) of this tile's values 0..7; 8..15 go to the next one
         self.p0, self.n = p0, len(bh)
         order = list(range(self.n - n_aux, self.n)) + list(range(self.n - n_aux))  # aux k-steps first
         self.units = [p0 + k for k in order]
@@ -63,14 +70,14 @@ def stage_list(auxs):
     auxh = [AUXH + 4 * a for a in range(auxs)]
     auxl = [AUXL + 4 * a for a in range(auxs)]
 
-    def dense(ih, il, ks, ntiles, epi, oh, ol, name):
+    def dense(ih, il, ks, ntiles, epi, oh, ol, name, frag0=None):
         nonlocal p, tno
         for t in range(ntiles):
             bh = [ih + 4 * k for k in range(ks)] + auxh
             bl = [il + 4 * k for k in range(ks)] + auxl
             out_h = [oh + 8 * t + q for q in range(8)] if oh is not None else None
             out_l = [ol + 8 * t + q for q in range(8)] if ol is not None else None
-            tiles.append(Tile(p, bh, bl, auxs, ACC[tno & 1], True, epi, out_h, out_l, f"{name}.{t}"))
+            tiles.append(Tile(p, bh, bl, auxs, ACC[tno & 1], True, epi, out_h, out_l, f"{name}.{t}", None if frag0 is None else auxs + frag0 + 2 * t))
             p += len(bh)
             tno += 1
 
@@ -86,25 +93,25 @@ def stage_list(auxs):
 
     for l in range(7):
         a, b = ((XH, XL), (YH, YL)) if l % 2 == 0 else ((YH, YL), (XH, XL))
-        dense(a[0], a[1], KS, 8, "sin", b[0], b[1], f"L{l + 1}")
-    dense(YH, YL, KS, 8, "id", XH, XL, "feats")
+        dense(a[0], a[1], KS, 8, "sin", b[0], b[1], f"L{l + 1}", 16 * (l + 1))   # mlp_layout.h: a_l at fragment 16 l (+ auxs)
+    dense(YH, YL, KS, 8, "id", XH, XL, "feats", 128)
     dense(YH, YL, KS, 1, "sigma", None, None, "sigma")
     H0, H1 = (YH, YL), (YH + 32, YL + 32)
-    dense(XH, XL, KS, 4, "sin", H0[0], H0[1], "rgbh")
+    dense(XH, XL, KS, 4, "sin", H0[0], H0[1], "rgbh", 144)
     head(H0[0], H0[1], False, "Hr")
-    dense(XH, XL, KS, 4, "sin", H1[0], H1[1], "s1")
-    dense(H1[0], H1[1], HS, 4, "sin", H0[0], H0[1], "s2")
-    dense(H0[0], H0[1], HS, 4, "sin", H1[0], H1[1], "s3")
+    dense(XH, XL, KS, 4, "sin", H1[0], H1[1], "s1", 152)
+    dense(H1[0], H1[1], HS, 4, "sin", H0[0], H0[1], "s2", 168)
+    dense(H0[0], H0[1], HS, 4, "sin", H1[0], H1[1], "s3", 176)
     head(H1[0], H1[1], False, "Hs")
-    dense(XH, XL, KS, 4, "sin", H0[0], H0[1], "e1")
+    dense(XH, XL, KS, 4, "sin", H0[0], H0[1], "e1", 160)
     head(H0[0], H0[1], True, "Hb")
     return tiles, p
 
 
 class Core3:
-    def __init__(self, auxs, R=64, PF=2, FILL=2, ablate=()):
-        assert R % NW == 0 and R <= 64 and PF + 1 <= NA
-        self.auxs, self.R, self.PF, self.FILL = auxs, R, PF, FILL
+    def __init__(self, auxs, R=64, PF=2, FILL=2, ablate=(), save=0):
+        assert R % NW == 0 and R <= 64 and PF + 1 <= NA and save in (0, 16)
+        self.auxs, self.R, self.PF, self.FILL, self.save = auxs, R, PF, FILL, save
         self.ablate = set(ablate)
         self.tiles, self.n_units = stage_list(auxs)
         self.ins = []
@@ -194,6 +201,7 @@ class Core3:
             self._e("sync", (vm, need), f"s_waitcnt vmcnt({vm})")
             self._e("barrier", (), "s_barrier")
 
+        self.n_saves, self.cur_frag = 0, 0
         epi_q = []  # items: [earliest MFMA index, kind, args, writes (set of registers), reads_acc (accumulator base or None)]
         written_at, trans_at = {}, {}
 
@@ -204,17 +212,32 @@ class Core3:
                 epi_q.append([g0, "mov", (SIG, a), {SIG}, a])
                 return
             sin = t.epi == "sin"
+            saving = self.save and t.save_frag is not None
+            sv = None
+            if saving and sin:
+                sv = SV[self.n_saves & 1]
+                self.n_saves += 1
+
+            def phase(q):  # unorm16 phases of values 2 q, 2 q + 1 (exact fractions) -> word q of the tile's two store quads
+                if sv is not None:
+                    epi_q.append([g0, "pknorm", (sv + q, a + 2 * q, a + 2 * q + 1), set(), a])
+                    if q in (3, 7):
+                        epi_q.append([g0, "store", (sv + (q - 3), t.save_frag + (q >> 2)), set(), None])
             if sin:
                 for g in range(16):  # the exact fraction first: v_sin's own range reduction is not trusted at parity tolerances
                     epi_q.append([g0, "fract", (a + g,), set(), a])
+                phase(0)
                 epi_q.append([g0, "sin", (a + 0,), set(), a])
                 epi_q.append([g0, "sin", (a + 1,), set(), a])
             for q in range(8):
                 v0, v1 = a + 2 * q, a + 2 * q + 1
                 t0, t1, t2 = (TMP[q & 1] + j for j in range(3))
                 if sin and q < 7:
+                    phase(q + 1)
                     epi_q.append([g0, "sin", (v0 + 2,), set(), a])
                 epi_q.append([g0, "pk", (t.out_h[q], v0, v1), {t.out_h[q]}, a])
+                if saving and not sin and q in (3, 7):  # identity stage: the bf16 hi plane itself
+                    epi_q.append([g0, "store", (t.out_h[q - 3], t.save_frag + (q >> 2)), set(), None])
                 if sin and q < 7:
                     epi_q.append([g0, "sin", (v1 + 2,), set(), a])
                 epi_q.append([g0, "shl", (t0, t.out_h[q]), set(), None])
@@ -249,6 +272,14 @@ class Core3:
                 self._e("sub", args, f"v_sub_f32 v{d}, v{x}, v{y}")
             elif kind == "accw":
                 self._e("accw", args, f"v_accvgpr_write_b32 {rn(args[0])}, v{args[1]}")
+            elif kind == "pknorm":
+                self._e("pknorm", args, f"v_cvt_pknorm_u16_f32 v{args[0]}, v{args[1]}, v{args[2]}")
+            elif kind == "store":
+                reg, frag = args
+                delta = (frag - self.cur_frag) * 1024
+                self.cur_frag = frag
+                self._e("soff", (delta,), f"v_add_u32 v{SOFF}, 0x{delta & 0xffffffff:x}, v{SOFF}")
+                self._e("store", (reg, frag), f"global_store_dwordx4 v{SOFF}, v[{reg}:{reg + 3}], %[ab] nt")
             elif kind == "mov":
                 self._e("mov", args, f"v_mov_b32 v{args[0]}, v{args[1]}")
             for r in item[3]:
@@ -365,6 +396,8 @@ class Core3:
             drop |= {"barrier"}
         if "noepi" in ab:
             drop |= {"sin", "fract", "pk", "shl", "and", "sub"}
+        if "nostore" in ab:
+            drop |= {"store", "soff", "pknorm"}
         out, seen = [], False
         for x in self.ins:
             if x.op == "sync":
@@ -379,14 +412,17 @@ class Core3:
         lines = ["// GENERATED by csrc/gen/fwd_core3.py -- do not edit (tests/test_fwd_core.py checks it is current).",
                  f"// parity-mode (bf16x3) forward core, AUXS = {self.auxs}: {s['mfma']} MFMAs, {s['instructions']} instructions, "
                  f"{s['barriers']} rendezvous, {s['rows']} LDS-DMA rows, ring of {self.R} units, A fragments {self.PF} k-steps ahead.",
-                 "// Operands: %[sh] / %[sl] hi / lo stream base (SGPR pairs), %[wb] LDS ring address + wave * 2048, %[wave], %[m0save]."]
+                 "// Operands: %[sh] / %[sl] hi / lo stream base (SGPR pairs), %[wb] LDS ring address + wave * 2048, %[wave], %[m0save]"
+                 + (", %[ab] activation workspace (SGPR pair)." if self.save else ".")]
         lines += ['"' + t + '\\n"' for t in self.text()]
         return "\n".join(lines) + "\n"
 
     @staticmethod
-    def clobber_file():
-        # operands: v[0:127] (X hi, X lo in), v[128:143] (head out), v[144:159] (aux in), SIG, VL0, VL1, VOFF
+    def clobber_file(save=0):
+        # operands: v[0:127] (X hi, X lo in), v[128:143] (head out), v[144:159] (aux in), SIG, VL0, VL1, VOFF[, SOFF]
         regs = [f"v{r}" for r in range(TMP[0], TMP[1] + 4)]
+        if save:
+            regs += [f"v{r}" for r in range(SV[0], SV[1] + 8)]
         regs += [f"a{r}" for r in range(N_AGPR)]
         return ("// GENERATED by csrc/gen/fwd_core3.py: clobber list of the parity-mode forward core\n" + ", ".join(f'"{r}"' for r in regs)
                 + ', "memory", "scc"\n')
@@ -411,6 +447,8 @@ class Machine3:
         self.ar = {}
         self.issued = {"full": [], "skip": []}
         self.last_write = {}
+        self.soff = 0       # save = 16: byte offset of SOFF relative to the tile's workspace base
+        self.stores = {}    # fragment -> [4, 64] uint32
 
     def f(self, r):
         return self.v[r].view(np.float32)
@@ -488,6 +526,16 @@ class Machine3:
             elif op == "sub":
                 d, x, y = a
                 self.setf(d, self.f(x) - self.f(y))
+            elif op == "pknorm":  # v_cvt_pknorm_u16_f32: round(clamp(x, 0, 1) * 65535), RNE
+                d, s0, s1 = a
+                u = [np.rint(np.clip(self.f(r).astype(np.float64), 0, 1) * 65535).astype(np.uint32) for r in (s0, s1)]
+                self.v[d] = u[0] | (u[1] << np.uint32(16))
+            elif op == "soff":
+                self.soff += a[0]
+            elif op == "store":
+                reg, frag = a
+                assert self.soff == frag * 1024 and frag not in self.stores, (self.soff, frag)
+                self.stores[frag] = self.v[reg:reg + 4].copy()
             elif op in ("accw", "accr", "mov"):
                 self.v[a[0]] = self.v[a[1]]
                 self.last_write[a[0]] = n
@@ -508,13 +556,15 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     out_dir = a.out or os.path.dirname(here)
     for auxs in (1, 2):
-        c = Core3(auxs, PF=a.PF, FILL=a.FILL, ablate=[x for x in a.ablate.split(",") if x])
-        path = os.path.join(out_dir, f"mlp_fwd3_core_a{auxs}.inc")
-        with open(path, "w") as f:
-            f.write(c.inc_file())
-        print(path, c.stats)
-    with open(os.path.join(out_dir, "mlp_fwd3_core_clobbers.inc"), "w") as f:
-        f.write(Core3.clobber_file())
+        for save in (0, 16):
+            c = Core3(auxs, PF=a.PF, FILL=a.FILL, ablate=[x for x in a.ablate.split(",") if x], save=save)
+            path = os.path.join(out_dir, f"mlp_fwd3_core_a{auxs}{'s16' if save else ''}.inc")
+            with open(path, "w") as f:
+                f.write(c.inc_file())
+            print(path, c.stats)
+    for save, name in ((0, "mlp_fwd3_core_clobbers.inc"), (16, "mlp_fwd3_core_clobbers_s16.inc")):
+        with open(os.path.join(out_dir, name), "w") as f:
+            f.write(Core3.clobber_file(save))
 
 
 if __name__ == "__main__":

@@ -109,21 +109,22 @@ def _gen3():
 
 
 @pytest.mark.parametrize("auxs", [1, 2])
-def test_generated_parity_core_is_current(auxs):
+@pytest.mark.parametrize("save", [0, 16])
+def test_generated_parity_core_is_current(auxs, save):
     g = _gen3()
-    with open(os.path.join(ROOT, "satnerf_amd", "csrc", f"mlp_fwd3_core_a{auxs}.inc")) as f:
-        assert f.read() == g.Core3(auxs).inc_file(), "re-run satnerf_amd/csrc/gen/fwd_core3.py"
-    with open(os.path.join(ROOT, "satnerf_amd", "csrc", "mlp_fwd3_core_clobbers.inc")) as f:
-        assert f.read() == g.Core3.clobber_file()
+    with open(os.path.join(ROOT, "satnerf_amd", "csrc", f"mlp_fwd3_core_a{auxs}{'s16' if save else ''}.inc")) as f:
+        assert f.read() == g.Core3(auxs, save=save).inc_file(), "re-run satnerf_amd/csrc/gen/fwd_core3.py"
+    with open(os.path.join(ROOT, "satnerf_amd", "csrc", "mlp_fwd3_core_clobbers_s16.inc" if save else "mlp_fwd3_core_clobbers.inc")) as f:
+        assert f.read() == g.Core3.clobber_file(save)
 
 
-@pytest.mark.parametrize("tau", [4, 16])
-def test_parity_core_stream_computes_the_forward_pass(tau):
+@pytest.mark.parametrize("tau,save", [(4, 0), (16, 0), (4, 16), (16, 16)])
+def test_parity_core_stream_computes_the_forward_pass(tau, save):
     """hi / lo planes everywhere, three MFMAs per k-step: the instruction list on the unified 512-register model against the fp64
     emulator (exact operands) -- the split representation carries ~16 bits, so 1e-5 of the outputs"""
     g = _gen3()
     auxs = g.aux_steps(tau)
-    core = g.Core3(auxs)
+    core = g.Core3(auxs, save=save)
     params = O.procedural_satnerf_params(256, tau, seed=3)
     flat = np.concatenate([v.numpy().reshape(-1) for v in params.values()]).astype(np.float32)
     em = E.Emulator(flat, 256, tau, bf16=False)
@@ -164,3 +165,20 @@ def test_parity_core_stream_computes_the_forward_pass(tau):
     for name, a, b in zip(("albedo", "sigma", "sun_v", "beta"), got, (albedo, sigma, sun_v, beta)):
         err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
         assert err < 3e-5, (name, err)  # hi + lo planes carry 16-17 bits of every operand
+    if save:
+        # SR_FMT16 workspaces (mlp_layout.h): fragment pair (F + 2 t, F + 2 t + 1) of a sin stage = unorm16 phases of its pre-activations,
+        # of feats = the bf16 values; word q of a fragment = values 2 q, 2 q + 1 of the lane
+        def halves(frag):
+            w = m.stores[frag]  # [4, 64]
+            return np.stack([(w[q] >> np.uint32(16 * j)) & 0xFFFF for q in range(4) for j in range(2)], 1).astype(np.int64)  # [64, 8]
+        stages = [(f"a{l}", 16 * l, 8) for l in range(1, 8)] + [("rgbh", 144, 4), ("s1", 152, 4), ("e1", 160, 4), ("s2", 168, 4), ("s3", 176, 4)]
+        for tag, f0, nt in stages:
+            for k in range(2 * nt):
+                want = np.rint((em.saved["pre"][tag][k] % 1.0) * 65535).astype(np.int64)
+                d = np.abs(halves(auxs + f0 + k) - want)
+                assert np.minimum(d, 65535 - d).max() <= 24, (tag, k)  # fp32 accumulation of ~16-bit operands vs fp64: 3e-4 of a revolution
+        for k in range(16):
+            got = g.bf16_to_f32(halves(auxs + 128 + k).astype(np.uint32))
+            ref = em.saved["feats"][k]
+            assert (np.abs(got - ref) <= 2.0 ** -8 * np.abs(ref) + 1e-4).all(), k
+        assert sorted(m.stores) == sorted(auxs + f for f in list(range(16, 144)) + list(range(144, 184)))
