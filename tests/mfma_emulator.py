@@ -25,7 +25,7 @@ class Emulator:
     def __init__(self, flat, feat=256, tau=4, bf16=False, l0_split=False):
         self.l0_split = l0_split  # fc_net.0 as the generated core computes it: two k-steps of three-way bf16 splits (gen/fwd_core.py l0_terms)
         m = packing.forward_maps(feat, tau)
-        self.m, self.tau, self.auxs, self.bf16 = m, tau, m["auxs"], bf16
+        self.m, self.tau, self.auxs, self.bf16, self.m_feat = m, tau, m["auxs"], bf16, feat
         flat = np.asarray(flat, np.float32)
         self.flat = flat
         idx = m["idx"]
@@ -98,7 +98,8 @@ class Emulator:
         sv = self.saved = {"aux": aux, "a": [], "pre": {}}
         cur = []
         pre0 = []
-        for s in range(16):
+        nks, nt, nth = self.m_feat // 16, self.m_feat // 32, self.m_feat // 64  # k-steps / output tiles of a trunk layer, tiles of a head layer
+        for s in range(nks):
             sig = 16 * s + 8 * h[:, None] + np.arange(8)[None, :]
             w = self.l0[sig]  # [64, 8, 4]
             pre = w[..., 0] * xyz[p, 0:1] + w[..., 1] * xyz[p, 1:2] + w[..., 2] * xyz[p, 2:3] + w[..., 3]
@@ -109,22 +110,22 @@ class Emulator:
         sv["a"].append(cur)
         sv["pre"]["a0"] = pre0
         for l in range(1, 8):
-            cur = self._stage(cur, aux, 8, sin_rev, tag=f"a{l}")
+            cur = self._stage(cur, aux, nt, sin_rev, tag=f"a{l}")
             sv["a"].append(cur)
-        feats = self._stage(cur, aux, 8, lambda v: v)
+        feats = self._stage(cur, aux, nt, lambda v: v)
         sv["feats"] = feats
         sig_acc = self._tile(cur + aux)
         softplus = lambda v: np.where(v > 20, v, np.log1p(np.exp(np.minimum(v, 20))))  # noqa: E731
         sigmoid = lambda v: 1 / (1 + np.exp(-v))  # noqa: E731
         sigma = softplus(sig_acc[:32, 0])
         c = np.zeros((64, 16))
-        rgbh = self._stage(feats, aux, 4, sin_rev, tag="rgbh")
+        rgbh = self._stage(feats, aux, nth, sin_rev, tag="rgbh")
         c += self._tile(rgbh)
-        s1 = self._stage(feats, aux, 4, sin_rev, tag="s1")
-        s2 = self._stage(s1, aux, 4, sin_rev, tag="s2")
-        s3 = self._stage(s2, aux, 4, sin_rev, tag="s3")
+        s1 = self._stage(feats, aux, nth, sin_rev, tag="s1")
+        s2 = self._stage(s1, aux, nth, sin_rev, tag="s2")
+        s3 = self._stage(s2, aux, nth, sin_rev, tag="s3")
         c += self._tile(s3)
-        e1 = self._stage(feats, aux, 4, sin_rev, tag="e1")
+        e1 = self._stage(feats, aux, nth, sin_rev, tag="e1")
         sv.update(rgbh=rgbh, s1=s1, s2=s2, s3=s3, e1=e1)
         acc = c + self._tile(e1 + aux)
         assert self.cur == self.stream.shape[0], (self.cur, self.stream.shape)

@@ -182,3 +182,56 @@ def test_parity_core_stream_computes_the_forward_pass(tau, save):
             ref = em.saved["feats"][k]
             assert (np.abs(got - ref) <= 2.0 ** -8 * np.abs(ref) + 1e-4).all(), k
         assert sorted(m.stores) == sorted(auxs + f for f in list(range(16, 144)) + list(range(144, 184)))
+
+
+# ---- the width-512 core: csrc/gen/fwd_core512.py -> csrc/mlp_fwd512_core_a*.inc ---------------------------------------------------------
+GEN512 = os.path.join(ROOT, "satnerf_amd", "csrc", "gen", "fwd_core512.py")
+
+
+def _gen512():
+    spec = importlib.util.spec_from_file_location("fwd_core512_gen", GEN512)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("auxs", [1, 2])
+def test_generated_width512_core_is_current(auxs):
+    g = _gen512()
+    with open(os.path.join(ROOT, "satnerf_amd", "csrc", f"mlp_fwd512_core_a{auxs}.inc")) as f:
+        assert f.read() == g.Core512(auxs).inc_file(), "re-run satnerf_amd/csrc/gen/fwd_core512.py"
+    with open(os.path.join(ROOT, "satnerf_amd", "csrc", "mlp_fwd512_core_clobbers.inc")) as f:
+        assert f.read() == g.Core512.clobber_file()
+
+
+@pytest.mark.parametrize("tau", [4, 16])
+def test_width512_core_stream_computes_the_forward_pass(tau):
+    g = _gen512()
+    auxs = g.aux_steps(tau)
+    core = g.Core512(auxs)
+    params = O.procedural_satnerf_params(512, tau, seed=3)
+    flat = np.concatenate([v.numpy().reshape(-1) for v in params.values()]).astype(np.float32)
+    em = E.Emulator(flat, 512, tau, bf16=True)
+    rng = np.random.default_rng(5)
+    xyz = rng.uniform(-1, 1, (32, 3))
+    sun = rng.normal(size=(32, 3))
+    sun /= np.linalg.norm(sun, axis=1, keepdims=True)
+    t = rng.uniform(-1, 1, (32, tau))
+    albedo, sigma, sun_v, beta = em.forward_tile(xyz, sun, t)
+    bits = g.bf16_bits(em.stream.reshape(-1, 64, 8).astype(np.float32))
+    stream_bits = (bits[:, :, 0::2] | (bits[:, :, 1::2] << 16)).astype(np.uint32)
+    assert stream_bits.shape[0] == core.n_pieces
+    m = g.Machine512(core, stream_bits)
+    for k in range(32):  # fc_net.0 output (the C++ prologue's job) and the aux fragment(s), which arrive in VGPRs
+        m.v[g.X + 4 * k:g.X + 4 * k + 4] = g.f32_to_frag(em.saved["a"][0][k])
+    for a in range(auxs):
+        m.v[g.IN_AUX + 4 * a:g.IN_AUX + 4 * a + 4] = g.f32_to_frag(em.saved["aux"][a])
+    m.run()
+    head = np.stack([m.f(g.OUT_HEAD + r) for r in range(5)], 1).astype(np.float64)
+    sig = m.f(g.SIG).astype(np.float64)
+    sigmoid = lambda v: 1 / (1 + np.exp(-v))  # noqa: E731
+    softplus = lambda v: np.where(v > 20, v, np.log1p(np.exp(np.minimum(v, 20))))  # noqa: E731
+    got = (sigmoid(head[:32, 0:3]) * 1.002 - 0.001, softplus(sig[:32]), sigmoid(head[:32, 3]), softplus(head[32:, 0]))
+    for name, a, b in zip(("albedo", "sigma", "sun_v", "beta"), got, (albedo, sigma, sun_v, beta)):
+        err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+        assert err < 5e-4, (name, err)  # K = 512 fp32 accumulation vs fp64: a few bf16 roundings of intermediate activations flip
