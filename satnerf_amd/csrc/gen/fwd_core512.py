@@ -11,6 +11,9 @@ Same method as fwd_core.py (read that docstring first); the machine shape is fwd
     wave), one rendezvous per output tile (33 MFMAs; two tiles per rendezvous would need a ring of 5 tiles), A fragments PF MFMAs
     ahead, the epilogue of tile t-1 (16 v_sin,
     8 v_cvt_pk, 8 v_accvgpr_write when the output vector lives in AGPRs) in the gaps of tile t.
+save = 8 (the training forward): the PHASE8 byte of every sin stage's pre-activation (SDWA add into its byte of the store quad before
+the in-place sine), MX8 feats + scale bytes, non-temporal stores in the MFMA gaps -- fwd_core.py's scheme with the unit numbers of
+width 512 (mlp_layout.h: a_l at 16 l + t, feats 128, rgbh 144, s1 152, e1 160, s2 168, s3 176, scale unit 184, all + auxs).
 5,370 MFMAs per 32 points (tau <= 8).  ``python fwd_core512.py`` writes csrc/mlp_fwd512_core_a{1,2}.inc and the clobber list;
 tests/test_fwd_core.py checks they are current and executes the list on the lane-accurate model below against the emulator.
 """
@@ -34,6 +37,9 @@ SIG = 168
 VL = (169, 170, 171)          # LDS read bases: ring + lane * 16 (+ 64 KiB, + 128 KiB)
 VOFF = 172
 N_VGPR = 173
+SV = (174, 178)               # save = 8: two quads of store data (register tuples are 64-bit aligned on gfx950)
+SOFF, KMAGIC, EB, MXT, K128 = 182, 183, 184, 188, 192   # workspace offset, PHASE8 constant, feats scale bytes (4 regs), MX8 temporaries (4), 128.0f
+N_VGPR_SAVE = 193
 Y = A0 + 0                    # 128 AGPRs; the head hidden vectors H0 / H1 are its halves
 AR0, NA = A0 + 128, 6
 AUX = A0 + 152                # 2 quads
@@ -43,7 +49,8 @@ IN_AUX, OUT_HEAD = 144, 128   # operands arrive / leave in VGPRs: aux fragments 
 
 
 class Tile:
-    def __init__(self, p0, bregs, n_aux, acc, c0, epi, out, name):
+    def __init__(self, p0, bregs, n_aux, acc, c0, epi, out, name, save_unit=None):
+        self.save_unit = save_unit  # save = 8: workspace unit of this tile's 16 values per lane
         self.p0, self.n = p0, len(bregs)
         order = list(range(self.n - n_aux, self.n)) + list(range(self.n - n_aux))  # aux k-steps first
         self.pieces = [p0 + k for k in order]
@@ -56,12 +63,12 @@ def stage_list(auxs):
     tiles, p, tno = [], 0, 0
     auxb = [AUX + 4 * a for a in range(auxs)]
 
-    def dense(inp, ks, ntiles, epi, outbase, name):
+    def dense(inp, ks, ntiles, epi, outbase, name, unit0=None):
         nonlocal p, tno
         for t in range(ntiles):
             b = [inp + 4 * k for k in range(ks)] + auxb
             out = [outbase + 8 * t + q for q in range(8)] if outbase is not None else None
-            tiles.append(Tile(p, b, auxs, ACC[tno & 1], True, epi, out, f"{name}.{t}"))
+            tiles.append(Tile(p, b, auxs, ACC[tno & 1], True, epi, out, f"{name}.{t}", None if unit0 is None else auxs + unit0 + t))
             p += len(b)
             tno += 1
 
@@ -76,23 +83,26 @@ def stage_list(auxs):
 
     H0, H1 = Y, Y + 4 * HS
     for l in range(7):
-        dense(X if l % 2 == 0 else Y, KS, MT, "sin", Y if l % 2 == 0 else X, f"L{l + 1}")
-    dense(Y, KS, MT, "id", X, "feats")
+        dense(X if l % 2 == 0 else Y, KS, MT, "sin", Y if l % 2 == 0 else X, f"L{l + 1}", MT * (l + 1))
+    dense(Y, KS, MT, "id", X, "feats", 8 * MT)
     dense(Y, KS, 1, "sigma", None, "sigma")
-    dense(X, KS, MTH, "sin", H0, "rgbh")
+    dense(X, KS, MTH, "sin", H0, "rgbh", 9 * MT)
     head(H0, False, "Hr")
-    dense(X, KS, MTH, "sin", H1, "s1")
-    dense(H1, HS, MTH, "sin", H0, "s2")
-    dense(H0, HS, MTH, "sin", H1, "s3")
+    dense(X, KS, MTH, "sin", H1, "s1", 9 * MT + MTH)
+    dense(H1, HS, MTH, "sin", H0, "s2", 9 * MT + 3 * MTH)
+    dense(H0, HS, MTH, "sin", H1, "s3", 9 * MT + 4 * MTH)
     head(H1, False, "Hs")
-    dense(X, KS, MTH, "sin", H0, "e1")
+    dense(X, KS, MTH, "sin", H0, "e1", 9 * MT + 2 * MTH)
     head(H0, True, "Hb")
     return tiles, p
 
 
 class Core512:
-    def __init__(self, auxs, R=144, PF=5, GROUP=1, FILL=2, ablate=()):
-        assert R % NW == 0 and R <= 192 and PF + 1 <= NA
+    def __init__(self, auxs, R=144, PF=5, GROUP=1, FILL=None, ablate=(), save=0):
+        assert R % NW == 0 and R <= 192 and PF + 1 <= NA and save in (0, 8)
+        if FILL is None:
+            FILL = 3 if save else 2
+        self.save = save
         self.auxs, self.R, self.PF, self.GROUP, self.FILL = auxs, R, PF, GROUP, FILL
         self.ablate = set(ablate)
         self.tiles, self.n_pieces = stage_list(auxs)
@@ -164,6 +174,7 @@ class Core512:
             self._e("sync", (vm, need), f"s_waitcnt vmcnt({vm})")
             self._e("barrier", (), "s_barrier")
 
+        self.n_saves, self.cur_unit = 0, 0
         epi_q = []  # [earliest MFMA index, kind, args, registers written (hazard tracking / forced flushes), accumulator read or None]
         written_at, trans_at = {}, {}
 
@@ -175,6 +186,41 @@ class Core512:
                 return
             sin = t.epi == "sin"
             to_agpr = t.out[0] >= A0
+
+            def out_pk(q):  # cvt_pk of values 2 q, 2 q + 1 into the output vector (through a temporary when it lives in AGPRs)
+                d = TMP[q & 3] if to_agpr else t.out[q]
+                epi_q.append([g0, "pk", (d, a + 2 * q, a + 2 * q + 1), set() if to_agpr else {d}, a])
+                if to_agpr:
+                    epi_q.append([g0, "accw", (t.out[q], d), {t.out[q]}, None])
+            if self.save and t.save_unit is not None:
+                sv = SV[self.n_saves & 1]
+                self.n_saves += 1
+                if sin:
+                    # PHASE8: byte = low mantissa byte of (pre-activation + 1.5 * 2^15), written straight into its place of the store quad
+                    # by an SDWA add BEFORE the value's sin overwrites the accumulator; cvt_pk one pair behind (trans -> VALU use)
+                    for q in range(8):
+                        for g in (2 * q, 2 * q + 1):
+                            epi_q.append([g0, "phase", (sv + (g >> 2), g & 3, a + g), set(), a])
+                            epi_q.append([g0, "sin", (a + g,), set(), a])
+                        if q > 0:
+                            out_pk(q - 1)
+                    epi_q.append([g0, "store", (sv, t.save_unit), set(), None])
+                    out_pk(7)
+                else:
+                    # MX8: E = exponent of 1.0079 max|v| clamped to [6, 254]; u = cvt_pk_u8(v * 2^(133 - E) + 128); byte t of EB = E
+                    tt = t.save_unit - (self.auxs + 8 * MT)
+                    epi_q.append([g0, "mx_max", (a, 0, True), set(), a])
+                    for g in range(2, 16, 2):
+                        epi_q.append([g0, "mx_max", (a, g, False), set(), a])
+                    epi_q.append([g0, "mx_exp", (tt,), set(), None])
+                    for g in range(16):
+                        epi_q.append([g0, "mx_q", (sv + (g >> 2), g & 3, a + g), set(), a])
+                    epi_q.append([g0, "store", (sv, t.save_unit), set(), None])
+                    for q in range(8):
+                        out_pk(q)
+                    if tt == MT - 1:
+                        epi_q.append([g0, "store_scale", (self.auxs + 9 * MT + 5 * MTH,), set(), None])
+                return
             if sin:
                 epi_q.append([g0, "sin", (a + 0,), set(), a])
                 epi_q.append([g0, "sin", (a + 1,), set(), a])
@@ -205,6 +251,39 @@ class Core512:
                 self._e("accw", args, f"v_accvgpr_write_b32 {rn(args[0])}, v{args[1]}")
             elif kind == "mov":
                 self._e("mov", args, f"v_mov_b32 v{args[0]}, v{args[1]}")
+            elif kind == "phase":
+                d, byte, src = args
+                self._e("phase", args, f"v_add_f32_sdwa v{d}, v{src}, v{KMAGIC} dst_sel:BYTE_{byte} dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD")
+            elif kind in ("store", "store_scale"):
+                reg, unit = (args[0], args[1]) if kind == "store" else (EB, args[0])
+                assert reg % 2 == 0
+                delta = (unit - self.cur_unit) * 1024
+                self.cur_unit = unit
+                self._e("soff", (delta,), f"v_add_u32 v{SOFF}, 0x{delta & 0xffffffff:x}, v{SOFF}")
+                self._e("store", (reg, unit), f"global_store_dwordx4 v{SOFF}, v[{reg}:{reg + 3}], %[ab]" + (" nt" if kind == "store" else ""))
+            elif kind == "mx_max":
+                a_, g, first = args
+                if first:
+                    self._e("mx_max", (MXT, a_ + g, a_ + g + 1, None), f"v_max_f32 v{MXT}, |v{a_ + g}|, |v{a_ + g + 1}|")
+                else:
+                    self._e("mx_max", (MXT, a_ + g, a_ + g + 1, MXT), f"v_max3_f32 v{MXT}, |v{a_ + g}|, |v{a_ + g + 1}|, v{MXT}")
+            elif kind == "mx_exp":
+                (tt,) = args
+                m_, e, inv = MXT, MXT + 1, MXT + 2
+                self._e("mx_e1", (m_,), f"v_fmac_f32 v{m_}, 0x3c000000, v{m_}")
+                self._e("mx_e2", (e, m_), f"v_lshrrev_b32 v{e}, 23, v{m_}")
+                self._e("mx_e3a", (e,), f"v_max_u32 v{e}, 6, v{e}")
+                self._e("mx_e3", (e,), f"v_min_u32 v{e}, 0xfe, v{e}")
+                self._e("mx_e4", (inv, e), f"v_sub_u32 v{inv}, 0x104, v{e}")
+                self._e("mx_e5", (inv,), f"v_lshlrev_b32 v{inv}, 23, v{inv}")
+                if tt & 3:
+                    self._e("mx_e6", (EB + (tt >> 2), e, 8 * (tt & 3), False), f"v_lshl_or_b32 v{EB + (tt >> 2)}, v{e}, {8 * (tt & 3)}, v{EB + (tt >> 2)}")
+                else:
+                    self._e("mx_e6", (EB + (tt >> 2), e, 0, True), f"v_mov_b32 v{EB + (tt >> 2)}, v{e}")
+            elif kind == "mx_q":
+                d, byte, src = args
+                self._e("mx_q1", (MXT + 3, src, MXT + 2), f"v_fma_f32 v{MXT + 3}, v{src}, v{MXT + 2}, v{K128}")
+                self._e("mx_q2", (d, MXT + 3, byte), f"v_cvt_pk_u8_f32 v{d}, v{MXT + 3}, {byte}, v{d}")
             for r in item[3]:
                 written_at[r] = len(self.ins) - 1
 
@@ -291,6 +370,8 @@ class Core512:
             drop |= {"barrier"}
         if "noepi" in ab:
             drop |= {"sin", "pk"}
+        if "nostore" in ab:
+            drop |= {"store", "soff"}
         out, seen = [], False
         for x in self.ins:
             if x.op == "sync":
@@ -305,14 +386,17 @@ class Core512:
         lines = ["// GENERATED by csrc/gen/fwd_core512.py -- do not edit (tests/test_fwd_core.py checks it is current).",
                  f"// width-512 forward core, AUXS = {self.auxs}: {s['mfma']} MFMAs, {s['instructions']} instructions, {s['barriers']} rendezvous, "
                  f"{s['rows']} LDS-DMA rows, ring of {self.R} pieces, A fragments {self.PF} ahead.",
-                 "// Operands: %[sb] stream base (SGPR pair), %[wb] LDS ring address + wave * 1024, %[wave] wave index, %[m0save] scratch SGPR."]
+                 "// Operands: %[sb] stream base (SGPR pair), %[wb] LDS ring address + wave * 1024, %[wave] wave index, %[m0save] scratch SGPR"
+                 + (", %[ab] activation workspace (SGPR pair)." if self.save else ".")]
         lines += ['"' + t + '\\n"' for t in self.text()]
         return "\n".join(lines) + "\n"
 
     @staticmethod
-    def clobber_file():
-        # operands: v[0:127] (X in), v[128:143] (head out), v[144:151] (aux in), SIG, VL, VOFF
+    def clobber_file(save=0):
+        # operands: v[0:127] (X in), v[128:143] (head out), v[144:151] (aux in), SIG, VL, VOFF[, KMAGIC, SOFF, K128]
         regs = [f"v{r}" for r in list(range(ACC[1], ACC[1] + 16)) + list(TMP) if not IN_AUX <= r < IN_AUX + 8]
+        if save:
+            regs += [f"v{r}" for r in range(SV[0], N_VGPR_SAVE) if r not in (KMAGIC, SOFF, K128)]
         regs += [f"a{r}" for r in range(N_AGPR)]
         return ("// GENERATED by csrc/gen/fwd_core512.py: clobber list of the width-512 forward core\n" + ", ".join(f'"{r}"' for r in regs)
                 + ', "memory", "scc"\n')
@@ -335,6 +419,8 @@ class Machine512:
         self.issued = {"full": [], "skip": []}
         self.last_write = {}
         self.voff_rows = 0
+        self.soff = 0
+        self.stores = {}
 
     def f(self, r):
         return self.v[r].view(np.float32)
@@ -408,6 +494,40 @@ class Machine512:
             elif op in ("accw", "accr", "mov"):
                 self.v[a[0]] = self.v[a[1]]
                 self.last_write[a[0]] = n
+            elif op == "phase":
+                d, byte, src = a
+                b = (self.f(src) + self.f(KMAGIC)).astype(np.float32).view(np.uint32) & np.uint32(0xFF)
+                self.v[d] = (self.v[d] & np.uint32(~(0xFF << (8 * byte)) & 0xFFFFFFFF)) | (b << np.uint32(8 * byte))
+            elif op == "soff":
+                self.soff += a[0]
+            elif op == "store":
+                reg, unit = a
+                assert self.soff == unit * 1024 and unit not in self.stores, (self.soff, unit)
+                self.stores[unit] = self.v[reg:reg + 4].copy()
+            elif op == "mx_max":
+                m_, x, y, z = a
+                r = np.maximum(np.abs(self.f(x)), np.abs(self.f(y)))
+                self.setf(m_, r if z is None else np.maximum(r, self.f(z)))
+            elif op == "mx_e1":
+                self.setf(a[0], self.f(a[0]).astype(np.float64) * 0.0078125 + self.f(a[0]).astype(np.float64))
+            elif op == "mx_e2":
+                self.v[a[0]] = self.v[a[1]] >> np.uint32(23)
+            elif op == "mx_e3":
+                self.v[a[0]] = np.clip(self.v[a[0]], 6, 254).astype(np.uint32)
+            elif op == "mx_e4":
+                self.v[a[0]] = (np.uint32(260) - self.v[a[1]]).astype(np.uint32)
+            elif op == "mx_e5":
+                self.v[a[0]] = (self.v[a[0]] << np.uint32(23)).astype(np.uint32)
+            elif op == "mx_e6":
+                d, e, sh, first = a
+                self.v[d] = self.v[e].copy() if first else ((self.v[e] << np.uint32(sh)) | self.v[d]).astype(np.uint32)
+            elif op == "mx_q1":
+                t_, src, inv = a
+                self.setf(t_, self.f(src).astype(np.float64) * self.f(inv).astype(np.float64) + self.f(K128).astype(np.float64))
+            elif op == "mx_q2":
+                d, t_, byte = a
+                b = np.clip(np.rint(self.f(t_).astype(np.float64)), 0, 255).astype(np.uint32)
+                self.v[d] = (self.v[d] & np.uint32(~(0xFF << (8 * byte)) & 0xFFFFFFFF)) | (b << np.uint32(8 * byte))
         assert self.consumed.all()
 
 
@@ -419,18 +539,20 @@ def main():
     ap.add_argument("--ablate", default="")
     ap.add_argument("--PF", type=int, default=5)
     ap.add_argument("--GROUP", type=int, default=1)
-    ap.add_argument("--FILL", type=int, default=2)
+    ap.add_argument("--FILL", type=int, default=None)
     a = ap.parse_args()
     here = os.path.dirname(os.path.abspath(__file__))
     out_dir = a.out or os.path.dirname(here)
     for auxs in (1, 2):
-        c = Core512(auxs, PF=a.PF, GROUP=a.GROUP, FILL=a.FILL, ablate=[x for x in a.ablate.split(",") if x])
-        path = os.path.join(out_dir, f"mlp_fwd512_core_a{auxs}.inc")
-        with open(path, "w") as f:
-            f.write(c.inc_file())
-        print(path, c.stats)
-    with open(os.path.join(out_dir, "mlp_fwd512_core_clobbers.inc"), "w") as f:
-        f.write(Core512.clobber_file())
+        for save in (0, 8):
+            c = Core512(auxs, PF=a.PF, GROUP=a.GROUP, FILL=a.FILL, ablate=[x for x in a.ablate.split(",") if x], save=save)
+            path = os.path.join(out_dir, f"mlp_fwd512_core_a{auxs}{'s8' if save else ''}.inc")
+            with open(path, "w") as f:
+                f.write(c.inc_file())
+            print(path, c.stats)
+    for save, name in ((0, "mlp_fwd512_core_clobbers.inc"), (8, "mlp_fwd512_core_clobbers_s8.inc")):
+        with open(os.path.join(out_dir, name), "w") as f:
+            f.write(Core512.clobber_file(save))
 
 
 if __name__ == "__main__":

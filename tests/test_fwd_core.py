@@ -196,19 +196,20 @@ def _gen512():
 
 
 @pytest.mark.parametrize("auxs", [1, 2])
-def test_generated_width512_core_is_current(auxs):
+@pytest.mark.parametrize("save", [0, 8])
+def test_generated_width512_core_is_current(auxs, save):
     g = _gen512()
-    with open(os.path.join(ROOT, "satnerf_amd", "csrc", f"mlp_fwd512_core_a{auxs}.inc")) as f:
-        assert f.read() == g.Core512(auxs).inc_file(), "re-run satnerf_amd/csrc/gen/fwd_core512.py"
-    with open(os.path.join(ROOT, "satnerf_amd", "csrc", "mlp_fwd512_core_clobbers.inc")) as f:
-        assert f.read() == g.Core512.clobber_file()
+    with open(os.path.join(ROOT, "satnerf_amd", "csrc", f"mlp_fwd512_core_a{auxs}{'s8' if save else ''}.inc")) as f:
+        assert f.read() == g.Core512(auxs, save=save).inc_file(), "re-run satnerf_amd/csrc/gen/fwd_core512.py"
+    with open(os.path.join(ROOT, "satnerf_amd", "csrc", "mlp_fwd512_core_clobbers_s8.inc" if save else "mlp_fwd512_core_clobbers.inc")) as f:
+        assert f.read() == g.Core512.clobber_file(save)
 
 
-@pytest.mark.parametrize("tau", [4, 16])
-def test_width512_core_stream_computes_the_forward_pass(tau):
+@pytest.mark.parametrize("tau,save", [(4, 0), (16, 0), (4, 8), (16, 8)])
+def test_width512_core_stream_computes_the_forward_pass(tau, save):
     g = _gen512()
     auxs = g.aux_steps(tau)
-    core = g.Core512(auxs)
+    core = g.Core512(auxs, save=save)
     params = O.procedural_satnerf_params(512, tau, seed=3)
     flat = np.concatenate([v.numpy().reshape(-1) for v in params.values()]).astype(np.float32)
     em = E.Emulator(flat, 512, tau, bf16=True)
@@ -226,7 +227,28 @@ def test_width512_core_stream_computes_the_forward_pass(tau):
         m.v[g.X + 4 * k:g.X + 4 * k + 4] = g.f32_to_frag(em.saved["a"][0][k])
     for a in range(auxs):
         m.v[g.IN_AUX + 4 * a:g.IN_AUX + 4 * a + 4] = g.f32_to_frag(em.saved["aux"][a])
+    m.v[g.KMAGIC] = np.full(64, 49152.0, np.float32).view(np.uint32)
+    m.v[g.K128] = np.full(64, 128.0, np.float32).view(np.uint32)
     m.run()
+    if save:  # the 8-bit workspaces at width 512 (mlp_layout.h): a_l at 16 l + t, feats 128 + t, rgbh 144, s1 152, e1 160, s2 168, s3 176, scales 184
+        def unit_bytes(u):
+            w = m.stores[u]
+            return np.stack([(w[q] >> np.uint32(8 * j)) & 0xFF for q in range(4) for j in range(4)], 1).astype(np.int64)  # [64, 16]
+        stages = [(f"a{l}", 16 * l, 16) for l in range(1, 8)] + [("rgbh", 144, 8), ("s1", 152, 8), ("e1", 160, 8), ("s2", 168, 8), ("s3", 176, 8)]
+        for tag, u0, nt in stages:
+            pre = em.saved["pre"][tag]
+            for t in range(nt):
+                want = np.rint((np.concatenate([pre[2 * t], pre[2 * t + 1]], 1) % 1.0) * 256).astype(np.int64) % 256
+                d = (unit_bytes(auxs + u0 + t) - want) % 256
+                assert np.minimum(d, 256 - d).max() <= 1, (tag, t)
+        sc = unit_bytes(auxs + 184)  # [64, 16]: byte t = E of feats tile t
+        for t in range(16):
+            e = sc[:, t]
+            val = (unit_bytes(auxs + 128 + t) - 128) * np.exp2(e - 133.0)[:, None]
+            ref = np.concatenate([em.saved["feats"][2 * t], em.saved["feats"][2 * t + 1]], 1)
+            assert (np.abs(val - ref) <= 1.01 * np.exp2(e - 133.0)[:, None] + 2.0 ** -8 * np.abs(ref)).all(), t
+            assert (np.abs(ref).max(1) <= 127.01 * np.exp2(e - 133.0)).all() and (e >= 6).all()
+        assert sorted(m.stores) == sorted([auxs + u for u in list(range(16, 184)) + [184]])
     head = np.stack([m.f(g.OUT_HEAD + r) for r in range(5)], 1).astype(np.float64)
     sig = m.f(g.SIG).astype(np.float64)
     sigmoid = lambda v: 1 / (1 + np.exp(-v))  # noqa: E731
