@@ -121,7 +121,7 @@ def cpu_baseline(phase, n_rays, n_samples, budget_s=12.0):
             "sample": f"{it} x {n} rays x {n_samples} samples, {phase}, torch {torch.__version__} CPU fp32"}
 
 
-def measure(phase, mode, n_rays, n_samples, steps, warmup, world, rank, dev, want_kernels=True, bwd_fmt=None):
+def measure(phase, mode, n_rays, n_samples, steps, warmup, world, rank, dev, want_kernels=True, bwd_fmt=None, fc_units=None):
     """Run one phase in one numeric mode: returns (seconds for `steps` steps on this rank, {kernel: mean ms} from the eager leg)."""
     from satnerf_amd import ops, rendering
     from satnerf_amd import train as train_mod
@@ -131,6 +131,8 @@ def measure(phase, mode, n_rays, n_samples, steps, warmup, world, rank, dev, wan
     args = default_args(n_samples=n_samples, mlp_mode=mode)
     if bwd_fmt is not None:
         args.bwd_fmt = bwd_fmt
+    if fc_units is not None:
+        args.fc_units = fc_units
     torch.manual_seed(0)  # identical init on every rank
     model = load_model(args).to(dev)
     emb = torch.nn.Embedding(args.t_embbeding_vocab, args.t_embbeding_tau).to(dev)
@@ -309,6 +311,18 @@ def main():
             sdt, _, sfmt = measure("train", "bf16", a.rays, a.samples, n_sub, 0, 1, 0, dev, want_kernels=False, bwd_fmt=16)
             out["train_bf16_state16"] = {"metric": f"training rays/sec, mlp_mode=bf16, saved state {sfmt}-bit (gradients <= 1.4e-2 of the reference)",
                                          "value": a.rays * n_sub / sdt, "ms_per_step": sdt / n_sub * 1e3, "steps": n_sub}
+        if a.mode == "bf16":  # the reference's own sat-nerf width (opt.py:50 fc_units = 512; run_all.sh trains with it), same workload
+            release_leg()
+            wdt, wk, _ = measure("forward", "bf16", a.rays, a.samples, n_fwd, 0, 1, 0, dev, fc_units=512)
+            flop512 = 5259264.0 * a.rays * a.samples  # SURVEY.md 8(d) at width 512
+            out["forward_width512"] = {"metric": "inference rays/sec at fc_units=512 (render_rays no_grad)", "value": a.rays * n_fwd / wdt,
+                                       "ms_per_step": wdt / n_fwd * 1e3, "steps": n_fwd, "kernel_ms": wk.get("mlp_fwd"),
+                                       "mlp_frac_of_mfma_peak": flop512 / (wk["mlp_fwd"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if wk.get("mlp_fwd") else None}
+            release_leg()
+            n512 = max(a.steps // 4, 10)
+            vdt, _, vfmt = measure("train", "bf16", a.rays, a.samples, n512, 0, 1, 0, dev, want_kernels=False, fc_units=512)
+            out["train_width512"] = {"metric": f"training rays/sec at fc_units=512, mlp_mode=bf16, saved state {vfmt}-bit",
+                                     "value": a.rays * n512 / vdt, "ms_per_step": vdt / n512 * 1e3, "steps": n512}
         if a.mode != "bf16x3":
             release_leg()
             qdt, qk, _ = measure("forward", "bf16x3", a.rays, a.samples, n_fwd, 0, 1, 0, dev)

@@ -1,0 +1,36 @@
+"""The kernels behind the A/B switches stay correct: SATNERF_FWD_V1=1 (the hipcc-scheduled forward kernels of mlp_fwd.inc instead of the
+generated cores -- also the fallback when a workspace exceeds the generated streams' 32-bit offsets) and SATNERF_WGRAD_V2=1 (the
+fat-wave weight-gradient kernel wgrad8f.hip).  The switches are read once per process, so each case runs the relevant reference-golden
+tests in a child interpreter with the variable set."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(env_extra, test_file, keyword):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join("tests", test_file), "-q", "-x", "-m", "gpu", "-k", keyword, "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "no tests ran" not in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.gpu
+def test_hipcc_scheduled_forward_kernels_match_the_goldens():
+    # parity mode, throughput mode, f16, width 512, one-launch render: all through launch_fwd<...> of mlp_fwd.inc
+    _run({"SATNERF_FWD_V1": "1"}, "test_hip_parity.py",
+         "mlp_forward_points_golden or render_rays_golden_parity_mode or f16_mode_matches or width_512_fused or one_launch_render")
+
+
+@pytest.mark.gpu
+def test_hipcc_scheduled_training_forward_matches_the_gradient_goldens():
+    _run({"SATNERF_FWD_V1": "1"}, "test_hip_backward.py", "gradients_match_reference_golden")
+
+
+@pytest.mark.gpu
+def test_fat_wave_weight_gradient_kernel_matches_the_gradient_goldens():
+    _run({"SATNERF_WGRAD_V2": "1"}, "test_hip_backward.py", "gradients_match_reference_golden or direct_step_matches_autograd")
