@@ -16,6 +16,9 @@
 // rendezvous before its decode, so a wave may read scale bytes another wave fetched.
 #include <stdlib.h>
 
+#ifndef SR_W8_ABL
+#define SR_W8_ABL 0  // 2..4: timing ablations (wrong results), tools/ab_wgrad_abl.sh
+#endif
 #include "codec8.h"
 #include "common.h"
 #include "mlp_device.h"
@@ -107,6 +110,9 @@ __global__ void __launch_bounds__(1024) wgrad8_kernel(const Wgrad8Params prm) {
     }
   };
   auto decode = [&](int slot) {
+#if SR_W8_ABL == 3  // timing experiment: no decode at all
+    return;
+#endif
     if (!has_prim || p_codec == kRaw16) return;
     char* sl = lds + slot * kSlot8Bytes;
     uint4* raw = reinterpret_cast<uint4*>(sl + (p_dst + 1) * kFragStride8 + lane * 16);
@@ -123,8 +129,13 @@ __global__ void __launch_bounds__(1024) wgrad8_kernel(const Wgrad8Params prm) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) o[q] = pack_bf16x2(mx8_value(w[q >> 1], 2 * (q & 1), s, bias), mx8_value(w[q >> 1], 2 * (q & 1) + 1, s, bias));
     }
+#if SR_W8_ABL == 2  // timing experiment: decode arithmetic kept, LDS writes dropped (wrong results)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(o[i]));
+#else
     *reinterpret_cast<uint4*>(sl + p_dst * kFragStride8 + lane * 16) = make_uint4(o[0], o[1], o[2], o[3]);
     *raw = make_uint4(o[4], o[5], o[6], o[7]);
+#endif
   };
 
   // ---- MFMA side: identical to wgrad.hip --------------------------------------------------------------------------------
@@ -163,6 +174,14 @@ __global__ void __launch_bounds__(1024) wgrad8_kernel(const Wgrad8Params prm) {
     f32x16 acc[2][2] = {}, acc_aux = {};
     auto kstep = [&](const char* b, int ks) {
       if constexpr (kFull) {
+#if SR_W8_ABL == 4  // timing experiment: reads only, no MFMAs
+        {
+          const uint4 ra0 = operand(b, 2 * wr, ks), ra1 = operand(b, 2 * wr + 1, ks);
+          const uint4 rb0 = operand(b, 8 + 2 * wc, ks), rb1 = operand(b, 8 + 2 * wc + 1, ks);
+          asm volatile("" ::"v"(ra0.x), "v"(ra1.x), "v"(rb0.x), "v"(rb1.x), "v"(ra0.w), "v"(ra1.w), "v"(rb0.w), "v"(rb1.w));
+          return;
+        }
+#endif
         const uint4 a0 = operand(b, 2 * wr, ks), a1 = operand(b, 2 * wr + 1, ks);
         const uint4 b0 = operand(b, 8 + 2 * wc, ks), b1 = operand(b, 8 + 2 * wc + 1, ks);
         acc[0][0] = mma(a0, b0, acc[0][0]), acc[1][0] = mma(a1, b0, acc[1][0]);
