@@ -477,7 +477,6 @@ class Machine3:
                 for g in range(16):
                     prev = np.zeros(64, np.float32) if c0 else self.f(acc + g).copy()
                     self.setf(acc + g, (prev.astype(np.float64) + d[:, g]).astype(np.float32))
-                self.mfma_log.append((unit, plane, breg))
             elif op == "dsread":
                 dst, slot, plane = a
                 unit = self.ring_unit[slot][plane]
@@ -541,7 +540,6 @@ class Machine3:
                 self.last_write[a[0]] = n
         assert (self.uses == 3).all()
 
-    mfma_log: list = []
 
 
 def main():

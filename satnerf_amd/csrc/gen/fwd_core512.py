@@ -9,8 +9,7 @@ Same method as fwd_core.py (read that docstring first); the machine shape is fwd
     v_accvgpr_write behind the cvt_pk), the A-fragment ring (ds_read_b128 straight into AGPRs), aux fragments, head accumulator;
   * 4 waves per workgroup, LDS ring of 144 pieces (1 KiB = one k-step of one 32-row output tile) fed by rows of 4 (one request per
     wave), one rendezvous per output tile (33 MFMAs; two tiles per rendezvous would need a ring of 5 tiles), A fragments PF MFMAs
-    ahead, the epilogue of tile t-1 (16 v_sin,
-    8 v_cvt_pk, 8 v_accvgpr_write when the output vector lives in AGPRs) in the gaps of tile t.
+    ahead, the epilogue of tile t-1 (16 v_sin, 8 v_cvt_pk, 8 v_accvgpr_write when the output vector lives in AGPRs) in the gaps of tile t.
 save = 8 (the training forward): the PHASE8 byte of every sin stage's pre-activation (SDWA add into its byte of the store quad before
 the in-place sine), MX8 feats + scale bytes, non-temporal stores in the MFMA gaps -- fwd_core.py's scheme with the unit numbers of
 width 512 (mlp_layout.h: a_l at 16 l + t, feats 128, rgbh 144, s1 152, e1 160, s2 168, s3 176, scale unit 184, all + auxs).
