@@ -34,3 +34,22 @@ def test_hipcc_scheduled_training_forward_matches_the_gradient_goldens():
 @pytest.mark.gpu
 def test_fat_wave_weight_gradient_kernel_matches_the_gradient_goldens():
     _run({"SATNERF_WGRAD_V2": "1"}, "test_hip_backward.py", "gradients_match_reference_golden or direct_step_matches_autograd")
+
+
+@pytest.mark.gpu
+def test_bench_contract_with_two_ranks_sharing_the_gpu():
+    """bench.py's N > 1 path (per-rank bank shares, barrier + max over ranks, whole-job rays/s) launched as the driver launches it; the two
+    ranks share the one GPU through the gloo test hook (measurements use nccl = RCCL, one rank per GPU)."""
+    import json
+
+    env = dict(os.environ, SATNERF_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 2 * 1024 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-3 * d["value"]  # whole-job rays/s = all ranks' rays / max-over-ranks time
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
