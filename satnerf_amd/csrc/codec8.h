@@ -22,7 +22,12 @@ __device__ __forceinline__ uint4 phase8_encode(const V& x) {  // x[0..15]
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 __device__ __forceinline__ float ubyte_f32(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }  // v_cvt_f32_ubyte<k>
-__device__ __forceinline__ float phase8_rev(uint32_t w, int k) { return ubyte_f32(w, k) * (1.0f / 256.0f); }
+// phase byte k of w as a number of revolutions for v_sin / v_cos -- 128 + u / 256, built by ONE v_perm_b32: the byte lands in bits 8..15 of
+// 0x43000000 (= 128.0f, whose mantissa lsb is 2^-16).  sin and cos have period 1 in revolutions and the hardware reduces |x| <= 256
+// exactly, so this is sin / cos of u / 256 without the convert + scale pair (one instruction per value less in the dX and dW decoders).
+__device__ __forceinline__ float phase8_rev(uint32_t w, int k) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_perm(0x43000000u, w, 0x070c000cu | ((uint32_t)k << 8)));
+}
 
 // ---- MX8 --------------------------------------------------------------------------------------------------------------
 // E = biased exponent of max|v| * (1 + 2^-7) (so that max|v| / 2^(E-133) <= 127.008 rounds to <= 127), clamped to >= 6.
