@@ -17,7 +17,7 @@
 #include <stdlib.h>
 
 #ifndef SR_W8_ABL
-#define SR_W8_ABL 0  // 2..4: timing ablations (wrong results), tools/ab_wgrad_abl.sh
+#define SR_W8_ABL 0  // 2..6: timing ablations (wrong results), tools/ab_wgrad_abl.sh
 #endif
 #include "codec8.h"
 #include "common.h"
@@ -96,6 +96,9 @@ __global__ void __launch_bounds__(1024) wgrad8_kernel(const Wgrad8Params prm) {
   const uint32_t p_voff = (uint32_t)src_unit * 16u, s_voff = (uint32_t)(sec_is_aux ? src_unit : lane) * 16u;
   const int p_off = (p_codec == kRaw16 ? p_dst : p_dst + 1) * kFragStride8;  // a DF lands where its second fragment will be
   auto issue = [&](long tile, int slot) {
+#if SR_W8_ABL == 5  // timing experiment: no LDS-DMA (operands are whatever the LDS holds)
+    return;
+#endif
     const uint32_t base = ring + slot * kSlot8Bytes;
     if (has_prim) glds16_s(reinterpret_cast<const char*>(p_base + tile * p_stride * 64), p_voff, base + p_off);
     if (has_sec) glds16_s(reinterpret_cast<const char*>(s_base + tile * s_stride * 64), s_voff, base + sec_off);
@@ -165,7 +168,9 @@ __global__ void __launch_bounds__(1024) wgrad8_kernel(const Wgrad8Params prm) {
   const bool full = n_rt == 2 && n_ct == 2;
   auto rendezvous = [] {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if SR_W8_ABL != 6  // (6: timing experiment without the workgroup barrier)
     __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");
   };
 
