@@ -2,7 +2,7 @@
 # Run on the GPU box (via gpurun): regenerates the round's profile artefacts under gpurun_out/profiles_${TAG}/.
 # Counters are collected in their own passes with --kernel-trace only (never combined with other trace domains).
 set -u
-TAG=${1:-r02}; root=$(pwd); out=$root/gpurun_out/profiles_${TAG}; mkdir -p $out
+TAG=${1:-r03}; root=$(pwd); out=$root/gpurun_out/profiles_${TAG}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 B="python $root/bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -d $out/train_stats -o t --output-format csv -- $B > $out/train_stats.log 2>&1
@@ -22,7 +22,7 @@ fi
 TAG=$TAG python - <<'PY'
 import csv, glob, collections
 import os
-out = "gpurun_out/profiles_" + os.environ.get("TAG", "r02")
+out = "gpurun_out/profiles_" + os.environ.get("TAG", "r03")
 acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
