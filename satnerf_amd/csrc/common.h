@@ -77,6 +77,10 @@ __device__ __forceinline__ float sin_rev_precise(float x) {
 // loads (216 vs 226 us) and uses ws_load_cached.
 typedef unsigned int u32x4_native __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ws_store(uint4* p, const uint4& v) {
+#ifdef SR_ABL_NO_WS_STORE  // timing experiment (tools/ab_bwd_abl.sh): the value is computed, the store dropped
+  asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(p));
+  return;
+#endif
   __builtin_nontemporal_store(__builtin_bit_cast(u32x4_native, v), reinterpret_cast<u32x4_native*>(p));
 }
 __device__ __forceinline__ uint4 ws_load(const uint4* p) {
