@@ -9,28 +9,36 @@ __global__ void __launch_bounds__(1024) reduce_atomic(float* acc, const int* blo
   float* dst = acc + (long)block_of[blockIdx.x] * kBlockFloats;
   for (int i = threadIdx.x; i < kBlockFloats; i += 1024) unsafeAtomicAdd(dst + i, v + i);
 }
+// the same with the slices of a block all on ONE XCD (workgroup i runs on XCD i % 8: blocks 2x, 2x + 1 belong to XCD x) and atomics of
+// workgroup scope, which the XCD's own L2 performs
+__global__ void __launch_bounds__(1024) reduce_atomic_xcd(float* acc, float v) {
+  const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+  float* dst = acc + (long)(2 * xcd + (k & 1)) * kBlockFloats;
+  for (int i = threadIdx.x; i < kBlockFloats; i += 1024) __hip_atomic_fetch_add(dst + i, v + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __global__ void __launch_bounds__(1024) write_plain(float* out, float v) {
   float* dst = out + (long)blockIdx.x * kBlockFloats;
   for (int i = threadIdx.x; i < kBlockFloats; i += 1024) __builtin_nontemporal_store(v + i, dst + i);
 }
 int main() {
-  const int n_wg = 252, n_blocks = 15;
+  const int n_wg = 256, n_blocks = 16;
   float *acc, *out; int* bo; int h[n_wg];
   for (int i = 0; i < n_wg; ++i) h[i] = i * n_blocks / n_wg;
   (void)hipMalloc(&acc, (size_t)n_blocks * kBlockFloats * 4); (void)hipMalloc(&out, (size_t)n_wg * kBlockFloats * 4); (void)hipMalloc(&bo, sizeof(h));
   (void)hipMemcpy(bo, h, sizeof(h), hipMemcpyHostToDevice);
   (void)hipMemset(acc, 0, (size_t)n_blocks * kBlockFloats * 4);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int variant = 0; variant < 2; ++variant) {
+  for (int variant = 0; variant < 3; ++variant) {
     for (int rep = 0; rep < 3; ++rep) {
       (void)hipEventRecord(e0);
       for (int it = 0; it < 20; ++it) {
         if (variant == 0) hipLaunchKernelGGL(reduce_atomic, dim3(n_wg), dim3(1024), 0, 0, acc, bo, 1.0f);
+        else if (variant == 2) hipLaunchKernelGGL(reduce_atomic_xcd, dim3(n_wg), dim3(1024), 0, 0, acc, 1.0f);
         else hipLaunchKernelGGL(write_plain, dim3(n_wg), dim3(1024), 0, 0, out, 1.0f);
       }
       (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
       float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-      printf("%s: %.1f us per launch (%d workgroups x %d KB)\n", variant == 0 ? "fp32 atomics into 15 L2-resident blocks" : "plain non-temporal stores of 252 blocks", ms / 20 * 1e3, n_wg, kBlockFloats * 4 / 1024);
+      printf("%s: %.1f us per launch (%d workgroups x %d KB)\n", variant == 0 ? "fp32 agent-scope atomics into 16 blocks" : variant == 2 ? "workgroup-scope atomics, a block's slices on one XCD" : "plain non-temporal stores of 256 blocks", ms / 20 * 1e3, n_wg, kBlockFloats * 4 / 1024);
     }
   }
   return 0;
