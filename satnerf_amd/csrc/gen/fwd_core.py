@@ -584,9 +584,23 @@ class Machine:
         self.voff_rows = 0   # rows VOFF has been advanced by: the source of the next request is stream piece 8 * voff_rows + wave
         self.soff = 0        # SAVE8: byte offset of SOFF relative to the tile's workspace base
         self.stores = {}     # unit -> [4, 64] uint32 (or [2, 64] for the scale unit)
+        self._xdl, self._n_mfma, self._nops = {}, 0, 0
 
     def f(self, r):
         return self.v[r].view(np.float32)
+
+    # XDL write -> VALU read: the generators start a tile's epilogue two MFMAs after its last one (each later MFMA holds the issue port for
+    # 8 wait states; 11 are needed after an 8-pass MFMA) or behind an s_nop chain; checked for every VALU source register
+    def _mfma_wrote(self, acc):
+        for g in range(16):
+            self._xdl[acc + g] = self._n_mfma
+        self._n_mfma += 1
+        self._nops = 0
+
+    def _valu_reads(self, *regs):
+        for r in regs:
+            k = self._xdl.get(r)
+            assert k is None or self._n_mfma - 1 - k >= 2 or self._nops >= 12, ("VALU reads an MFMA result too early", r)
 
     def run(self):
         c = self.c
@@ -610,6 +624,9 @@ class Machine:
                 for g in range(16):
                     prev = np.zeros(64, np.float32) if c0 else self.f(acc + g).copy()
                     self.v[acc + g] = (prev.astype(np.float64) + d[:, g]).astype(np.float32).view(np.uint32)
+                self._mfma_wrote(acc)
+            elif op == "nop":
+                self._nops += a[0] + 1
             elif op == "dsread":
                 dst, slot = a
                 piece = self.ring_piece[slot]
@@ -649,15 +666,19 @@ class Machine:
                 self.voff_rows += 1
             elif op == "sin":
                 r = a[0]
+                self._valu_reads(r)
                 self.v[r] = np.sin(2 * np.pi * self.f(r).astype(np.float64)).astype(np.float32).view(np.uint32)
             elif op == "pk":
                 d, s0, s1 = a
+                self._valu_reads(s0, s1)
                 self.v[d] = (bf16_bits(self.f(s0)) | (bf16_bits(self.f(s1)) << 16)).astype(np.uint32)
             elif op == "mov":
                 d, s = a
+                self._valu_reads(s)
                 self.v[d] = self.v[s]
             elif op == "phase":  # v_add_f32_sdwa dst_sel:BYTE_k UNUSED_PRESERVE: the low byte of the fp32 sum
                 d, byte, src = a
+                self._valu_reads(src)
                 ssum = (self.f(src) + self.f(KMAGIC)).astype(np.float32)
                 b = ssum.view(np.uint32) & np.uint32(0xFF)
                 self.v[d] = (self.v[d] & np.uint32(~(0xFF << (8 * byte)) & 0xFFFFFFFF)) | (b << np.uint32(8 * byte))
@@ -669,6 +690,7 @@ class Machine:
                 self.stores[unit] = self.v[reg:reg + (4 if op == "store" else 2)].copy()
             elif op == "mx_max":
                 m, x, y, z = a
+                self._valu_reads(x, y)
                 r = np.maximum(np.abs(self.f(x)), np.abs(self.f(y)))
                 if z is not None:
                     r = np.maximum(r, self.f(z))
@@ -689,6 +711,7 @@ class Machine:
                 self.v[d] = self.v[e].copy() if first else ((self.v[e] << np.uint32(sh)) | self.v[d]).astype(np.uint32)
             elif op == "mx_q1":
                 t, src, inv = a
+                self._valu_reads(src)
                 self.v[t] = (self.f(src).astype(np.float64) * self.f(inv).astype(np.float64) + self.f(K128).astype(np.float64)).astype(np.float32).view(np.uint32)
             elif op == "mx_e3a":
                 pass  # (the clamp is applied by mx_e3)

@@ -449,12 +449,26 @@ class Machine3:
         self.last_write = {}
         self.soff = 0       # save = 16: byte offset of SOFF relative to the tile's workspace base
         self.stores = {}    # fragment -> [4, 64] uint32
+        self._xdl, self._n_mfma, self._nops = {}, 0, 0
 
     def f(self, r):
         return self.v[r].view(np.float32)
 
     def setf(self, r, x):
         self.v[r] = np.asarray(x, np.float32).view(np.uint32)
+
+    # XDL write -> VALU read: the generators start a tile's epilogue two MFMAs after its last one (each later MFMA holds the issue port for
+    # 8 wait states; 11 are needed after an 8-pass MFMA) or behind an s_nop chain; checked for every VALU source register
+    def _mfma_wrote(self, acc):
+        for g in range(16):
+            self._xdl[acc + g] = self._n_mfma
+        self._n_mfma += 1
+        self._nops = 0
+
+    def _valu_reads(self, *regs):
+        for r in regs:
+            k = self._xdl.get(r)
+            assert k is None or self._n_mfma - 1 - k >= 2 or self._nops >= 12, ("VALU reads an MFMA result too early", r)
 
     def run(self):
         c = self.c
@@ -477,6 +491,9 @@ class Machine3:
                 for g in range(16):
                     prev = np.zeros(64, np.float32) if c0 else self.f(acc + g).copy()
                     self.setf(acc + g, (prev.astype(np.float64) + d[:, g]).astype(np.float32))
+                self._mfma_wrote(acc)
+            elif op == "nop":
+                self._nops += a[0] + 1
             elif op == "dsread":
                 dst, slot, plane = a
                 unit = self.ring_unit[slot][plane]
@@ -510,12 +527,15 @@ class Machine3:
                     self.ring_unit[slot][plane] = u
                     self.ring[slot, plane] = self.stream[plane][u]
             elif op == "fract":
+                self._valu_reads(a[0])
                 x = self.f(a[0]).astype(np.float64)
                 self.setf(a[0], x - np.floor(x))
             elif op == "sin":
+                self._valu_reads(a[0])
                 self.setf(a[0], np.sin(2 * np.pi * self.f(a[0]).astype(np.float64)))
             elif op == "pk":
                 d, s0, s1 = a
+                self._valu_reads(s0, s1)
                 self.v[d] = (bf16_bits(self.f(s0)) | (bf16_bits(self.f(s1)) << 16)).astype(np.uint32)
                 self.last_write[d] = n
             elif op == "shl":
@@ -524,9 +544,11 @@ class Machine3:
                 self.v[a[0]] = self.v[a[1]] & np.uint32(0xFFFF0000)
             elif op == "sub":
                 d, x, y = a
+                self._valu_reads(x, y)
                 self.setf(d, self.f(x) - self.f(y))
             elif op == "pknorm":  # v_cvt_pknorm_u16_f32: round(clamp(x, 0, 1) * 65535), RNE
                 d, s0, s1 = a
+                self._valu_reads(s0, s1)
                 u = [np.rint(np.clip(self.f(r).astype(np.float64), 0, 1) * 65535).astype(np.uint32) for r in (s0, s1)]
                 self.v[d] = u[0] | (u[1] << np.uint32(16))
             elif op == "soff":
@@ -536,6 +558,7 @@ class Machine3:
                 assert self.soff == frag * 1024 and frag not in self.stores, (self.soff, frag)
                 self.stores[frag] = self.v[reg:reg + 4].copy()
             elif op in ("accw", "accr", "mov"):
+                self._valu_reads(a[1])
                 self.v[a[0]] = self.v[a[1]]
                 self.last_write[a[0]] = n
         assert (self.uses == 3).all()

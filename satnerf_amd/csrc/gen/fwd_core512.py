@@ -420,12 +420,26 @@ class Machine512:
         self.voff_rows = 0
         self.soff = 0
         self.stores = {}
+        self._xdl, self._n_mfma, self._nops = {}, 0, 0
 
     def f(self, r):
         return self.v[r].view(np.float32)
 
     def setf(self, r, x):
         self.v[r] = np.asarray(x, np.float32).view(np.uint32)
+
+    # XDL write -> VALU read: the generators start a tile's epilogue two MFMAs after its last one (each later MFMA holds the issue port for
+    # 8 wait states; 11 are needed after an 8-pass MFMA) or behind an s_nop chain; checked for every VALU source register
+    def _mfma_wrote(self, acc):
+        for g in range(16):
+            self._xdl[acc + g] = self._n_mfma
+        self._n_mfma += 1
+        self._nops = 0
+
+    def _valu_reads(self, *regs):
+        for r in regs:
+            k = self._xdl.get(r)
+            assert k is None or self._n_mfma - 1 - k >= 2 or self._nops >= 12, ("VALU reads an MFMA result too early", r)
 
     def run(self):
         c = self.c
@@ -449,6 +463,9 @@ class Machine512:
                 for g in range(16):
                     prev = np.zeros(64, np.float32) if c0 else self.f(acc + g).copy()
                     self.setf(acc + g, (prev.astype(np.float64) + d[:, g]).astype(np.float32))
+                self._mfma_wrote(acc)
+            elif op == "nop":
+                self._nops += a[0] + 1
             elif op == "dsread":
                 dst, slot = a
                 piece = self.ring_piece[slot]
@@ -485,16 +502,20 @@ class Machine512:
             elif op == "voff":
                 self.voff_rows += 1
             elif op == "sin":
+                self._valu_reads(a[0])
                 self.setf(a[0], np.sin(2 * np.pi * self.f(a[0]).astype(np.float64)))
             elif op == "pk":
                 d, s0, s1 = a
+                self._valu_reads(s0, s1)
                 self.v[d] = (bf16_bits(self.f(s0)) | (bf16_bits(self.f(s1)) << 16)).astype(np.uint32)
                 self.last_write[d] = n
             elif op in ("accw", "accr", "mov"):
+                self._valu_reads(a[1])
                 self.v[a[0]] = self.v[a[1]]
                 self.last_write[a[0]] = n
             elif op == "phase":
                 d, byte, src = a
+                self._valu_reads(src)
                 b = (self.f(src) + self.f(KMAGIC)).astype(np.float32).view(np.uint32) & np.uint32(0xFF)
                 self.v[d] = (self.v[d] & np.uint32(~(0xFF << (8 * byte)) & 0xFFFFFFFF)) | (b << np.uint32(8 * byte))
             elif op == "soff":
@@ -505,6 +526,7 @@ class Machine512:
                 self.stores[unit] = self.v[reg:reg + 4].copy()
             elif op == "mx_max":
                 m_, x, y, z = a
+                self._valu_reads(x, y)
                 r = np.maximum(np.abs(self.f(x)), np.abs(self.f(y)))
                 self.setf(m_, r if z is None else np.maximum(r, self.f(z)))
             elif op == "mx_e1":
@@ -522,6 +544,7 @@ class Machine512:
                 self.v[d] = self.v[e].copy() if first else ((self.v[e] << np.uint32(sh)) | self.v[d]).astype(np.uint32)
             elif op == "mx_q1":
                 t_, src, inv = a
+                self._valu_reads(src)
                 self.setf(t_, self.f(src).astype(np.float64) * self.f(inv).astype(np.float64) + self.f(K128).astype(np.float64))
             elif op == "mx_q2":
                 d, t_, byte = a
