@@ -585,6 +585,7 @@ class Machine:
         self.soff = 0        # SAVE8: byte offset of SOFF relative to the tile's workspace base
         self.stores = {}     # unit -> [4, 64] uint32 (or [2, 64] for the scale unit)
         self._xdl, self._n_mfma, self._nops = {}, 0, 0
+        self._trans, self._pc, self._m0_at = {}, 0, -9  # v_sin results, instruction index, last M0 write
 
     def f(self, r):
         return self.v[r].view(np.float32)
@@ -601,11 +602,17 @@ class Machine:
         for r in regs:
             k = self._xdl.get(r)
             assert k is None or self._n_mfma - 1 - k >= 2 or self._nops >= 12, ("VALU reads an MFMA result too early", r)
+            assert self._pc - self._trans.get(r, -9) >= 2, ("trans result used by the next instruction", r)  # trans -> VALU: 1 wait state
 
     def run(self):
         c = self.c
-        for ins in c.ins:
+        for pc, ins in enumerate(c.ins):
             op, a = ins.op, ins.a
+            self._pc = pc
+            if op == "m0":
+                self._m0_at = pc
+            elif op == "dma":
+                assert pc - self._m0_at >= 2, "M0 write -> LDS-DMA needs one wait state"
             if op == "mfma":
                 acc, areg, breg, c0 = a
                 assert not any(d == areg for d, _, _ in self.pending_reads), "MFMA reads an A fragment still in flight"
@@ -667,6 +674,7 @@ class Machine:
             elif op == "sin":
                 r = a[0]
                 self._valu_reads(r)
+                self._trans[r] = self._pc
                 self.v[r] = np.sin(2 * np.pi * self.f(r).astype(np.float64)).astype(np.float32).view(np.uint32)
             elif op == "pk":
                 d, s0, s1 = a

@@ -450,6 +450,7 @@ class Machine3:
         self.soff = 0       # save = 16: byte offset of SOFF relative to the tile's workspace base
         self.stores = {}    # fragment -> [4, 64] uint32
         self._xdl, self._n_mfma, self._nops = {}, 0, 0
+        self._trans, self._pc, self._m0_at = {}, 0, -9  # v_sin results, instruction index, last M0 write
 
     def f(self, r):
         return self.v[r].view(np.float32)
@@ -469,11 +470,17 @@ class Machine3:
         for r in regs:
             k = self._xdl.get(r)
             assert k is None or self._n_mfma - 1 - k >= 2 or self._nops >= 12, ("VALU reads an MFMA result too early", r)
+            assert self._pc - self._trans.get(r, -9) >= 2, ("trans result used by the next instruction", r)  # trans -> VALU: 1 wait state
 
     def run(self):
         c = self.c
         for n, ins in enumerate(c.ins):
             op, a = ins.op, ins.a
+            self._pc = n
+            if op == "m0":
+                self._m0_at = n
+            elif op == "dma":
+                assert n - self._m0_at >= 2, "M0 write -> LDS-DMA needs one wait state"
             if op == "mfma":
                 acc, areg, breg, c0 = a
                 assert not any(d == areg for d, *_ in self.pending), "MFMA reads an A fragment still in flight"
@@ -532,6 +539,7 @@ class Machine3:
                 self.setf(a[0], x - np.floor(x))
             elif op == "sin":
                 self._valu_reads(a[0])
+                self._trans[a[0]] = self._pc
                 self.setf(a[0], np.sin(2 * np.pi * self.f(a[0]).astype(np.float64)))
             elif op == "pk":
                 d, s0, s1 = a

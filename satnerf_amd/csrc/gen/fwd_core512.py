@@ -421,6 +421,7 @@ class Machine512:
         self.soff = 0
         self.stores = {}
         self._xdl, self._n_mfma, self._nops = {}, 0, 0
+        self._trans, self._pc, self._m0_at = {}, 0, -9  # v_sin results, instruction index, last M0 write
 
     def f(self, r):
         return self.v[r].view(np.float32)
@@ -440,11 +441,17 @@ class Machine512:
         for r in regs:
             k = self._xdl.get(r)
             assert k is None or self._n_mfma - 1 - k >= 2 or self._nops >= 12, ("VALU reads an MFMA result too early", r)
+            assert self._pc - self._trans.get(r, -9) >= 2, ("trans result used by the next instruction", r)  # trans -> VALU: 1 wait state
 
     def run(self):
         c = self.c
         for n, ins in enumerate(c.ins):
             op, a = ins.op, ins.a
+            self._pc = n
+            if op == "m0":
+                self._m0_at = n
+            elif op == "dma":
+                assert n - self._m0_at >= 2, "M0 write -> LDS-DMA needs one wait state"
             if op == "mfma":
                 acc, areg, breg, c0 = a
                 assert not any(d == areg for d, _, _ in self.pending), "MFMA reads an A fragment still in flight"
@@ -503,6 +510,7 @@ class Machine512:
                 self.voff_rows += 1
             elif op == "sin":
                 self._valu_reads(a[0])
+                self._trans[a[0]] = self._pc
                 self.setf(a[0], np.sin(2 * np.pi * self.f(a[0]).astype(np.float64)))
             elif op == "pk":
                 d, s0, s1 = a

@@ -2,7 +2,8 @@
 are current, and the instruction list -- executed on a lane-accurate numpy model of the VGPR file, the LDS ring, the LDS-DMA rows and
 v_mfma_f32_32x32x16_bf16 -- reproduces the forward pass of tests/mfma_emulator.py (itself held to the oracle) on the packed weight
 stream.  This validates register allocation, piece addressing, operand order, the lgkmcnt / vmcnt counts and the ring protocol
-(no piece read before its rendezvous, no ring slot overwritten before every wave consumed it) without a GPU."""
+(no piece read before its rendezvous, no ring slot overwritten before every wave consumed it) and the hazards the assembler does not
+pad inside inline asm (XDL write -> VALU read, VALU write -> MFMA operand, trans -> VALU use, M0 write -> LDS-DMA) without a GPU."""
 import importlib.util
 import os
 
