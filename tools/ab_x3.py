@@ -1,5 +1,6 @@
+"""Parity-mode (bf16x3) forward MLP kernel time for one library build (SATRENDER_LIB); with a -DSR_CORE_TIMING build (tools/ab_core3.sh) and SR_CORE_TIMING=1 also the in-kernel cycle / clock stamps."""
 import os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from satnerf_amd import ops, data
 from satnerf_amd.models import load_model
 dev = "cuda:0"

@@ -1,5 +1,6 @@
+"""Training-step time of Trainer variants (graph / eager, autograd / kernel-direct, saved-state formats) at 1024 rays x 64 samples."""
 import sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from satnerf_amd import data as O  # synthetic rays / default args (the oracle is test infrastructure)
 from satnerf_amd.models import load_model
 from satnerf_amd.train import Trainer

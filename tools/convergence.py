@@ -220,5 +220,5 @@ if __name__ == "__main__":
     ap.add_argument("--seeds", default="0,1,2")
     a = ap.parse_args()
     res = run_seeds(tuple(int(x) for x in a.seeds.split(",")), steps=a.steps, batch=a.batch, n_eval=a.eval, verbose=True,
-                    modes=(("bf16", None), ("bf16", 16), ("f16", None)))
+                    modes=(("bf16", None), ("bf16", 16), ("f16", None), ("bf16x3", None)))
     print(json.dumps(res))

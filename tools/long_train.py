@@ -1,5 +1,6 @@
+"""A few thousand kernel-direct training steps (colour + depth-supervision batches) on a learnable synthetic scene: loss curve and step time."""
 import sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from satnerf_amd import data as O  # synthetic rays / default args (the oracle is test infrastructure)
 from satnerf_amd.models import load_model
 from satnerf_amd.train import Trainer
