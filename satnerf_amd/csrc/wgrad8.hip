@@ -17,7 +17,7 @@
 #include <stdlib.h>
 
 #ifndef SR_W8_ABL
-#define SR_W8_ABL 0  // 2..6: timing ablations (wrong results), tools/ab_wgrad_abl.sh
+#define SR_W8_ABL 0  // 2..8: timing ablations (wrong results), tools/ab_wgrad_abl.sh
 #endif
 #include "codec8.h"
 #include "common.h"
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(1024) wgrad8_kernel(const Wgrad8Params prm) {
     }
   };
   auto decode = [&](int slot) {
-#if SR_W8_ABL == 3  // timing experiment: no decode at all
+#if SR_W8_ABL == 3 || SR_W8_ABL == 8  // timing experiment: no decode at all (8: LDS-DMA and rendezvous only)
     return;
 #endif
     if (!has_prim || p_codec == kRaw16) return;
@@ -152,6 +152,9 @@ __global__ void __launch_bounds__(1024) wgrad8_kernel(const Wgrad8Params prm) {
       rd_off[ks][rd] = rh * kFragStride8 + ((q >> 1) ? 512 + ((point + 8) & 31) * 16 : point * 16) + (q & 1) * 8;
     }
   auto operand = [&](const char* buf, int frag_pair, int ks) {
+#if SR_W8_ABL == 7  // timing experiment: no transposed operand reads (MFMAs on register garbage)
+    return make_uint4((uint32_t)frag_pair, (uint32_t)ks, 0x3f803f80u, 0x3f803f80u);
+#endif
     const char* p = buf + frag_pair * 2 * kFragStride8;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + rd_off[ks][0]));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + rd_off[ks][1]));
@@ -178,6 +181,9 @@ __global__ void __launch_bounds__(1024) wgrad8_kernel(const Wgrad8Params prm) {
     constexpr bool kFull = decltype(full_tag)::value;
     f32x16 acc[2][2] = {}, acc_aux = {};
     auto kstep = [&](const char* b, int ks) {
+#if SR_W8_ABL == 8
+      return;
+#endif
       if constexpr (kFull) {
 #if SR_W8_ABL == 4  // timing experiment: reads only, no MFMAs
         {
