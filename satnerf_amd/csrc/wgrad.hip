@@ -256,6 +256,13 @@ extern "C" int sr_wgrad_plan(int32_t* blocks, int n_blocks, int64_t n_points, in
   // to the block whose workgroups would otherwise finish last: minimises max_b cost_b * ceil(tiles / slices_b)
   // cost of a tile of a block = ca + cb * row fragments + cc * column fragments (relative; MI355X A/B in profiles/r02_ab_variants.txt)
   double ca = 0.4, cb = 0.02, cc = 0.0175;
+  // the 4-wave kernel (wgrad9.hip, the default) runs ONE instruction stream for every block -- narrow blocks contract stale operands --
+  // so a tile costs the same whatever the block: equal slices (the remainder goes to the first blocks)
+  static const bool old_kernel = [] {
+    const char *a = getenv("SATNERF_WGRAD_V1"), *b = getenv("SATNERF_WGRAD_V2");
+    return (a && a[0] == '1') || (b && b[0] == '1');
+  }();
+  if (!old_kernel) ca = 1.0, cb = 0.0, cc = 0.0;
 #ifdef SR_PLAN_ENV
   if (const char* e = getenv("SR_WGRAD_COST")) sscanf(e, "%lf,%lf,%lf", &ca, &cb, &cc);
 #endif

@@ -45,7 +45,8 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 //   bits 0-1 source (1 dpre, 2 acts) | 2-3 codec (0 RAW16, 1 PHASE8, 2 MX8) | 4-11 unit within the tile | 12-17 operand fragment
 //   (0..15 rows, 16..31 columns; a DF expands into fragment and fragment + 1) | 18-19 scale area | 20-23 byte within the lane's 16 B
 // ints 16..18: the scale unit fetched into scale area 0..2 (bits 0-1 source, 4-11 unit; 0 = none), by waves 2..4.
-constexpr int kWg8LoadInts = 20;
+// ints 20..99: the duty table of the 4-wave kernel (wgrad9.hip, packing.wgrad9_duties); ints 100..107: its exponent scan list.
+constexpr int kWg8LoadInts = 108;
 enum { kSrcDpre = 1, kSrcActs = 2, kRaw16 = 0, kPhase8 = 1, kMx8 = 2 };
 
 constexpr int kFragStride8 = 1088;  // as wgrad.hip: 1-KiB lane-linear fragment image + 64 B so that transposed reads spread over the banks
@@ -266,6 +267,9 @@ __global__ void __launch_bounds__(1024) wgrad8_kernel(const Wgrad8Params prm) {
 namespace sr {
 int launch_wgrad8f(const uint4* dpre, const uint4* acts, const int* blocks, const int* loads, float* partial, long n_tiles, int n_blocks,
                    int ak, int auxs, int dk, int n_slices, hipStream_t st);  // wgrad8f.hip
+int launch_wgrad9(const uint4* dpre, const uint4* acts, const int* blocks, const int* loads, float* partial, long n_tiles, int n_blocks, int ak,
+                  int dk, int load_ints, int n_slices, hipStream_t st);  // wgrad9.hip
+bool wgrad9_fits(long n_tiles, int ak, int dk);
 }
 using namespace sr;
 
@@ -281,9 +285,13 @@ extern "C" int sr_satnerf_wgrad8(int feat, int tau, int64_t n_points, const uint
   p.auxs = aux_steps(tau);
   p.ak = (int)(sr_act_elems_per_tile(feat, SR_FMT8) / 512) - (2 - p.auxs);  // the size query assumes the 2-step aux layout
   p.dk = (int)(sr_dpre_elems_per_tile(feat, SR_FMT8) / 512);
-  // width 256: SATNERF_WGRAD_V2=1 selects the fat-wave kernel with the hand-placed per-tile stream (wgrad8f.hip; experimental: correct,
-  // not yet faster -- profiles/r03_ab_variants.txt)
+  // default: the 4-wave kernel with 128 x 128 register tiles and the generated slice loop (wgrad9.hip), either width.  SATNERF_WGRAD_V1=1
+  // keeps the r02 kernel below (A/B; it also takes the workspaces beyond the 32-bit offsets of the new one); SATNERF_WGRAD_V2=1 the r03
+  // fat-wave experiment (wgrad8f.hip, width 256).
+  static const bool v1 = [] { const char* e = getenv("SATNERF_WGRAD_V1"); return e && e[0] == '1'; }();
   static const bool v2 = [] { const char* e = getenv("SATNERF_WGRAD_V2"); return e && e[0] == '1'; }();
+  if (!v1 && !v2 && wgrad9_fits(p.n_tiles, p.ak, p.dk))
+    return launch_wgrad9(p.dpre, p.acts, blocks, loads, partial, p.n_tiles, n_blocks, p.ak, p.dk, kWg8LoadInts, n_slices, (hipStream_t)stream);
   if (feat == 256 && v2)
     return launch_wgrad8f(p.dpre, p.acts, blocks, loads, partial, p.n_tiles, n_blocks, p.ak, p.auxs, p.dk, n_slices, (hipStream_t)stream);
   const size_t lds = (size_t)kSlots8 * kSlot8Bytes;

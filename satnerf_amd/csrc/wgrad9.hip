@@ -1,0 +1,300 @@
+// Weight gradients of the fused Sat-NeRF MLP from the 8-bit training workspaces, third generation (gfx950):
+//   dW[row][col] = sum over sample points of dpre[row] * act[col]
+// = autograd's grad_weight = grad_output^T @ input / grad_bias of every nn.Linear in SatNeRF (models/satnerf.py:104-153).  Same job
+// table, split-K plan and fp32 partial blocks as wgrad8.hip (reduced by sr_grad_tail / sr_unpack_grads); what changed is the machine:
+//
+//   * 4 waves per workgroup, ONE PER SIMD, each owning a 128 x 128 quadrant of the 256 x 256 job block: 4 x 4 MFMA tiles = 256 fp32
+//     accumulators in AGPRs (+ 2 aux tiles in VGPRs): one transposed operand read per MFMA.
+//   * The 8-bit operands go HBM -> VGPRs, are decoded in registers with packed fp16 arithmetic (MX8: v_perm + v_pk_fma_f16 per pair;
+//     PHASE8: v_perm + two v_sin_f16 per pair) and reach the LDS once, as fp16 fragments; the MFMAs take fp16 operands.  With one wave
+//     per SIMD a wave's time is the sum of its issue slots (tools/probe_lds.hip), so the instruction count per MFMA is what matters.
+//   * fp16's range is fitted per workgroup: before the loop the workgroup scans the MX8 exponent bytes (and the bf16 row fragment) of
+//     ITS slice of points for the largest one, Emax; rows are decoded times G = 2^(138 - Emax) (|value| < 2^12; lanes 2^-19 below the
+//     slice's largest flush to zero), MX8 columns (feats) likewise with their own Emax, and the fp32 accumulators are unscaled when
+//     the partial block is written.
+//   * The whole slice loop is one generated, hand-placed asm statement (csrc/gen/wgrad9_loop.py -> wgrad9_loop_{p,m}.inc): 36 MFMAs per
+//     tile, the decode of tile i + 2, the global loads of tile i + 5 and the operand reads of the next k-step in their gaps, one
+//     s_barrier per tile, LDS ring of four fp16 slots.
+//
+// What each wave fetches is the "duty" table built on the host (packing.wgrad9_duties): ints 20.. of a block's row of the load table.
+#include <stdlib.h>
+
+#include "codec8.h"
+#include "common.h"
+#include "mlp_device.h"
+#include "mlp_layout.h"
+
+namespace sr {
+
+typedef float f32x32w __attribute__((ext_vector_type(32)));
+
+namespace {
+constexpr int kFrag9 = 1088, kPair9 = 2 * kFrag9, kSlotFrags9 = 36, kSlot9 = kSlotFrags9 * kFrag9, kSlots9 = 4;  // = gen/wgrad9_loop.py
+constexpr int kOldInts = 20, kDutyInts = 4, kDuties = 5, kDumpFrag = 34, kScanEntries = 4;
+
+struct Wgrad9Params {
+  const char* dpre;
+  const char* acts;
+  const int* blocks;  // planned job table (mlp_layout.h kWgTableInts ints per block)
+  const int* loads;   // load_ints ints per block; ints 20.. = the duty table
+  float* partial;
+  long n_tiles;
+  int n_blocks;
+  int ak, dk;  // 1-KiB units per tile of the activation / dpre workspace
+  int load_ints;
+  long long* dbg;  // SR_W9_TIMING builds: per workgroup (shader cycles, 100-MHz ticks, tiles) of wave 0's slice loop
+};
+}  // namespace
+
+__global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int* d = prm.blocks;
+  int blk = 0;
+  for (; blk + 1 < prm.n_blocks && (int)blockIdx.x >= d[kWgFirstSlice] + d[kWgSlices]; ++blk) d += kWgTableInts;
+  const int nr = d[1] + d[3], nc = d[5] + d[7];
+  const bool col_mx = d[8] == 0;  // packing.KIND_BF16: the identity stage (feats) -> MX8 columns
+  const long tiles_per_split = (prm.n_tiles + d[kWgSlices] - 1) / d[kWgSlices];
+  const long t_begin = (long)((int)blockIdx.x - d[kWgFirstSlice]) * tiles_per_split;
+  long t_end = t_begin + tiles_per_split;
+  if (t_end > prm.n_tiles) t_end = prm.n_tiles;
+  uint32_t nt = t_end > t_begin ? (uint32_t)(t_end - t_begin) : 0u;
+  const uint32_t tleft = t_begin < prm.n_tiles ? (uint32_t)(prm.n_tiles - 1 - t_begin) : 0u;
+  const long t0 = t_begin < prm.n_tiles ? t_begin : 0;
+
+  // ---- this wave's duties -> wave-uniform bases -------------------------------------------------------------------------------
+  const int* duty = prm.loads + (long)blk * prm.load_ints + kOldInts + wave * kDuties * kDutyInts;
+  uint64_t base[kDuties], sbase[4];
+  uint32_t wb[kDuties];
+  bool on[kDuties];  // the duty feeds an operand fragment (not the dump area)
+  const uint32_t ring = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+  int raw_src = 0;
+#pragma unroll
+  for (int k = 0; k < kDuties; ++k) {
+    const int src = __builtin_amdgcn_readfirstlane(duty[kDutyInts * k]), unit = __builtin_amdgcn_readfirstlane(duty[kDutyInts * k + 1]);
+    const int dst = __builtin_amdgcn_readfirstlane(duty[kDutyInts * k + 2]), sc = __builtin_amdgcn_readfirstlane(duty[kDutyInts * k + 3]);
+    const char* ws = src == 1 ? prm.dpre : prm.acts;
+    base[k] = (uint64_t)(uintptr_t)(ws + (long)unit * 1024);
+    if (k < 4) sbase[k] = (uint64_t)(uintptr_t)(ws + (long)(sc >> 4) * 1024 + (sc & 15));
+    wb[k] = ring + (uint32_t)dst * kFrag9;
+    on[k] = dst != kDumpFrag;
+    if (k == 4) raw_src = src;
+  }
+  const uint32_t strd = (uint32_t)prm.dk * 1024u, stra = (uint32_t)prm.ak * 1024u, strx = raw_src == 1 ? strd : stra;
+  // rotated image (as wgrad8): LDS position `lane` of a fragment holds source lane src_unit's 16 bytes, so that the transposed reads
+  // spread over the banks; every global load fetches that lane's bytes, every LDS write goes to lane * 16
+  const uint32_t src_unit = lane < 32 ? lane : 32 + ((lane - 8) & 31);
+  const uint32_t vd = (uint32_t)t0 * strd + src_unit * 16u, va = (uint32_t)t0 * stra + src_unit * 16u, vx = (uint32_t)t0 * strx + src_unit * 16u;
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  // transposed operand reads (as wgrad8): per-lane offset of k-step 0 / 1 inside a fragment pair
+  const int hh = lane >> 5, rh = (lane >> 4) & 1, m = (lane >> 2) & 3, q = lane & 3;
+  uint32_t rdo[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int point = 16 * ks + 8 * hh + m;
+    rdo[ks] = ring + (uint32_t)(rh * kFrag9 + ((q >> 1) ? 512 + ((point + 8) & 31) * 16 : point * 16) + (q & 1) * 8);
+  }
+  // quadrant (wr, wc): row pairs 4 wr + ((a + 2 wc) & 3) for operand slot a = 0..3 (slots 0, 1 also take the aux columns), column pairs
+  // 8 + 4 wc + c
+  const int wr = wave >> 1, wc = wave & 1;
+  const uint32_t aofl = (uint32_t)(4 * wr + 2 * wc) * kPair9, aofh = (uint32_t)(4 * wr + ((2 * wc + 2) & 3)) * kPair9;
+  const uint32_t bof = (uint32_t)(8 + 4 * wc) * kPair9;
+
+  // ---- fp16 range: the largest MX8 exponent / bf16 exponent of the rows (and of MX8 columns) over this workgroup's slice ----------
+  // a value is < 2^(E - 126) for an MX8 lane with exponent byte E and for a bf16 with biased exponent E alike
+  uint32_t er = 0, ec = 0;
+  {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    // the block's scan list (ints 100.. of its load-table row): where its MX8 exponent bytes live.  Wave w takes the tiles = w (mod 4) of
+    // the slice; all of an entry's loads (one 16-byte lane slot per tile) are in flight at once.
+    const int* scan = prm.loads + (long)blk * prm.load_ints + kOldInts + 4 * kDuties * kDutyInts;
+    const uint32_t n_mine = nt > (uint32_t)wave ? (nt - (uint32_t)wave + 3u) / 4u : 0u;  // tiles wave, wave + 4, ...
+    auto bytes_max = [](u16x2 m, uint32_t x) {
+      m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2, x & 0x00ff00ffu));
+      return __builtin_elementwise_max(m, __builtin_bit_cast(u16x2, (x >> 8) & 0x00ff00ffu));
+    };
+    for (int i = 0; i < kScanEntries; ++i) {
+      const int e0 = __builtin_amdgcn_readfirstlane(scan[2 * i]), e1 = __builtin_amdgcn_readfirstlane(scan[2 * i + 1]);
+      if (e0 == 0) break;
+      const char* ws = (e0 & 255) == 1 ? prm.dpre : prm.acts;
+      const uint32_t stride = (e0 & 255) == 1 ? strd : stra;
+      const char* p0 = ws + (long)(e0 >> 8) * 1024 + lane16;
+      uint32_t mk[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t nib = ((uint32_t)e1 >> (4 * k)) & 15u;
+        mk[k] = (nib & 1u ? 0xffu : 0u) | (nib & 2u ? 0xff00u : 0u) | (nib & 4u ? 0xff0000u : 0u) | (nib & 8u ? 0xff000000u : 0u);
+      }
+      u16x2 m = {0, 0};
+      for (uint32_t jb = 0; jb < n_mine; jb += 32) {
+        uint4 w[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {  // (clamped, not predicated: the loads of a pass issue back to back)
+          const uint32_t jj = jb + j < n_mine ? jb + j : n_mine - 1;
+          w[j] = *reinterpret_cast<const uint4*>(p0 + (uint64_t)(((uint32_t)t0 + (uint32_t)wave + 4u * jj) * stride));
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+          if (mk[0]) m = bytes_max(m, w[j].x & mk[0]);
+          if (mk[1]) m = bytes_max(m, w[j].y & mk[1]);
+          if (mk[2]) m = bytes_max(m, w[j].z & mk[2]);
+          if (mk[3]) m = bytes_max(m, w[j].w & mk[3]);
+        }
+      }
+      const uint32_t e = m[0] > m[1] ? m[0] : m[1];
+      if ((e1 >> 16) & 1) ec = ec > e ? ec : e;
+      else er = er > e ? er : e;
+    }
+    // a bf16 row fragment (d_sigma_pre / d_head) is wave 0's raw duty: every wave scans its share of it.  |value| is ordered by the low
+    // 15 bits of each half, exponent = bits 14:7
+    const int* raw0 = prm.loads + (long)blk * prm.load_ints + kOldInts + 4 * kDutyInts;
+    const int r_src = __builtin_amdgcn_readfirstlane(raw0[0]), r_unit = __builtin_amdgcn_readfirstlane(raw0[1]);
+    if (r_src == 1 && __builtin_amdgcn_readfirstlane(raw0[2]) != kDumpFrag && n_mine > 0) {
+      u16x2 m = {0, 0};
+      const char* rp = prm.dpre + (long)r_unit * 1024 + lane16;
+      for (uint32_t jb = 0; jb < n_mine; jb += 32) {
+        uint4 w[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+          const uint32_t jj = jb + j < n_mine ? jb + j : n_mine - 1;
+          w[j] = *reinterpret_cast<const uint4*>(rp + (uint64_t)(((uint32_t)t0 + (uint32_t)wave + 4u * jj) * strd));
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+          const uint32_t ww[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2, ww[k] & 0x7fff7fffu));
+        }
+      }
+      const uint32_t eb = (uint32_t)(m[0] > m[1] ? m[0] : m[1]) >> 7;
+      er = er > eb ? er : eb;
+    }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)er, sh), p = (uint32_t)__shfl_xor((int)ec, sh);
+      er = er > o ? er : o, ec = ec > p ? ec : p;
+    }
+    uint32_t* red = reinterpret_cast<uint32_t*>(lds);
+    if (lane == 0) red[2 * wave] = er, red[2 * wave + 1] = ec;
+    __syncthreads();
+    er = ec = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      er = er > red[2 * w] ? er : red[2 * w], ec = ec > red[2 * w + 1] ? ec : red[2 * w + 1];
+    }
+    er = (uint32_t)__builtin_amdgcn_readfirstlane((int)er), ec = (uint32_t)__builtin_amdgcn_readfirstlane((int)ec);
+    __syncthreads();  // the reduction scratch is the first LDS slot
+    er = er < 32u ? 32u : er > 254u ? 254u : er;  // (gradients below 2^-94 are zero for every purpose; keeps the scales normal floats)
+    ec = ec < 32u ? 32u : ec > 254u ? 254u : ec;
+  }
+  // rows: value * G, G = 2^(138 - er); the stream forms the fp16 scale of a lane as exponent field E - erow
+  const uint32_t erow = er - 20u, ecol = ec - 20u;
+  const float g_row = __builtin_bit_cast(float, (265u - er) << 23), g_col = col_mx ? __builtin_bit_cast(float, (265u - ec) << 23) : 1.0f;
+  const float sraw = raw_src == 1 ? g_row : 1.0f;          // the raw fragment is a row of dpre or the (unscaled) aux columns
+  const float un_row = 1.0f / g_row, un_col = 1.0f / g_col;  // (powers of two: exact)
+
+  f32x32w c0, c1, c2, c3, c4, c5, c6, c7, cx;
+#ifdef SR_W9_TIMING
+  const uint32_t nt_in = nt;
+  const uint64_t tc0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifndef SR_W9_P_INC
+#define SR_W9_P_INC "wgrad9_loop_p.inc"
+#define SR_W9_M_INC "wgrad9_loop_m.inc"
+#endif
+#define SR_W9_OUTS                                                                                                                    \
+  "={a[0:31]}"(c0), "={a[32:63]}"(c1), "={a[64:95]}"(c2), "={a[96:127]}"(c3), "={a[128:159]}"(c4), "={a[160:191]}"(c5),              \
+      "={a[192:223]}"(c6), "={a[224:255]}"(c7), "={v[0:31]}"(cx), [nt] "+s"(nt)
+#define SR_W9_INS                                                                                                                     \
+  "{v240}"(rdo[0]), "{v241}"(rdo[1]), "{v242}"(lane16), "{v243}"(vd), "{v244}"(va), "{v245}"(vx), [b0] "s"(base[0]), [b1] "s"(base[1]), \
+      [b2] "s"(base[2]), [b3] "s"(base[3]), [bx] "s"(base[4]), [sb0] "s"(sbase[0]), [sb1] "s"(sbase[1]), [sb2] "s"(sbase[2]),        \
+      [sb3] "s"(sbase[3]), [w0] "s"(wb[0]), [w1] "s"(wb[1]), [w2] "s"(wb[2]), [w3] "s"(wb[3]), [wx] "s"(wb[4]), [aofl] "s"(aofl),    \
+      [aofh] "s"(aofh), [bof] "s"(bof), [strd] "s"(strd), [stra] "s"(stra), [strx] "s"(strx), [tleft] "s"(tleft), [erow] "s"(erow),   \
+      [ecol] "s"(ecol), [sraw] "s"(sraw)
+  if (col_mx) {
+    asm volatile(
+#include SR_W9_M_INC
+        : SR_W9_OUTS
+        : SR_W9_INS
+        :
+#include "wgrad9_loop_clobbers.inc"
+    );
+  } else {
+    asm volatile(
+#include SR_W9_P_INC
+        : SR_W9_OUTS
+        : SR_W9_INS
+        :
+#include "wgrad9_loop_clobbers.inc"
+    );
+  }
+#undef SR_W9_OUTS
+#undef SR_W9_INS
+#ifdef SR_W9_TIMING
+  if (prm.dbg && tid == 0) {
+    prm.dbg[3 * blockIdx.x] = (long long)(__builtin_amdgcn_s_memtime() - tc0);
+    prm.dbg[3 * blockIdx.x + 1] = (long long)(__builtin_amdgcn_s_memrealtime() - tr0);
+    prm.dbg[3 * blockIdx.x + 2] = nt_in;
+  }
+#endif
+
+  // ---- partial block of this slice ------------------------------------------------------------------------------------------------
+  float* out = prm.partial + (long)blockIdx.x * kWgBlockFloats;
+  const int n_rows = 16 * nr, n_cols = 16 * nc;
+  const f32x32w* cc[8] = {&c0, &c1, &c2, &c3, &c4, &c5, &c6, &c7};
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int row0 = 32 * (4 * wr + ((a + 2 * wc) & 3));
+    if (row0 >= n_rows) continue;  // (wave-uniform) row tiles the block does not have: stale-LDS results, never read
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int col = 128 * wc + 32 * c + (lane & 31);
+      if (128 * wc + 32 * c >= n_cols) continue;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int row = row0 + (g & 3) + 8 * (g >> 2) + 4 * hh;
+        out[row * 256 + col] = (*cc[2 * a + (c >> 1)])[16 * (c & 1) + g] * un_row * un_col;
+      }
+    }
+  }
+  float* oa = out + 256 * 256;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int row0 = 32 * (4 * wr + ((a + 2 * wc) & 3));
+    if (row0 >= n_rows) continue;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int row = row0 + (g & 3) + 8 * (g >> 2) + 4 * hh;
+      oa[row * 32 + (lane & 31)] = cx[16 * a + g] * un_row;
+    }
+  }
+}
+
+// the 4-wave kernel reads both workspaces through 32-bit per-lane offsets
+bool wgrad9_fits(long n_tiles, int ak, int dk) {
+  const long big = ak > dk ? ak : dk;
+  return n_tiles * big * 1024l < (1l << 32);
+}
+
+int launch_wgrad9(const uint4* dpre, const uint4* acts, const int* blocks, const int* loads, float* partial, long n_tiles, int n_blocks,
+                  int ak, int dk, int load_ints, int n_slices, hipStream_t st) {
+  Wgrad9Params p;
+  p.dpre = (const char*)dpre, p.acts = (const char*)acts, p.blocks = blocks, p.loads = loads, p.partial = partial;
+  p.n_tiles = n_tiles, p.n_blocks = n_blocks, p.ak = ak, p.dk = dk, p.load_ints = load_ints;
+  const char* dbg = getenv("SR_W9_DBG");
+  p.dbg = dbg ? (long long*)strtoull(dbg, nullptr, 10) : nullptr;
+  const size_t lds = (size_t)kSlots9 * kSlot9;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)wgrad9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad9_kernel, dim3(n_slices), dim3(256), lds, st, p);
+  return check_launch("wgrad9_kernel");
+}
+
+}  // namespace sr

@@ -417,7 +417,11 @@ def backward_maps(feat=256, tau=4):
 # csrc/mlp_layout.h (SR_FMT8): logical 16-bit fragment f of a workspace -> (unit, codec[, scale unit, scale byte]).
 SRC_DPRE, SRC_ACTS = 1, 2
 RAW16, PHASE8, MX8 = 0, 1, 2
-WG8_LOAD_INTS = 20
+WG8_OLD_INTS = 20          # load table of the 16- / 8-wave kernels (wgrad8.hip, wgrad8f.hip)
+WG9_DUTY_INTS = 4 * 5 * 4  # duty table of the 4-wave kernel (wgrad9.hip): 4 waves x 5 duties x (source, unit, LDS fragment, scale)
+WG9_SCAN_INTS = 8          # ... + 4 x (source | unit << 8, byte mask | is_column << 16): where the block's MX8 exponent bytes live (range scan)
+WG8_LOAD_INTS = WG8_OLD_INTS + WG9_DUTY_INTS + WG9_SCAN_INTS
+WG9_DUMP_FRAG = 34         # LDS fragment an unused duty decodes into (csrc/gen/wgrad9_loop.py: 16 rows + 16 columns + 2 aux + 2 dump)
 def fmt8_geometry(feat=256):
     """Unit (1 KiB) offsets of the 8-bit workspaces (csrc/mlp_layout.h kD8* / kA8*) and the 16-bit fragment numbers they map."""
     KS, HS = feat // 16, feat // 32
@@ -471,10 +475,11 @@ def act8_source(f, auxs, feat=256):
 
 @functools.lru_cache(maxsize=8)
 def wgrad8_loads(feat=256, tau=4):
-    """Load table of csrc/wgrad8.hip for the job blocks of ``backward_maps``: int32 [n_blocks, 20].
+    """Load tables of the 8-bit weight-gradient kernels for the job blocks of ``backward_maps``: int32 [n_blocks, 100].
 
-    Per block: ints 0..15 = the primary load of wave w (0 = none; bits 0-1 source, 2-3 codec, 4-11 unit, 12-17 operand
-    fragment, 18-19 scale area, 20-23 scale byte), ints 16..18 = the scale unit fetched into scale area 0..2 (0 = none)."""
+    Per block: ints 0..15 = the primary load of wave w of csrc/wgrad8.hip (0 = none; bits 0-1 source, 2-3 codec, 4-11 unit, 12-17 operand
+    fragment, 18-19 scale area, 20-23 scale byte), ints 16..18 = the scale unit fetched into scale area 0..2 (0 = none); ints 20..99 =
+    the duty table of csrc/wgrad9.hip (``wgrad9_duties``)."""
     bm = backward_maps(feat, tau)
     auxs = bm["auxs"]
     out = np.zeros((len(bm["block_rows"]), WG8_LOAD_INTS), np.int32)
@@ -506,4 +511,63 @@ def wgrad8_loads(feat=256, tau=4):
             out[b, w] = desc
         for k, (src, unit) in enumerate(areas):
             out[b, 16 + k] = src | (unit << 4)
+    duties = wgrad9_duties(feat, tau)
+    out[:, WG8_OLD_INTS:WG8_OLD_INTS + WG9_DUTY_INTS] = duties
+    # scan list: the distinct (source, scale unit) of the enabled MX8 duties with the mask of their bytes in the lane's 16; rows and columns apart
+    for b in range(out.shape[0]):
+        ent = {}
+        for w in range(4):
+            for k in range(4):
+                src, unit, dst, sc = duties[b].reshape(4, 5, 4)[w, k]
+                is_col = k >= 2
+                if dst == WG9_DUMP_FRAG or (is_col and bm["blocks"][b, 8] != KIND_BF16):
+                    continue
+                key = (int(src), int(sc) >> 4, is_col)
+                ent[key] = ent.get(key, 0) | (1 << (int(sc) & 15))
+        assert len(ent) <= WG9_SCAN_INTS // 2, (b, ent)
+        for i, ((src, unit, is_col), mask) in enumerate(sorted(ent.items())):
+            out[b, WG8_OLD_INTS + WG9_DUTY_INTS + 2 * i] = src | (unit << 8)
+            out[b, WG8_OLD_INTS + WG9_DUTY_INTS + 2 * i + 1] = mask | (int(is_col) << 16)
     return out
+
+
+@functools.lru_cache(maxsize=8)
+def wgrad9_duties(feat=256, tau=4):
+    """Duty table of csrc/wgrad9.hip: int32 [n_blocks, 80] = 4 waves x 5 duties x (source, unit, LDS fragment, scale).
+
+    A workgroup of four waves owns one job block; per 32-point tile every wave fetches, decodes and writes to the LDS slot
+      duties 0, 1: one MX8 double fragment of dpre rows each     duties 2, 3: one double fragment of activation columns each (PHASE8, or
+      MX8 for the feats columns)     duty 4: one raw bf16 fragment (an aux fragment, or the bf16 row fragment d_sigma_pre / d_head).
+    ``source`` 1 = dpre, 2 = acts workspace; ``unit`` = 1-KiB unit within the tile; ``LDS fragment`` 0..15 rows, 16..31 columns, 32 / 33
+    aux, WG9_DUMP_FRAG = unused duty (it fetches a valid unit and decodes it into the dump fragments); ``scale`` = 16 * unit + byte of
+    the lane's MX8 exponent (same source).  Rows are always read from dpre and columns from acts (the kernel steps one per-lane offset per
+    workspace), the raw duty from either."""
+    bm = backward_maps(feat, tau)
+    auxs = bm["auxs"]
+    out = np.zeros((len(bm["block_rows"]), 4, 5, 4), np.int32)
+    for b, (rows, cols) in enumerate(zip(bm["block_rows"], bm["block_cols"])):
+        out[b, :, 0:2] = [SRC_DPRE, 0, WG9_DUMP_FRAG, 0]
+        out[b, :, 2:4] = [SRC_ACTS, auxs, WG9_DUMP_FRAG, 16 * auxs]
+        out[b, :, 4] = [SRC_ACTS, 0, WG9_DUMP_FRAG, 0]
+        raw_wave = 0
+        for a in range(auxs):                                    # aux fragments: waves 1, 2
+            out[b, 1 + a, 4] = [SRC_ACTS, a, 32 + a, 0]
+        for base, frags, src, lookup, d0 in ((0, rows, SRC_DPRE, lambda f: dpre8_source(f, feat), 0),
+                                             (16, cols, SRC_ACTS, lambda f: act8_source(f, auxs, feat), 2)):
+            pos, n_df = 0, 0
+            while pos < len(frags):
+                d = lookup(frags[pos])
+                if d["codec"] == RAW16:
+                    assert src == SRC_DPRE and raw_wave == 0, (b, frags)   # one bf16 row fragment per block: wave 0 (aux: waves 1, 2)
+                    out[b, 0, 4] = [src, d["unit"], base + pos, 0]
+                    raw_wave = 1
+                    pos += 1
+                    continue
+                assert d["half"] == 0 and pos + 1 < len(frags) and frags[pos + 1] == frags[pos] + 1, (b, frags, pos)
+                assert (d["codec"] == MX8) == (src == SRC_DPRE or bm["blocks"][b, 8] == KIND_BF16), (b, frags, pos)
+                assert n_df < 8, (b, frags)
+                scale = 16 * d["scale_unit"] + d["scale_byte"] if d["codec"] == MX8 else 16 * auxs
+                out[b, n_df % 4, d0 + n_df // 4] = [src, d["unit"], base + pos, scale]
+                n_df += 1
+                pos += 2
+    return out.reshape(len(bm["block_rows"]), WG9_DUTY_INTS)
