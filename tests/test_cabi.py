@@ -89,8 +89,9 @@ def test_wgrad_plan_host_only(handle):
         if fmt == 16:
             assert (ns == ns[0]).all()  # equal slices
         elif n_points == 65536 and n_wg == 256:
-            # cost-weighted: every workgroup used, full 256 x 256 blocks get more slices than the one-row head blocks
-            assert n.value == 256 and ns[:8].min() > ns[12] >= ns[13] >= 1 and ns[:8].max() - ns[:8].min() <= 1
+            # every workgroup used; the default 4-wave kernel (wgrad9.hip) runs one stream for every block: slices differ by at most one
+            # (the cost-weighted split of the r02 kernel is selected together with it, SATNERF_WGRAD_V1=1)
+            assert n.value == 256 and ns.max() - ns.min() <= 1
     bad = np.ascontiguousarray(blocks0.copy())
     bad[0, 1] = 17
     assert handle.sr_wgrad_plan(bad.ctypes.data_as(ctypes.c_void_p), bad.shape[0], 65536, 256, 16, ctypes.byref(n)) != 0
