@@ -76,9 +76,10 @@ def acc(a, c):
 
 
 class Stream:
-    def __init__(self, col_codec, ablate=()):
+    def __init__(self, col_codec, ablate=(), main=True):
         assert col_codec in ("phase", "mx")
         self.col_codec = col_codec
+        self.main = main               # False: a wave whose quadrant nobody reads (narrow blocks): aux tiles only, same loads / decode / rendezvous
         self.ablate = set(ablate)      # timing experiments (wrong results): nomfma, noload, nodec, noread, nowrite, nobar
         self.ns = 2 if col_codec == "phase" else 4     # scale-byte loads per tile
         self.nld = 4 + self.ns + 1                     # global loads per tile and wave
@@ -247,12 +248,13 @@ class Stream:
                     fi += 1
 
         for ks in range(2):
-            rq = list(OPS)
+            rq = list(OPS) if self.main else ["A0", "A1", "X"]
             for idx in range(18):
                 if idx == 0:   # every operand of this k-step has landed (they were read one k-step ago): one wait instead of one per MFMA
                     self.wait_for(("cur", ks, "X", 1))
                 if idx < 16:
-                    self.mfma(ks, *order[idx])
+                    if self.main:
+                        self.mfma(ks, *order[idx])
                 else:
                     self.mfma_aux(ks, idx - 16)
                 if rq and idx < 9:     # one operand (two reads) of the next k-step per gap, all nine under way by gap 8
@@ -311,7 +313,7 @@ class Stream:
         e("s_waitcnt lgkmcnt(0)", "wait")
         self.lgkm = []
         e("s_barrier", "salu")
-        for name in OPS:
+        for name in (OPS if self.main else ("A0", "A1", "X")):
             self.read_operand("nxt", 0, 0, name)
         # ---- the loop: four tiles per trip -------------------------------------------------------------------------------------
         # LDS-counter bookkeeping at the loop label: the first body is generated from the prologue's state (the 18 reads of K0(0) in
@@ -353,11 +355,11 @@ def main():
         out_dir = sys.argv[1]
     suffix = sys.argv[2] if len(sys.argv) > 2 else ""
     ablate = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ()
-    for codec, tag in (("phase", "p"), ("mx", "m")):
-        s = Stream(codec, ablate=ablate)
+    for codec, tag in (("phase", "p"), ("mx", "m"), ("phase", "px"), ("mx", "mx")):
+        s = Stream(codec, ablate=ablate, main=len(tag) == 1)
         with open(os.path.join(out_dir, f"wgrad9_loop_{tag}{suffix}.inc"), "w") as f:
             f.write(s.inc_file())
-        print(codec, s.n, len(s.ins), "LDS operations in flight at body ends:", [len(x) for x in s.states])
+        print(tag, s.n, len(s.ins), "LDS operations in flight at body ends:", [len(x) for x in s.states])
     with open(os.path.join(out_dir, "wgrad9_loop_clobbers.inc"), "w") as f:
         f.write(clobber_file())
 

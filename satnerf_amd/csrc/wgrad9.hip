@@ -202,6 +202,8 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
 #ifndef SR_W9_P_INC
 #define SR_W9_P_INC "wgrad9_loop_p.inc"
 #define SR_W9_M_INC "wgrad9_loop_m.inc"
+#define SR_W9_PX_INC "wgrad9_loop_px.inc"
+#define SR_W9_MX_INC "wgrad9_loop_mx.inc"
 #endif
 #define SR_W9_OUTS                                                                                                                    \
   "={a[0:31]}"(c0), "={a[32:63]}"(c1), "={a[64:95]}"(c2), "={a[96:127]}"(c3), "={a[128:159]}"(c4), "={a[160:191]}"(c5),              \
@@ -212,7 +214,10 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
       [sb3] "s"(sbase[3]), [w0] "s"(wb[0]), [w1] "s"(wb[1]), [w2] "s"(wb[2]), [w3] "s"(wb[3]), [wx] "s"(wb[4]), [aofl] "s"(aofl),    \
       [aofh] "s"(aofh), [bof] "s"(bof), [strd] "s"(strd), [stra] "s"(stra), [strx] "s"(strx), [tleft] "s"(tleft), [erow] "s"(erow),   \
       [ecol] "s"(ecol), [sraw] "s"(sraw)
-  if (col_mx) {
+  // a wave whose 128 x 128 quadrant nobody reads (narrow blocks: packing.wgrad9_duties' quadrant mask) runs the stream without the 32
+  // main MFMAs and their operand reads: same loads, decode, rendezvous, aux tiles -- the time of a tile is unchanged, its energy is not
+  const bool quad_on = (__builtin_amdgcn_readfirstlane(prm.loads[(long)blk * prm.load_ints + kOldInts + 4 * kDuties * kDutyInts + 2 * kScanEntries]) >> wave) & 1;
+  if (col_mx && quad_on) {
     asm volatile(
 #include SR_W9_M_INC
         : SR_W9_OUTS
@@ -220,9 +225,25 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
         :
 #include "wgrad9_loop_clobbers.inc"
     );
-  } else {
+  } else if (col_mx) {
+    asm volatile(
+#include SR_W9_MX_INC
+        : SR_W9_OUTS
+        : SR_W9_INS
+        :
+#include "wgrad9_loop_clobbers.inc"
+    );
+  } else if (quad_on) {
     asm volatile(
 #include SR_W9_P_INC
+        : SR_W9_OUTS
+        : SR_W9_INS
+        :
+#include "wgrad9_loop_clobbers.inc"
+    );
+  } else {
+    asm volatile(
+#include SR_W9_PX_INC
         : SR_W9_OUTS
         : SR_W9_INS
         :

@@ -420,7 +420,8 @@ RAW16, PHASE8, MX8 = 0, 1, 2
 WG8_OLD_INTS = 20          # load table of the 16- / 8-wave kernels (wgrad8.hip, wgrad8f.hip)
 WG9_DUTY_INTS = 4 * 5 * 4  # duty table of the 4-wave kernel (wgrad9.hip): 4 waves x 5 duties x (source, unit, LDS fragment, scale)
 WG9_SCAN_INTS = 8          # ... + 4 x (source | unit << 8, byte mask | is_column << 16): where the block's MX8 exponent bytes live (range scan)
-WG8_LOAD_INTS = WG8_OLD_INTS + WG9_DUTY_INTS + WG9_SCAN_INTS
+WG9_MASK_INTS = 1          # ... + the mask of the 128 x 128 quadrants (bit = wave = 2 row half + column half) somebody reads
+WG8_LOAD_INTS = WG8_OLD_INTS + WG9_DUTY_INTS + WG9_SCAN_INTS + WG9_MASK_INTS
 WG9_DUMP_FRAG = 34         # LDS fragment an unused duty decodes into (csrc/gen/wgrad9_loop.py: 16 rows + 16 columns + 2 aux + 2 dump)
 def fmt8_geometry(feat=256):
     """Unit (1 KiB) offsets of the 8-bit workspaces (csrc/mlp_layout.h kD8* / kA8*) and the 16-bit fragment numbers they map."""
@@ -528,6 +529,13 @@ def wgrad8_loads(feat=256, tau=4):
         for i, ((src, unit, is_col), mask) in enumerate(sorted(ent.items())):
             out[b, WG8_OLD_INTS + WG9_DUTY_INTS + 2 * i] = src | (unit << 8)
             out[b, WG8_OLD_INTS + WG9_DUTY_INTS + 2 * i + 1] = mask | (int(is_col) << 16)
+    # quadrant mask: which (row half, column half) of each 256 x 256 block holds a gradient the scatter map reads
+    g = bm["gidx"][bm["gidx"] >= 0].astype(np.int64)
+    blk, w = g // WG_BLOCK_FLOATS, g % WG_BLOCK_FLOATS
+    main = w < 256 * 256
+    quad = 2 * ((w[main] // 256) // 128) + (w[main] % 256) // 128
+    for b, q in zip(blk[main], quad):
+        out[b, WG8_OLD_INTS + WG9_DUTY_INTS + WG9_SCAN_INTS] |= 1 << int(q)
     return out
 
 
