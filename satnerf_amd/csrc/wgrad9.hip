@@ -48,11 +48,22 @@ struct Wgrad9Params {
 
 __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+#ifdef SR_W9_TIMING
+  const uint64_t tk0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int* d = prm.blocks;
+  // which job block owns this slice: one lane per table row, one ballot (a scalar walk of the table costs one memory latency per block)
   int blk = 0;
-  for (; blk + 1 < prm.n_blocks && (int)blockIdx.x >= d[kWgFirstSlice] + d[kWgSlices]; ++blk) d += kWgTableInts;
+  for (int b0 = 0; b0 < prm.n_blocks; b0 += 64) {
+    const int b = b0 + lane;
+    const bool mine = b < prm.n_blocks && (int)blockIdx.x >= prm.blocks[kWgTableInts * b + kWgFirstSlice] &&
+                      (int)blockIdx.x < prm.blocks[kWgTableInts * b + kWgFirstSlice] + prm.blocks[kWgTableInts * b + kWgSlices];
+    const unsigned long long hit = __ballot(mine);
+    if (hit) { blk = b0 + __builtin_ctzll(hit); break; }
+  }
+  blk = __builtin_amdgcn_readfirstlane(blk);
+  const int* d = prm.blocks + kWgTableInts * blk;
   const int nr = d[1] + d[3], nc = d[5] + d[7];
   const bool col_mx = d[8] == 0;  // packing.KIND_BF16: the identity stage (feats) -> MX8 columns
   const long tiles_per_split = (prm.n_tiles + d[kWgSlices] - 1) / d[kWgSlices];
@@ -110,39 +121,59 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
     // the slice; all of an entry's loads (one 16-byte lane slot per tile) are in flight at once.
     const int* scan = prm.loads + (long)blk * prm.load_ints + kOldInts + 4 * kDuties * kDutyInts;
     const uint32_t n_mine = nt > (uint32_t)wave ? (nt - (uint32_t)wave + 3u) / 4u : 0u;  // tiles wave, wave + 4, ...
-    auto bytes_max = [](u16x2 m, uint32_t x) {
-      m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2, x & 0x00ff00ffu));
-      return __builtin_elementwise_max(m, __builtin_bit_cast(u16x2, (x >> 8) & 0x00ff00ffu));
+    // byte-wise running maximum without unpacking: a u16 maximum orders by the HIGH byte first, so pk_max(m, x) tracks bytes 1 and 3
+    // exactly (in the high bytes of m's halves) and pk_max(m', x << 8) bytes 0 and 2
+    auto bytes_max = [](u16x2& mh, u16x2& ml, uint32_t x) {
+      mh = __builtin_elementwise_max(mh, __builtin_bit_cast(u16x2, x));
+      ml = __builtin_elementwise_max(ml, __builtin_bit_cast(u16x2, x << 8));
     };
-    for (int i = 0; i < kScanEntries; ++i) {
+    auto top_byte = [](u16x2 mh, u16x2 ml) {
+      const uint32_t a = mh[0] > mh[1] ? mh[0] : mh[1], b = ml[0] > ml[1] ? ml[0] : ml[1];
+      return (a > b ? a : b) >> 8;
+    };
+    constexpr int kPass = 28;  // tiles of a wave per pass: all of a 112-tile slice (65,536 points over 18 slices)
+    // loads of one entry: wave-uniform tile base (scalar arithmetic) + the lane's 16 bytes; clamped, not predicated
+    auto fetch = [&](const char* ws, uint32_t unit, uint32_t stride, uint32_t jb, uint4 (&w)[kPass]) {
+#pragma unroll
+      for (int j = 0; j < kPass; ++j) {
+        const uint32_t jj = jb + j < n_mine ? jb + j : n_mine - 1;
+        const char* pt = ws + (uint64_t)unit * 1024 + (uint64_t)((uint32_t)t0 + (uint32_t)wave + 4u * jj) * stride;
+        w[j] = *reinterpret_cast<const uint4*>(pt + lane16);
+      }
+    };
+    for (int i = 0; i < kScanEntries && n_mine > 0; ++i) {
       const int e0 = __builtin_amdgcn_readfirstlane(scan[2 * i]), e1 = __builtin_amdgcn_readfirstlane(scan[2 * i + 1]);
       if (e0 == 0) break;
       const char* ws = (e0 & 255) == 1 ? prm.dpre : prm.acts;
       const uint32_t stride = (e0 & 255) == 1 ? strd : stra;
-      const char* p0 = ws + (long)(e0 >> 8) * 1024 + lane16;
       uint32_t mk[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const uint32_t nib = ((uint32_t)e1 >> (4 * k)) & 15u;
         mk[k] = (nib & 1u ? 0xffu : 0u) | (nib & 2u ? 0xff00u : 0u) | (nib & 4u ? 0xff0000u : 0u) | (nib & 8u ? 0xff000000u : 0u);
       }
-      u16x2 m = {0, 0};
-      for (uint32_t jb = 0; jb < n_mine; jb += 32) {
-        uint4 w[32];
+      u16x2 mh = {0, 0}, ml = {0, 0};
+      for (uint32_t jb = 0; jb < n_mine; jb += kPass) {
+        uint4 w[kPass];
+        fetch(ws, (uint32_t)e0 >> 8, stride, jb, w);
+        if (mk[0]) {  // (wave-uniform: one branch per dword of the slot, not per element)
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {  // (clamped, not predicated: the loads of a pass issue back to back)
-          const uint32_t jj = jb + j < n_mine ? jb + j : n_mine - 1;
-          w[j] = *reinterpret_cast<const uint4*>(p0 + (uint64_t)(((uint32_t)t0 + (uint32_t)wave + 4u * jj) * stride));
+          for (int j = 0; j < kPass; ++j) bytes_max(mh, ml, w[j].x & mk[0]);
         }
+        if (mk[1]) {
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-          if (mk[0]) m = bytes_max(m, w[j].x & mk[0]);
-          if (mk[1]) m = bytes_max(m, w[j].y & mk[1]);
-          if (mk[2]) m = bytes_max(m, w[j].z & mk[2]);
-          if (mk[3]) m = bytes_max(m, w[j].w & mk[3]);
+          for (int j = 0; j < kPass; ++j) bytes_max(mh, ml, w[j].y & mk[1]);
+        }
+        if (mk[2]) {
+#pragma unroll
+          for (int j = 0; j < kPass; ++j) bytes_max(mh, ml, w[j].z & mk[2]);
+        }
+        if (mk[3]) {
+#pragma unroll
+          for (int j = 0; j < kPass; ++j) bytes_max(mh, ml, w[j].w & mk[3]);
         }
       }
-      const uint32_t e = m[0] > m[1] ? m[0] : m[1];
+      const uint32_t e = top_byte(mh, ml);
       if ((e1 >> 16) & 1) ec = ec > e ? ec : e;
       else er = er > e ? er : e;
     }
@@ -152,16 +183,11 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
     const int r_src = __builtin_amdgcn_readfirstlane(raw0[0]), r_unit = __builtin_amdgcn_readfirstlane(raw0[1]);
     if (r_src == 1 && __builtin_amdgcn_readfirstlane(raw0[2]) != kDumpFrag && n_mine > 0) {
       u16x2 m = {0, 0};
-      const char* rp = prm.dpre + (long)r_unit * 1024 + lane16;
-      for (uint32_t jb = 0; jb < n_mine; jb += 32) {
-        uint4 w[32];
+      for (uint32_t jb = 0; jb < n_mine; jb += kPass) {
+        uint4 w[kPass];
+        fetch(prm.dpre, (uint32_t)r_unit, strd, jb, w);
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-          const uint32_t jj = jb + j < n_mine ? jb + j : n_mine - 1;
-          w[j] = *reinterpret_cast<const uint4*>(rp + (uint64_t)(((uint32_t)t0 + (uint32_t)wave + 4u * jj) * strd));
-        }
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
+        for (int j = 0; j < kPass; ++j) {
           const uint32_t ww[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
 #pragma unroll
           for (int k = 0; k < 4; ++k) m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2, ww[k] & 0x7fff7fffu));
@@ -253,10 +279,13 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
 #undef SR_W9_OUTS
 #undef SR_W9_INS
 #ifdef SR_W9_TIMING
+  const uint64_t tr1 = __builtin_amdgcn_s_memrealtime();
   if (prm.dbg && tid == 0) {
     prm.dbg[3 * blockIdx.x] = (long long)(__builtin_amdgcn_s_memtime() - tc0);
-    prm.dbg[3 * blockIdx.x + 1] = (long long)(__builtin_amdgcn_s_memrealtime() - tr0);
+    prm.dbg[3 * blockIdx.x + 1] = (long long)(tr1 - tr0);
     prm.dbg[3 * blockIdx.x + 2] = nt_in;
+    prm.dbg[3 * 1024 + 4 * blockIdx.x] = (long long)tk0, prm.dbg[3 * 1024 + 4 * blockIdx.x + 1] = (long long)tr0;
+    prm.dbg[3 * 1024 + 4 * blockIdx.x + 2] = (long long)tr1;
   }
 #endif
 
@@ -290,6 +319,10 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
       oa[row * 32 + (lane & 31)] = cx[16 * a + g] * un_row;
     }
   }
+#ifdef SR_W9_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  if (prm.dbg && tid == 0) prm.dbg[3 * 1024 + 4 * blockIdx.x + 3] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // the 4-wave kernel reads both workspaces through 32-bit per-lane offsets

@@ -18,7 +18,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 rays, ts = data.synthetic_rays(n); rays, ts = rays.to(dev), ts.to(dev); tgt = torch.rand(n, 3, device=dev)
 dbg9 = None
 if os.environ.get("AB_TIMING9"):  # wgrad9.hip built with -DSR_W9_TIMING: per workgroup (shader cycles, 100-MHz ticks, tiles)
-    dbg9 = torch.zeros(3 * 1024, dtype=torch.int64, device=dev)
+    dbg9 = torch.zeros(7 * 1024, dtype=torch.int64, device=dev)
     os.environ["SR_W9_DBG"] = str(dbg9.data_ptr())
 for _ in range(10): tr.step(rays, ts, tgt)
 timer = ops.KernelTimer(); ops.kernel_timer = timer
@@ -27,7 +27,12 @@ torch.cuda.synchronize()
 print(os.path.basename(os.environ.get("SATRENDER_LIB", "default")), {k: round(timer.mean_ms(k) * 1e3, 1) for k in ("mlp_fwd", "mlp_bwd", "wgrad")})
 
 if dbg9 is not None:
-    d = dbg9.cpu().view(-1, 3).double(); d = d[d[:, 2] > 0]
+    st = dbg9.cpu()[3 * 1024:].view(-1, 4).double(); st = st[st[:, 0] > 0]
+    if st.shape[0]:
+        k0 = st[:, 0].min()
+        f = lambda c: f"{float((st[:, c] - k0).median()) / 100:.1f} (max {float((st[:, c] - k0).max()) / 100:.1f})"
+        print(f"  stamps (us after the first workgroup's entry): entry {f(0)}, loop start {f(1)}, loop end {f(2)}, epilogue done {f(3)}")
+    d = dbg9.cpu()[:3 * 1024].view(-1, 3).double(); d = d[d[:, 2] > 0]
     cyc, ticks, nt = d[:, 0], d[:, 1], d[:, 2]
     print(f"  wgrad9 in situ, {d.shape[0]} workgroups: cycles/tile median {float((cyc / nt).median()):.0f}, slice loop {float(ticks.median()) / 100:.1f} us median / "
           f"{float(ticks.max()) / 100:.1f} us max, clock {float((cyc / ticks).median()) * 0.1:.2f} GHz")
