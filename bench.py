@@ -41,7 +41,7 @@ PREWARM = 50                      # untimed steps before --warmup: graph capture
 KERNEL_NAMES = {"mlp_fwd": "satnerf_fwd2_kernel (fused MLP forward on the generated core, saving activations in training)",
                 "mlp_bwd": "satnerf_bwd_kernel (fused dX chain)", "wgrad": "wgrad kernel (weight-gradient GEMMs)"}
 PMC_ROWS = {"mlp_fwd": "satnerf_fwd", "mlp_bwd": "satnerf_bwd_kernel", "wgrad": "wgrad"}
-PMC_FILE = os.path.join("profiles", "r03_train_pmc.csv")
+PMC_FILE = os.path.join("profiles", "r04_train_pmc.csv")
 
 
 def pmc_traffic(kernel_key):
@@ -62,6 +62,22 @@ def pmc_traffic(kernel_key):
     return None if fetch is None or write is None else (2.0 * fetch + write) * 1024.0
 
 
+def provenance():
+    """What a stale `traffic` figure would be detected by: the git blob id of the committed PMC summary and the build time of the library
+    the kernels of this run came from (the PMC file is regenerated with every kernel change; tools/collect_profiles2.sh)."""
+    import hashlib
+
+    from satnerf_amd import _lib
+
+    out = {"lib": os.path.relpath(_lib.LIB_PATH, ROOT), "lib_built_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(_lib.LIB_PATH)))}
+    path = os.path.join(ROOT, PMC_FILE)
+    if os.path.exists(path):
+        data = open(path, "rb").read()
+        out["pmc_blob"] = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+        out["pmc_mtime_utc"] = time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(path)))
+    return out
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +89,8 @@ def parse():
     ap.add_argument("--phase", default=None, choices=["train", "forward"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward / parity_mode sub-records")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --rays per GPU (the default, what the driver's N = 1, 2, 4, 8 curve measures); strong: --rays in total, rank r takes rays r::N")
     return ap.parse_args()
 
 
@@ -117,8 +135,17 @@ def cpu_baseline(phase, n_rays, n_samples, budget_s=12.0):
         one()
         it += 1
     dt = (time.time() - t0) / it
+    # SURVEY.md 8(d) asks for os.cpu_count() threads: reported beside the best pool size (torch's intra-op pool does not scale that far)
+    torch.set_num_threads(cores)
+    one()
+    t1, it_all = time.time(), 0
+    while time.time() - t1 < budget_s / 2 and it_all < 50:
+        one()
+        it_all += 1
+    dt_all = (time.time() - t1) / it_all
     return {"value": n / dt, "unit": "rays/s", "cores": best_thr, "host_cpus": cores, "kind": "port",
-            "sample": f"{it} x {n} rays x {n_samples} samples, {phase}, torch {torch.__version__} CPU fp32"}
+            "sample": f"{it} x {n} rays x {n_samples} samples, {phase}, torch {torch.__version__} CPU fp32",
+            "value_all_threads": n / dt_all, "all_threads": cores}
 
 
 def measure(phase, mode, n_rays, n_samples, steps, warmup, world, rank, dev, want_kernels=True, bwd_fmt=None, fc_units=None):
@@ -145,7 +172,13 @@ def measure(phase, mode, n_rays, n_samples, steps, warmup, world, rank, dev, wan
     torch.manual_seed(1234 + rank)  # per-rank sampling jitter
 
     if phase == "train":
-        stepper = train_mod.Trainer(models, args, world_size=world)
+        # the reference's schedule is ON (main.py:86-94,128-131): StepLR per epoch and the SNerfLoss warm-up live in the device-side
+        # schedule block of the captured step.  The measured steps are those of the main phase: the counter starts after the two
+        # warm-up epochs (SatNerfLoss with the uncertainty term, rate decayed twice), an epoch = one pass over the ray bank
+        spe = max(n_bank // (n_rays * world), 1)
+        stepper = train_mod.Trainer(models, args, world_size=world, steps_per_epoch=spe)
+        stepper.n_steps = 2 * spe
+        measure.schedule = {"steps_per_epoch": spe, "first_measured_step": stepper.n_steps, "warming_up": bool(stepper.warming_up())}
 
         def step():
             stepper.step_from_bank(bank)
@@ -210,6 +243,10 @@ def measure(phase, mode, n_rays, n_samples, steps, warmup, world, rank, dev, wan
         ops.kernel_timer = None
         kernels = {k: timer.mean_ms(k) for k in ("mlp_fwd", "mlp_bwd", "wgrad") if timer.mean_ms(k)}
     fmt = train_mod._fmt_of(args) if phase == "train" else None
+    if phase == "train":
+        measure.schedule.update(lr=float(stepper.lr), epoch=int(stepper.current_epoch()))
+        measure.collective = {"in_graph": bool(getattr(stepper, "_adam_in_graph", False) and stepper._collective),
+                              "capture_failed": bool(getattr(stepper, "_collective_capture_failed", False))}
     return dt, kernels, fmt
 
 
@@ -244,7 +281,31 @@ def main():
             dist.init_process_group(backend)
 
     phase = a.phase or "train"
-    dt, kernel_ms, fmt = measure(phase, a.mode, a.rays, a.samples, a.steps, a.warmup, world, rank, dev)
+    if a.scaling == "strong":
+        assert a.rays % world == 0, f"--scaling strong: --rays {a.rays} must divide by {world} ranks"
+    rays_rank = a.rays // world if a.scaling == "strong" else a.rays
+    comm = None
+    if world > 1:
+        # self-verification of the N > 1 line (nobody but the driver owns a multi-GPU node): every rank contributes a one, so the
+        # reduced value is the number of ranks the collective really spanned; then the step's own collective -- one all-reduce of the
+        # flat fp32 gradient (662,537 + 120 floats = 2.65 MB) -- timed alone with HIP events
+        import torch.distributed as dist
+
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        flat = torch.zeros(662537 + 120, device=dev)
+        for _ in range(5):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            dist.all_reduce(flat)
+        e1.record()
+        torch.cuda.synchronize()
+        comm = {"rccl_ranks": int(round(ones.item())), "backend": dist.get_backend(), "allreduce_us": e0.elapsed_time(e1) / 20 * 1e3,
+                "allreduce_bytes": flat.numel() * 4}
+    dt, kernel_ms, fmt = measure(phase, a.mode, rays_rank, a.samples, a.steps, a.warmup, world, rank, dev)
     host_enqueue_s = measure.host_enqueue_s
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -254,8 +315,8 @@ def main():
         return
 
     ms_step = dt / a.steps * 1e3
-    value = a.rays * world * a.steps / dt
-    points = a.rays * a.samples
+    value = rays_rank * world * a.steps / dt
+    points = rays_rank * a.samples
     flop = points * FLOP_PER_POINT  # one pass (forward, dX or dW) over the batch
     tiles = (points + 31) // 32
     au, du = WS_UNITS.get(fmt, (0, 0))
@@ -265,7 +326,7 @@ def main():
                    "workspace_gbps": ws_bytes[k] / (ms * 1e-3) / 1e9} for k, ms in kernel_ms.items()}
     dom = max(kernels, key=lambda k: kernels[k]["ms"])
     passes = 3 if phase == "train" else 1
-    traffic = pmc_traffic(dom) if phase == "train" and a.mode == "bf16" and a.rays == 1024 and a.samples == 64 else None
+    traffic = pmc_traffic(dom) if phase == "train" and a.mode == "bf16" and rays_rank == 1024 and a.samples == 64 else None
     roof = {"bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": kernels[dom]["tflops"] / MFMA_PEAK_TFLOPS, "kernel": KERNEL_NAMES[dom], "kernel_ms": kernels[dom]["ms"],
             "algorithmic_flop_per_launch": flop,
@@ -276,18 +337,23 @@ def main():
     out = {
         "metric": "training rays/sec (64 samples/ray)" if phase == "train" else "inference rays/sec (64 samples/ray, render_rays no_grad)",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "f16": "f16", "bf16x3": "bf16x3"}[a.mode],
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": {"bf16": "bf16", "f16": "f16", "bf16x3": "bf16x3"}[a.mode],
         "data": "synthetic", "phase": phase, "prewarm_steps": PREWARM,
         "host_enqueue_ms_per_step": host_enqueue_s / a.steps * 1e3,
+        "provenance": provenance(),
         # (the driver keeps the first 120 characters: arithmetic and saved-state format come first)
-        "config": {"workload": f"BASELINE configs[1] sat-nerf 256/tau4, {a.rays} rays x {a.samples} samples/GPU, mlp_mode={a.mode}"
+        "config": {"workload": f"BASELINE configs[1] sat-nerf 256/tau4, {rays_rank} rays x {a.samples} samples/GPU, mlp_mode={a.mode}"
                                + (f", saved state {fmt}-bit" if fmt else "") + ", noise_std=0 sc_lambda=0 n_importance=0"
                                + ", stratified jitter drawn in-kernel (Philox-4x32-10)"
                                + (", rays = consecutive chunks of the HBM-resident bank (one kernel per step)" if phase == "forward" else ""),
-                   "rays_per_gpu": a.rays,
+                   "rays_per_gpu": rays_rank, "global_batch": rays_rank * world,
                    "n_samples": a.samples, "parallelism": f"dp{world}"},
         "roofline": roof,
     }
+    if phase == "train":
+        out["schedule"] = measure.schedule      # StepLR + SNerfLoss warm-up are part of the measured step (main.py:86-94,128-131)
+    if comm is not None:
+        out["comm"] = dict(comm, **(measure.collective if phase == "train" else {}))
     if world == 1 and not a.no_extras and phase == "train":
         # driver-timed numbers for the other two claims: the >= 40 % forward kernel and the tolerance-passing arithmetic
         n_sub = max(20, min(a.steps, 200))

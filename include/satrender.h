@@ -50,6 +50,9 @@ int64_t sr_bwd_stream_elems(int feat, int tau);  /* bf16 elements of the transpo
 /* training workspaces, per 32-point tile, in 16-bit elements, for a workspace format `fmt` (below) */
 int64_t sr_act_elems_per_tile(int feat, int fmt);   /* activations saved by the forward pass          */
 int64_t sr_dpre_elems_per_tile(int feat, int fmt);  /* pre-activation gradients written by the dX pass */
+/* tiles both workspaces must hold for n_points points: ceil(n_points / 32) rounded up to the 8 tiles of a workgroup -- the forward and
+ * dX kernels run whole workgroups, and the waves past the last point still store their (unused) tile */
+int64_t sr_workspace_tiles(int64_t n_points);
 
 /* ---- weight packing:  replaces nothing in the reference (its weights feed addmm directly) ---------
  * out_hi[i] = bf16_rne(src[idx[i]] * scale[i]);  out_lo[i] = bf16_rne(src[idx[i]]*scale[i] - out_hi[i])
@@ -91,7 +94,7 @@ int sr_sky_fwd(const float* sun, int sun_stride, int64_t n, int hidden, const fl
  * outputs (any may be NULL): albedo (P,3), sigma (P), sun_v (P), beta (P)   [models/satnerf.py:45-49]
  * stream_hi/lo: packed forward stream from sr_pack_stream (lo required iff mode == SR_MODE_BF16X3)
  * l0: (feat,4) fp32 rows [w_x, w_y, w_z, b] of fc_net.0, each multiplied by 30/(2*pi), in slot order
- * acts: NULL, or training workspace of sr_act_elems_per_tile(feat, act_fmt) * ceil(P/32) 16-bit elements, written in the
+ * acts: NULL, or training workspace of sr_act_elems_per_tile(feat, act_fmt) * sr_workspace_tiles(P) 16-bit elements, written in the
  * format act_fmt (SR_FMT8 needs mode == SR_MODE_BF16; act_fmt is ignored when acts == NULL). */
 typedef struct sr_mlp_inputs {
   const float* org;
@@ -168,7 +171,7 @@ int sr_render_points_per_block(int feat, int mode);
 /* ---- backward of the fused MLP: replaces autograd through SatNeRF.forward (models/satnerf.py:156-208) ------------
  * sr_satnerf_mlp_bwd: data-gradient chain.  Inputs: the forward's saved `acts`, its four outputs and the gradients of
  * those outputs (g_* may be NULL = 0); bwd_stream = packed transposed weights (sr_pack_stream with
- * packing.backward_maps).  Outputs: dpre (sr_dpre_elems_per_tile(feat, fmt) * ceil(P/32) 16-bit elements) and d_t (P,tau)
+ * packing.backward_maps).  Outputs: dpre (sr_dpre_elems_per_tile(feat, fmt) * sr_workspace_tiles(P) 16-bit elements) and d_t (P,tau)
  * fp32, the gradient w.r.t. each point's embedding vector (NULL to skip).  `fmt` = format of BOTH workspaces.
  * sr_satnerf_wgrad: weight-gradient GEMMs dpre x acts over all points.  `blocks` (n_blocks x 12 int32, device) lists the job
  * blocks (rf0 nr0 rf1 nr1 | cf0 nc0 cf1 nc1 | col_kind n_slices first_slice -: up to two ranges of dpre row fragments and of

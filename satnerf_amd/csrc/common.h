@@ -25,6 +25,9 @@ int check_launch(const char* what);
     }                          \
   } while (0)
 
+// tiles a training workspace holds for n_points points (sr_workspace_tiles): whole workgroups of 8 waves = 8 tiles
+constexpr long ws_tiles(long n_points) { return ((n_points + 31) / 32 + 7) / 8 * 8; }
+
 // ---- bf16 helpers -----------------------------------------------------------------------------
 // Two fp32 -> one dword of two bf16 (RNE): element 0 in the low half.  Lowers to v_cvt_pk_bf16_f32.
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
@@ -38,7 +41,7 @@ __device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {
   f32x2 v = {a, b};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
 }
-// the same with saturation to +-65504 (the fp16 weight stream: a scaled weight beyond the fp16 range must not become inf; NaN stays NaN)
+// the same with saturation to +-65504 (the fp16 weight stream: a scaled weight beyond the fp16 range must not become inf; a NaN becomes -65504 -- v_max_f32 returns the number)
 __device__ __forceinline__ uint32_t pack_f16x2_sat(float a, float b) {
   return pack_f16x2(__builtin_fminf(__builtin_fmaxf(a, -65504.f), 65504.f), __builtin_fminf(__builtin_fmaxf(b, -65504.f), 65504.f));
 }

@@ -35,6 +35,8 @@ extern "C" int64_t sr_bwd_stream_elems(int feat, int tau) {
   return (feat == 512 ? bwd512_stream_pieces() : BwdStream::total_pieces()) * 512;
 }
 
+extern "C" int64_t sr_workspace_tiles(int64_t n_points) { return n_points < 0 ? -1 : sr::ws_tiles(n_points); }
+
 extern "C" int64_t sr_dpre_elems_per_tile(int feat, int fmt) {
   if (fmt != SR_FMT16 && fmt != SR_FMT8) return -1;
   if (feat == 512) return fmt == SR_FMT8 ? (int64_t)dpre8_units_512() * 64 * 8 : -1;

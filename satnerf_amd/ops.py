@@ -395,14 +395,14 @@ def acts_workspace(n_points, feat, device, fmt=16):
     per_tile = _lib.lib().sr_act_elems_per_tile(feat, int(fmt))
     if per_tile <= 0:
         raise ValueError(f"unsupported workspace (feat={feat}, fmt={fmt})")
-    return _ws_empty(((n_points + 31) // 32) * per_tile, torch.int16, device, 1)
+    return _ws_empty(_lib.lib().sr_workspace_tiles(n_points) * per_tile, torch.int16, device, 1)
 
 
 def satnerf_mlp_bwd(feat, tau, n_points, bwd_stream, acts, albedo, sigma, sun_v, beta, g_albedo, g_sigma, g_sun_v, g_beta, want_dt=True, fmt=16):
     """dX chain: returns (dpre workspace, d_t (P,tau) or None); ``fmt`` = format of ``acts`` and of the returned workspace."""
     dev = albedo.device
     per_tile = _lib.lib().sr_dpre_elems_per_tile(feat, int(fmt))
-    dpre = _ws_empty(((n_points + 31) // 32) * per_tile, torch.int16, dev, 2)
+    dpre = _ws_empty(_lib.lib().sr_workspace_tiles(n_points) * per_tile, torch.int16, dev, 2)
     d_t = torch.empty(n_points, tau, dtype=torch.float32, device=dev) if want_dt else None
     opt = lambda t, nm: _p(_chk(t, nm, allow_none=True))  # noqa: E731
     ev = kernel_timer.span("mlp_bwd") if kernel_timer is not None else None

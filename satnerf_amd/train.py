@@ -172,11 +172,13 @@ class Trainer:
     """
 
     def __init__(self, models, args, world_size=1, lr=5e-4, loss_fn=None, use_graph=True, steps_per_epoch=None, lr_gamma=0.9,
-                 warmup_epochs=2):
+                 warmup_epochs=2, lr_steps_per_epoch=None):
         """``steps_per_epoch`` (= len(dataset) // batch_size, train_utils.py:14-15) switches the reference's schedule on:
         StepLR(step_size=1, gamma=``lr_gamma``) per epoch (main.py:86-94, train_utils.py:41-57) and ``metrics.SNerfLoss`` instead
         of ``SatNerfLoss`` while epoch < ``warmup_epochs`` (main.py:128-131 hard-codes 2).  None = constant rate, SatNerfLoss
-        from the first step (what bench.py measures)."""
+        from the first step.  ``lr_steps_per_epoch`` (default: ``steps_per_epoch``) is the number of batches after which Lightning
+        steps the StepLR: a DataLoader epoch has ceil(len(dataset) / batch_size) batches (drop_last=False, main.py:96-110) while the
+        warm-up test divides by the floor -- pass both when the batch size does not divide the dataset."""
         self._snerf = args.model == "s-nerf"
         self._caller_args = args  # main.py:132 decays args.noise_std in place: the caller's object follows, also for s-nerf's private copy
         if args.model == "sat-nerf" and steps_per_epoch is None:
@@ -194,6 +196,7 @@ class Trainer:
         # process group (how the single-GPU test box exercises the captured RCCL path)
         self._collective = world_size > 1 or (os.environ.get("SATNERF_FORCE_ALLREDUCE", "0") == "1" and dist.is_available() and dist.is_initialized())
         self.lr0, self.lr_gamma, self.steps_per_epoch, self.warmup_epochs = lr, lr_gamma, steps_per_epoch, warmup_epochs
+        self.lr_steps_per_epoch = lr_steps_per_epoch if lr_steps_per_epoch else steps_per_epoch
         if args.model == "sat-nerf" and args.n_importance > 0 and loss_fn is None:
             # metrics.py:22 multiplies weights_fine (N,S+I,1) with beta_coarse (N,S,1): the reference cannot train this combination
             # either; training only the coarse model while eval renders the fine one would be silently wrong
@@ -386,7 +389,7 @@ class Trainer:
         if self.steps_per_epoch:
             # StepLR(step_size=1, gamma) is stepped by Lightning AFTER an epoch's last batch: step k (0-based) trains at
             # gamma ** (k // steps_per_epoch); main.py:121's += 1 only shifts the SNerfLoss test (current_epoch / warming_up)
-            self.lr = self.lr0 * self.lr_gamma ** (self.n_steps // int(self.steps_per_epoch))
+            self.lr = self.lr0 * self.lr_gamma ** (self.n_steps // int(self.lr_steps_per_epoch))
         host = (float(self.lr), 1.0 if self.warming_up() else 0.0)
         if host != self._sched_host:
             self.adam_state[1:3].copy_(torch.tensor(host, dtype=torch.float32))
@@ -460,19 +463,35 @@ class Trainer:
         from . import ops
 
         self._graph = torch.cuda.CUDAGraph()
+        failed = False
         try:
             with ops.graph_capture(self._graph):
                 self._static_loss = run()
         except RuntimeError:
             if not capture_collective:
                 raise
-            # the collective could not be captured on this stack: eager all-reduce + Adam after the replay instead
+            failed = True
+        if capture_collective and self._any_rank(failed):
+            # the collective could not be captured on SOME rank: every rank drops its graph and re-captures without it (eager all-reduce +
+            # Adam after the replay), together -- the warm-up passes of the retry issue collectives, so a rank retrying alone would
+            # leave the job with mismatched collectives.  The vote goes over a gloo side group: the RCCL communicator of a
+            # failed capture is not to be trusted with it.
             self._collective_capture_failed = True
             self._graph = None
             torch.cuda.synchronize()
             self.state.zero_grad()
             return self._capture(inputs, banks=banks)
         self.state.zero_grad()  # capture does not execute
+
+    def _any_rank(self, flag):
+        """logical OR of ``flag`` over the ranks (host-side vote on a gloo group; a single process answers for itself)"""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return bool(flag)
+        if getattr(self, "_vote_group", None) is None:
+            self._vote_group = dist.new_group(backend="gloo")  # (collective: every rank reaches its first capture)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._vote_group)
+        return bool(t.item())
 
     def step_from_bank(self, bank, depth_bank=None):
         """One step on the banks' next batches; with a captured graph the batches are gathered straight into its static inputs."""
@@ -510,9 +529,11 @@ class Trainer:
             return self.step(*batches[0], depth=batches[1] if depth_bank is not None else None)
         return self.step(*bank.next_batch(), depth=None if depth_bank is None else depth_bank.next_batch())
 
-    def step(self, rays, ts, rgbs, depth=None, _inputs_in_place=False):
+    def step(self, rays, ts, rgbs, depth=None, _inputs_in_place=False, validate=True):
         """``depth`` = (rays (M,11), ts (M,), depths (M,2) = [target depth, weight]) of the depth-supervision batch or None
-        (pass None once past ``ds_drop``: main.py:138 stops adding the term)."""
+        (pass None once past ``ds_drop``: main.py:138 stops adding the term).  ``validate=False`` skips the range check of the image
+        indices (one device reduction + a host sync per step, rendering.validate_ts) for callers that have checked their ``ts`` once:
+        the host then runs ahead of the replayed step again."""
         from . import ops
 
         if depth is not None and not float(getattr(self.args, "ds_lambda", 0.0)) > 0:
@@ -521,7 +542,7 @@ class Trainer:
             ts = self._zero_ts(ts)
             if depth is not None:
                 depth = (depth[0], self._zero_ts(depth[1]), depth[2])
-        if not _inputs_in_place:
+        if not _inputs_in_place and validate:
             from .rendering import validate_ts
 
             validate_ts(ts, self.models)

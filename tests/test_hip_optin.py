@@ -53,3 +53,18 @@ def test_bench_contract_with_two_ranks_sharing_the_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
     assert abs(d["value"] - 2 * 1024 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-3 * d["value"]  # whole-job rays/s = all ranks' rays / max-over-ranks time
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    # the N > 1 line verifies itself: the ones all-reduce counted both ranks, the 2.65 MB gradient all-reduce was timed alone, and the line
+    # says whether the collective rode inside the step's graph (gloo cannot be captured: eager here) or a capture failed
+    c = d["comm"]
+    assert c["rccl_ranks"] == 2 and c["backend"] == "gloo" and c["allreduce_us"] > 0 and c["allreduce_bytes"] == (662537 + 120) * 4
+    assert c["in_graph"] is False and c["capture_failed"] is False
+    assert d["schedule"]["steps_per_epoch"] >= 1 and d["schedule"]["warming_up"] is False and d["schedule"]["epoch"] >= 2
+    assert d["provenance"]["lib"].endswith("libsatrender.so") and d["config"]["global_batch"] == 2048
+    # strong scaling: the same global batch split over the ranks
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29534", "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--scaling", "strong"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["config"]["rays_per_gpu"] == 512 and d["config"]["global_batch"] == 1024
+    assert abs(d["value"] - 1024 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-3 * d["value"]

@@ -2,7 +2,7 @@
 
 Tolerances (max-norm relative): bf16x3 parity mode <= 1e-4 on rgb / depth / weights as north_star
 states; integer-free fp32 stages (sampling, compositing, sky) much tighter.  The single-pass bf16 throughput mode
-is measured and bounded at 2e-2 (expected ~1e-3).
+is measured and bounded per output at ~1.7x its measured error (1e-3 .. 3e-3; BF16_*_GATES below).
 """
 import pytest
 import torch
@@ -129,7 +129,18 @@ def test_sample_pdf_standalone_golden():
         assert ((got - want).abs() > 2e-6).float().mean() < 5e-3
 
 
-@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-4), ("bf16", 2e-2)])
+# per-output gates of the single-pass bf16 arithmetic, ~1.7x what it measures against the reference (r04: albedo 2.1e-3, sigma 3.3e-3,
+# sun 5.8e-4, beta 2.4e-3; rgb 1.2e-3 / depth 7.3e-4 / weights 1.1e-3 .. 1.5e-3 after compositing): a regression that costs half a digit fails
+BF16_POINT_GATES = {"albedo": 4e-3, "sigma": 6e-3, "sun": 1.5e-3, "sky": 1e-6, "beta": 4e-3}
+BF16_RENDER_GATES = {"rgb": 2.5e-3, "depth": 1.5e-3, "weights": 3e-3, "beta": 4e-3, "sun": 1.5e-3}
+
+
+def _gate(errs, gates, what=""):
+    bad = {k: (e, gates[k.split("_")[0]]) for k, e in errs.items() if e >= gates[k.split("_")[0]]}
+    assert not bad, (what, bad, errs)
+
+
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-4), ("bf16", None)])
 def test_mlp_forward_points_golden(mode, tol):
     _, _, load_model = _lazy()
     g = load_golden("mlp_forward")
@@ -141,9 +152,12 @@ def test_mlp_forward_points_golden(mode, tol):
     errs = {name: maxnorm_rel(out[:, sl], g["out"][:, sl]) for name, sl in
             (("albedo", slice(0, 3)), ("sigma", slice(3, 4)), ("sun", slice(4, 5)), ("sky", slice(5, 8)), ("beta", slice(8, 9)))}
     print(mode, errs)
-    assert max(errs.values()) < tol, errs
+    if tol is None:
+        _gate(errs, BF16_POINT_GATES, mode)
+    else:
+        assert max(errs.values()) < tol, errs
     sig = m(g["xyz"].to(DEV), input_sun_dir=g["sun"].to(DEV), input_t=g["t"].to(DEV), sigma_only=True, mlp_mode=mode).cpu()
-    assert maxnorm_rel(sig, g["sigma_only"]) < tol
+    assert maxnorm_rel(sig, g["sigma_only"]) < (BF16_POINT_GATES["sigma"] if tol is None else tol)
 
 
 RENDER_CASES = ["satnerf_coarse", "satnerf_sc", "satnerf_fine", "satnerf_noise", "satnerf_s128", "satnerf_s50_ragged"]
@@ -182,7 +196,7 @@ def test_render_rays_throughput_mode_is_close():
         res = rendering.render_rays(models, args, g["rays"].to(DEV), g["ts"].to(DEV))
     errs = {k: maxnorm_rel(res[k + "_coarse"].cpu(), g["out_" + k + "_coarse"]) for k in ("rgb", "depth", "weights", "beta")}
     print("bf16 mode", errs)
-    assert max(errs.values()) < 2e-2
+    _gate(errs, BF16_RENDER_GATES, "bf16 render_rays")
 
 
 def test_batched_inference_ragged_chunks():
@@ -234,7 +248,7 @@ def test_large_batch_properties_full_size():
         fres = rendering.render_rays(build_models(fast), fast, rays.to(DEV), ts.to(DEV))
     ferrs = {k: maxnorm_rel(fres[k][pick.to(DEV)].cpu(), want[k]) for k in ("rgb_coarse", "depth_coarse", "weights_coarse")}
     print("bf16   @1024x64", {k: f"{e:.1e}" for k, e in ferrs.items()})
-    assert max(ferrs.values()) < 2e-2, ferrs
+    _gate(ferrs, BF16_RENDER_GATES, "bf16 @1024x64")
 
 
 def test_width_512_golden_through_the_layer_path():
@@ -342,7 +356,7 @@ def _oracle_vs_hip(args, n_rays, seed, tol, sample=None, check=("rgb", "depth", 
 def test_tau16_two_aux_ksteps():
     """class-default t_embedding_dims=16 (models/satnerf.py:82) needs two aux k-steps in the weight stream."""
     _oracle_vs_hip(O.default_args(t_embbeding_tau=16, mlp_mode="bf16x3"), 77, 31, 1e-4)
-    _oracle_vs_hip(O.default_args(t_embbeding_tau=16, mlp_mode="bf16"), 77, 31, 2e-2)
+    _oracle_vs_hip(O.default_args(t_embbeding_tau=16, mlp_mode="bf16"), 77, 31, 5e-3)
 
 
 def test_config3_4096_rays_with_importance_sampling():
@@ -499,7 +513,7 @@ def test_one_launch_render_is_bit_identical_to_the_three_launches(mode, feat, s,
 def test_f16_mode_matches_reference_goldens_eight_times_closer_than_bf16(name):
     """mlp_mode='f16': the single-pass kernel with fp16 instead of bf16 MFMA operands (11 instead of 8 significand bits on the
     weights and the activations, same MFMA rate, fp32 accumulation, fp32 first layer).  Against the reference's own outputs:
-    rgb / depth / weights within 4e-4 (measured ~1.5e-4; the bf16 mode: ~1.1e-3), every result within 1e-3."""
+    rgb / depth / weights within 3e-4 (measured <= 1.6e-4; the bf16 mode: ~1.1e-3), every result within 6e-4 (measured <= 3.6e-4)."""
     _, rendering, _ = _lazy()
     g = load_golden(name)
     args = golden_cfg(g)
@@ -513,8 +527,8 @@ def test_f16_mode_matches_reference_goldens_eight_times_closer_than_bf16(name):
     errs = {k: maxnorm_rel(res[k].cpu(), v) for k, v in expected.items()}
     print(name, "f16", {k: f"{e:.1e}" for k, e in errs.items()})
     typ = "fine" if args.n_importance > 0 else "coarse"
-    assert max(errs[f"{k}_{typ}"] for k in ("rgb", "depth", "weights")) < 4e-4, errs
-    assert max(errs.values()) < 1e-3, errs
+    assert max(errs[f"{k}_{typ}"] for k in ("rgb", "depth", "weights")) < 3e-4, errs
+    assert max(errs.values()) < 6e-4, errs
 
 
 def test_bank_walking_renderer_renders_chunk_after_chunk():
@@ -716,15 +730,15 @@ def test_width_512_fused_forward_kernel():
     assert set(res) == set(expected)
     errs = {k: maxnorm_rel(res[k].cpu(), v) for k, v in expected.items()}
     print("feat 512 fused bf16", {k: f"{e:.1e}" for k, e in errs.items()})
-    assert max(errs[k] for k in ("rgb_coarse", "depth_coarse", "weights_coarse")) < 2e-2, errs
-    assert max(errs.values()) < 5e-2, errs
+    assert max(errs[k] for k in ("rgb_coarse", "depth_coarse", "weights_coarse")) < 3e-3, errs  # measured 6.6e-4 / 3.9e-4 / 1.0e-3
+    assert max(errs.values()) < 5e-3, errs                                                       # beta 2.4e-3, albedo 2.0e-3
     # the fp16-operand build of the same kernel: an order of magnitude closer
     args.mlp_mode = "f16"
     with torch.no_grad(), rendering.replay_rng(draws):
         res16 = rendering.render_rays(models, args, g["rays"].to(DEV), g["ts"].to(DEV))
     errs16 = {k: maxnorm_rel(res16[k].cpu(), v) for k, v in expected.items()}
     print("feat 512 fused f16", {k: f"{e:.1e}" for k, e in errs16.items()})
-    assert max(errs16[k] for k in ("rgb_coarse", "depth_coarse", "weights_coarse")) < 5e-4 and max(errs16.values()) < 1.5e-3, errs16
+    assert max(errs16[k] for k in ("rgb_coarse", "depth_coarse", "weights_coarse")) < 3e-4 and max(errs16.values()) < 6e-4, errs16
     args.mlp_mode = "bf16"
     # per-point outputs through the reference-signature forward: fused bf16 vs the layer path (3-pass) on random points
     x, sun, t = torch.rand(777, 3, device=DEV) * 2 - 1, torch.nn.functional.normalize(torch.randn(777, 3, device=DEV), dim=1), torch.rand(777, 16, device=DEV)

@@ -412,3 +412,38 @@ def test_f16_forward_trains_kernel_direct():
     assert tr16.direct
     losses = [tr16.step(rays.to(DEV), ts.to(DEV), target.to(DEV)).item() for _ in range(12)]
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("mode,fmt", [("bf16", 8), ("bf16", 16), ("bf16x3", 16)])
+def test_workspaces_hold_the_tail_waves_tiles(monkeypatch, mode, fmt):
+    """The forward and dX kernels run whole workgroups (8 or 4 waves = tiles): with 1001 rays x 64 samples = 2,002 tiles the last
+    workgroup's waves past the last point still store their tile.  The workspaces are sized by sr_workspace_tiles (a multiple of 8), so
+    nothing is written behind them: canaries right after both workspaces stay intact over a training step."""
+    from satnerf_amd import _lib, ops
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    assert _lib.lib().sr_workspace_tiles(1001 * 64) == 2008 and _lib.lib().sr_workspace_tiles(32) == 8
+    canaries = []
+    real_empty = ops._ws_empty
+
+    def guarded(n, dtype, device, slot):
+        if slot not in (1, 2):
+            return real_empty(n, dtype, device, slot)
+        buf = torch.empty(n + 4096, dtype=dtype, device=device)
+        buf[n:] = 0x5A5A if dtype == torch.int16 else 0
+        canaries.append(buf[n:])
+        return buf[:n]
+
+    monkeypatch.setattr(ops, "_ws_empty", guarded)
+    torch.manual_seed(0)
+    args = O.default_args(mlp_mode=mode, bwd_fmt=fmt)
+    models = {"coarse": load_model(args).to(DEV), "t": torch.nn.Embedding(30, 4).to(DEV)}
+    rays, ts = O.synthetic_rays(1001, seed=3)
+    tr = Trainer(models, args, use_graph=False)
+    tr.step(rays.to(DEV), ts.to(DEV), torch.rand(1001, 3, device=DEV))
+    torch.cuda.synchronize()
+    assert len(canaries) >= 2
+    for c in canaries:
+        assert bool((c == 0x5A5A).all()), "a kernel wrote behind its workspace"
+    assert torch.isfinite(tr.state.params).all()
