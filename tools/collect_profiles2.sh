@@ -2,12 +2,12 @@
 # Run on the GPU box (via gpurun): regenerates the round's profile artefacts under gpurun_out/profiles_${TAG}/.
 # Counters are collected in their own passes with --kernel-trace only (never combined with other trace domains).
 set -u
-TAG=${1:-r03}; root=$(pwd); out=$root/gpurun_out/profiles_${TAG}; mkdir -p $out
+TAG=${1:-r04}; root=$(pwd); out=$root/gpurun_out/profiles_${TAG}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 B="python $root/bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -d $out/train_stats -o t --output-format csv -- $B > $out/train_stats.log 2>&1
 rocprofv3 --kernel-trace --stats -d $out/fwd_stats -o t --output-format csv -- $B --phase forward > $out/fwd_stats.log 2>&1
-for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU"; do
+for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16" "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU"; do
   tag=$(echo $c | tr ' ' '_' | cut -c1-24)
   rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$tag -o p --output-format csv -- $B > $out/pmc_$tag.log 2>&1
 done
@@ -22,7 +22,7 @@ fi
 TAG=$TAG python - <<'PY'
 import csv, glob, collections
 import os
-out = "gpurun_out/profiles_" + os.environ.get("TAG", "r03")
+out = "gpurun_out/profiles_" + os.environ.get("TAG", "r04")
 acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
