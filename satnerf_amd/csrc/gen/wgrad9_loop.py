@@ -28,9 +28,13 @@ registers rotate with period 4, so every address is static:
     iteration i:  L(i+5)  global loads of tile i + 5 -> staging set (i + 5) % 4  (three tiles of lead)
                   M(i)    36 MFMAs (2 k-steps x (4 x 4 + 2 aux tiles)), operands read transposed from LDS slot i % 4; the operands of
                           k-step 1 and of the next tile's k-step 0 are read one k-step ahead, one operand per MFMA gap
-                  rendezvous (s_barrier) early in the iteration: it publishes tile i + 1 (written during iteration i - 1, long
-                          retired) before its first read and orders this iteration's writes behind every wave's reads of iteration i - 2
+                  PUBLISH tile i + 1 (decoded during iteration i - 1; its writes are waited for a few MFMAs into this iteration, when
+                          they have long retired): one ds_add on its slot's counter
                   D(i+2)  decode of the wave's four double fragments + one raw bf16 fragment of tile i + 2 -> LDS slot (i + 2) % 4
+                  CONSUME before the prefetch of tile i + 1: its slot's counter must show all four waves' publishes (read early, checked
+                          by scalar compare; polled on the rare miss).  No s_barrier in the loop: a barrier per tile cost 250 of 2,000
+                          cycles in arrival skew.  Four slots and a decode distance of two make the publish order also the
+                          write-after-read order (see consume_check)
 LDS operations return in order and are waited for by count.
 
 What a wave loads is a table of five "duties" built on the host (packing.wgrad9_duties): two row double fragments (MX8, from dpre), two
@@ -64,10 +68,12 @@ RD = {"AL": 216, "AH": 220, "B": 224, "X": 228}   # + 2 * ks + (slot >> 1): one 
 WB, WBX = 232, 236
 VOFF_D, VOFF_A, VOFF_X = 237, 238, 239
 IN_RD0, IN_RD1, IN_LANE16, IN_VD, IN_VA, IN_VX = 240, 241, 242, 243, 244, 245
-WADDR = 246
-N_VGPR = 247
+WADDR, VFLAG, VONE, VSEEN = 246, 247, 248, 249   # VFLAG: LDS address of the four per-slot publish counters; VSEEN: a counter read back
+N_VGPR = 250
+FLAGS_OFF = NSLOT * SLOT                           # the counters live right behind the four slots (zeroed by wgrad9.hip)
 XACC = (0, 16)
 S_ADV, S_T0, S_T1, S_T2, S_T3, S_SEL01, S_SEL23 = "s90", "s91", "s92", "s93", "s94", "s95", "s96"    # scratch scalars (clobbers)
+S_EXP, S_SEEN = "s97", "s98"                       # publishes a complete tile of this trip's slots has seen (4 per tile); a counter read back
 SEL01, SEL23 = "0x04010400", "0x04030402"   # v_perm_b32 selectors: bytes (b0, K, b1, K) / (b2, K, b3, K)
 
 
@@ -223,19 +229,60 @@ class Stream:
         it += self.rawcopy_items(sset, slot)
         return it
 
-    def rendezvous(self):
-        """every LDS write this wave has issued so far has retired (they date from the previous iteration), then s_barrier"""
-        w = [t for t in self.lgkm if t[0] == "w"]
-        if w:
-            self.wait_for(w[-1])
-        self.e("s_barrier", "salu")
+    def publish(self, slot):
+        """this wave's fragments of a tile are in LDS slot `slot` (their writes have been waited for): bump the slot's publish counter"""
+        # (an LDS atomic is a per-lane operation: one lane adds, or the counter would move by 64)
+        if "lane64" in self.ablate:   # debugging aid: every lane adds (the counter moves by 64 per wave), EXEC untouched
+            self.lds(("flag", "add"), f"ds_add_u32 v{VFLAG}, v{VONE} offset:{4 * slot}")
+            return
+        self.e("s_mov_b64 exec, 1", "salu")
+        self.lds(("flag", "add"), f"ds_add_u32 v{VFLAG}, v{VONE} offset:{4 * slot}")
+        self.e("s_mov_b64 exec, -1", "salu")
+
+    def consume_fetch(self, slot):
+        self.lds(("flag", "rd"), f"ds_read_b32 v{VSEEN}, v{VFLAG} offset:{4 * slot}")
+
+    def consume_check(self, slot, extra):
+        """all four waves have published the tile in `slot` (counter >= S_EXP + extra) before anyone reads it.  With four slots and a
+        decode distance of two this also orders the writes of iteration i behind every wave's reads of iteration i - 2: a wave publishes
+        tile i only after its own reads of tile i - 2 (same slot as tile i + 2) have returned.  The counter was read a few MFMAs ago;
+        the slow path re-reads it until the last wave has arrived (rare: the tile was written a whole iteration ago)."""
+        if "nobar" in self.ablate and self.in_loop:
+            self.wait_for(("flag", "rd"))
+            return
+        self.wait_for(("flag", "rd"))
+        lbl = self.next_label = getattr(self, "next_label", 10) + 1
+        self.e(f"v_readfirstlane_b32 {S_SEEN}, v{VSEEN}", "salu")
+        self.e(f"s_sub_u32 {S_SEEN}, {S_SEEN}, {S_EXP}", "salu")
+        if "lane64" in self.ablate:
+            extra *= 64
+        self.e(f"s_cmp_ge_i32 {S_SEEN}, {extra}", "salu")
+        self.e(f"s_cbranch_scc1 {lbl}f", "salu")
+        # slow path: drain (so that the bookkeeping below stays a lower bound of what has returned), poll
+        self.e(f"{lbl + 100}:", "label")
+        self.e(f"ds_read_b32 v{VSEEN}, v{VFLAG} offset:{4 * slot}", "lds")
+        self.e("s_waitcnt lgkmcnt(0)", "wait")
+        self.e(f"v_readfirstlane_b32 {S_SEEN}, v{VSEEN}", "salu")
+        self.e(f"s_sub_u32 {S_SEEN}, {S_SEEN}, {S_EXP}", "salu")
+        self.e(f"s_cmp_ge_i32 {S_SEEN}, {extra}", "salu")
+        self.e(f"s_cbranch_scc0 {lbl + 100}b", "salu")
+        self.e(f"{lbl}:", "label")
+        if "bar" in self.ablate:   # debugging aid: a real barrier on top of the counters
+            self.e("s_barrier", "salu")
 
     # ---- the statement -------------------------------------------------------------------------------------------------------
     def body(self, s):
         """one tile: L(i + 5), M(i) on slot s, rendezvous, D(i + 2), K0(i + 1)"""
         # the prefetched k-step-0 operands are now the current tile's
         self.lgkm = [("cur",) + t[1:] if t[0] == "nxt" else t for t in self.lgkm]
-        fillers = self.load_items((s + 1) % 4) + [self.rendezvous] + self.decode_tile((s + 2) % 4, (s + 2) % 4)
+        nslot = (s + 1) % 4
+        def publish_prev():   # the previous iteration's decode (tile i + 1): its writes are older than anything issued since, long retired
+            w = [t for t in self.lgkm if t[0] == "w"]
+            if w:
+                self.wait_for(w[-1])
+            self.publish(nslot)
+
+        fillers = self.load_items((s + 1) % 4) + [publish_prev] + self.decode_tile((s + 2) % 4, (s + 2) % 4)
         order = [(a, c) for c in range(4) for a in range(4)]
         per_gap = -(-len(fillers) // 34)
         fi = 0
@@ -252,11 +299,15 @@ class Stream:
             for idx in range(18):
                 if idx == 0:   # every operand of this k-step has landed (they were read one k-step ago): one wait instead of one per MFMA
                     self.wait_for(("cur", ks, "X", 1))
+                    if ks == 1:  # the next tile is complete (all four waves) before its first operand is prefetched; tile i + 1 of the
+                        self.consume_check(nslot, 4 if s < 3 else 8)  # fourth body belongs to the next trip
                 if idx < 16:
                     if self.main:
                         self.mfma(ks, *order[idx])
                 else:
                     self.mfma_aux(ks, idx - 16)
+                if ks == 0 and idx == 12:   # the other waves published tile i + 1 some ten MFMAs ago: read its counter now, compare at the k-step's end
+                    self.consume_fetch(nslot)
                 if rq and idx < 9:     # one operand (two reads) of the next k-step per gap, all nine under way by gap 8
                     name = rq.pop(0)
                     if ks == 0:
@@ -280,6 +331,9 @@ class Stream:
         e(f"v_mov_b32 v{K44}, 0x44444444")
         e(f"v_mov_b32 v{SX}, %[sraw]")
         e(f"v_mov_b32 v{SX + 1}, %[sraw]")
+        e(f"v_mov_b32 v{VONE}, 1")
+        e(f"v_mov_b32 v{VFLAG}, %[flags]")
+        e(f"s_mov_b32 {S_EXP}, 0", "salu")
         e(f"s_mov_b32 {S_SEL01}, {SEL01}", "salu")
         e(f"s_mov_b32 {S_SEL23}, {SEL23}", "salu")
         for ks in range(2):
@@ -306,11 +360,14 @@ class Stream:
                 f()
         for f in self.decode_tile(0, 0):
             f()
+        e("s_waitcnt lgkmcnt(0)", "wait")
+        self.lgkm = []
+        self.publish(0)
         for f in self.load_items(0):
             f()
         for f in self.decode_tile(1, 1):
             f()
-        e("s_waitcnt lgkmcnt(0)", "wait")
+        e("s_waitcnt lgkmcnt(0)", "wait")   # (tile 1 is published by the first iteration, as every iteration publishes its predecessor's decode)
         self.lgkm = []
         e("s_barrier", "salu")
         for name in (OPS if self.main else ("A0", "A1", "X")):
@@ -329,6 +386,7 @@ class Stream:
             e("s_sub_u32 %[nt], %[nt], 1", "salu")
             e("s_cmp_eq_u32 %[nt], 0", "salu")
             e("s_cbranch_scc1 9f", "salu")
+        e(f"s_add_u32 {S_EXP}, {S_EXP}, {256 if 'lane64' in self.ablate else 4}", "salu")
         e("s_branch 1b", "salu")
         self.in_loop = False
         e("9:", "label")
@@ -345,7 +403,7 @@ class Stream:
 def clobber_file():
     regs = [f'"v{r}"' for r in range(32, N_VGPR) if not IN_RD0 <= r <= IN_VX]
     return ("// GENERATED by csrc/gen/wgrad9_loop.py: clobber list of the slice-loop statement (accumulators are outputs, v240..v245 inputs)\n"
-            + ", ".join(regs) + f', "{S_ADV}", "{S_T0}", "{S_T1}", "{S_T2}", "{S_T3}", "{S_SEL01}", "{S_SEL23}", "memory", "scc"\n')
+            + ", ".join(regs) + f', "{S_ADV}", "{S_T0}", "{S_T1}", "{S_T2}", "{S_T3}", "{S_SEL01}", "{S_SEL23}", "{S_EXP}", "{S_SEEN}", "memory", "scc"\n')
 
 
 def main():

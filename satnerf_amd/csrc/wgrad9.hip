@@ -13,8 +13,8 @@
 //     slice's largest flush to zero), MX8 columns (feats) likewise with their own Emax, and the fp32 accumulators are unscaled when
 //     the partial block is written.
 //   * The whole slice loop is one generated, hand-placed asm statement (csrc/gen/wgrad9_loop.py -> wgrad9_loop_{p,m}.inc): 36 MFMAs per
-//     tile, the decode of tile i + 2, the global loads of tile i + 5 and the operand reads of the next k-step in their gaps, one
-//     s_barrier per tile, LDS ring of four fp16 slots.
+//     tile, the decode of tile i + 2, the global loads of tile i + 5 and the operand reads of the next k-step in their gaps; LDS ring
+//     of four fp16 slots, waves synchronise through per-slot publish counters in the LDS (no s_barrier in the loop).
 //
 // What each wave fetches is the "duty" table built on the host (packing.wgrad9_duties): ints 20.. of a block's row of the load table.
 #include <stdlib.h>
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
       const uint32_t a = mh[0] > mh[1] ? mh[0] : mh[1], b = ml[0] > ml[1] ? ml[0] : ml[1];
       return (a > b ? a : b) >> 8;
     };
-    constexpr int kPass = 28;  // tiles of a wave per pass: all of a 112-tile slice (65,536 points over 18 slices)
+    constexpr int kPass = 32;  // tiles of a wave per pass: one pass covers a slice of up to 128 tiles (65,536 points over 18 slices: 114)
     // loads of one entry: wave-uniform tile base (scalar arithmetic) + the lane's 16 bytes; clamped, not predicated
     auto fetch = [&](const char* ws, uint32_t unit, uint32_t stride, uint32_t jb, uint4 (&w)[kPass]) {
 #pragma unroll
@@ -210,16 +210,22 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
       er = er > red[2 * w] ? er : red[2 * w], ec = ec > red[2 * w + 1] ? ec : red[2 * w + 1];
     }
     er = (uint32_t)__builtin_amdgcn_readfirstlane((int)er), ec = (uint32_t)__builtin_amdgcn_readfirstlane((int)ec);
+    if (tid < kSlots9) reinterpret_cast<uint32_t*>(lds + kSlots9 * kSlot9)[tid] = 0u;  // the slots' publish counters (gen/wgrad9_loop.py)
     __syncthreads();  // the reduction scratch is the first LDS slot
     er = er < 32u ? 32u : er > 254u ? 254u : er;  // (gradients below 2^-94 are zero for every purpose; keeps the scales normal floats)
     ec = ec < 32u ? 32u : ec > 254u ? 254u : ec;
   }
-  // rows: value * G, G = 2^(138 - er); the stream forms the fp16 scale of a lane as exponent field E - erow
-  const uint32_t erow = er - 20u, ecol = ec - 20u;
-  const float g_row = __builtin_bit_cast(float, (265u - er) << 23), g_col = col_mx ? __builtin_bit_cast(float, (265u - ec) << 23) : 1.0f;
-  const float sraw = raw_src == 1 ? g_row : 1.0f;          // the raw fragment is a row of dpre or the (unscaled) aux columns
+  // rows: value * G, G = 2^(138 - er); the stream forms the fp16 scale of a lane as exponent field E - erow.  Everything handed to the
+  // stream as a scalar is made one explicitly: an "s" operand fed a value the compiler holds in a VGPR is silently passed in that VGPR,
+  // which may be one of the statement's output registers (the stream zeroes them first)
+  const uint32_t erow = (uint32_t)__builtin_amdgcn_readfirstlane((int)(er - 20u)), ecol = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ec - 20u));
+  const uint32_t g_row_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)((265u - er) << 23));
+  const uint32_t g_col_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)(col_mx ? (265u - ec) << 23 : 0x3f800000u));
+  const float g_row = __builtin_bit_cast(float, g_row_bits), g_col = __builtin_bit_cast(float, g_col_bits);
+  const uint32_t sraw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(raw_src == 1 ? g_row_bits : 0x3f800000u));  // the raw fragment: a dpre row (x G) or the aux columns (x 1)
   const float un_row = 1.0f / g_row, un_col = 1.0f / g_col;  // (powers of two: exact)
 
+  const uint32_t flags = ring + (uint32_t)(kSlots9 * kSlot9);
   f32x32w c0, c1, c2, c3, c4, c5, c6, c7, cx;
 #ifdef SR_W9_TIMING
   const uint32_t nt_in = nt;
@@ -232,14 +238,14 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
 #define SR_W9_MX_INC "wgrad9_loop_mx.inc"
 #endif
 #define SR_W9_OUTS                                                                                                                    \
-  "={a[0:31]}"(c0), "={a[32:63]}"(c1), "={a[64:95]}"(c2), "={a[96:127]}"(c3), "={a[128:159]}"(c4), "={a[160:191]}"(c5),              \
-      "={a[192:223]}"(c6), "={a[224:255]}"(c7), "={v[0:31]}"(cx), [nt] "+s"(nt)
+  "=&{a[0:31]}"(c0), "=&{a[32:63]}"(c1), "=&{a[64:95]}"(c2), "=&{a[96:127]}"(c3), "=&{a[128:159]}"(c4), "=&{a[160:191]}"(c5),        \
+      "=&{a[192:223]}"(c6), "=&{a[224:255]}"(c7), "=&{v[0:31]}"(cx), [nt] "+s"(nt)
 #define SR_W9_INS                                                                                                                     \
   "{v240}"(rdo[0]), "{v241}"(rdo[1]), "{v242}"(lane16), "{v243}"(vd), "{v244}"(va), "{v245}"(vx), [b0] "s"(base[0]), [b1] "s"(base[1]), \
       [b2] "s"(base[2]), [b3] "s"(base[3]), [bx] "s"(base[4]), [sb0] "s"(sbase[0]), [sb1] "s"(sbase[1]), [sb2] "s"(sbase[2]),        \
       [sb3] "s"(sbase[3]), [w0] "s"(wb[0]), [w1] "s"(wb[1]), [w2] "s"(wb[2]), [w3] "s"(wb[3]), [wx] "s"(wb[4]), [aofl] "s"(aofl),    \
       [aofh] "s"(aofh), [bof] "s"(bof), [strd] "s"(strd), [stra] "s"(stra), [strx] "s"(strx), [tleft] "s"(tleft), [erow] "s"(erow),   \
-      [ecol] "s"(ecol), [sraw] "s"(sraw)
+      [ecol] "s"(ecol), [sraw] "s"(sraw), [flags] "s"(flags)
   // a wave whose 128 x 128 quadrant nobody reads (narrow blocks: packing.wgrad9_duties' quadrant mask) runs the stream without the 32
   // main MFMAs and their operand reads: same loads, decode, rendezvous, aux tiles -- the time of a tile is unchanged, its energy is not
   const bool quad_on = (__builtin_amdgcn_readfirstlane(prm.loads[(long)blk * prm.load_ints + kOldInts + 4 * kDuties * kDutyInts + 2 * kScanEntries]) >> wave) & 1;
@@ -338,7 +344,7 @@ int launch_wgrad9(const uint4* dpre, const uint4* acts, const int* blocks, const
   p.n_tiles = n_tiles, p.n_blocks = n_blocks, p.ak = ak, p.dk = dk, p.load_ints = load_ints;
   const char* dbg = getenv("SR_W9_DBG");
   p.dbg = dbg ? (long long*)strtoull(dbg, nullptr, 10) : nullptr;
-  const size_t lds = (size_t)kSlots9 * kSlot9;
+  const size_t lds = (size_t)kSlots9 * kSlot9 + 16;  // four operand slots + their publish counters
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)wgrad9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
