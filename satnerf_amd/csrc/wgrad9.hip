@@ -53,17 +53,42 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
 #endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // which job block owns this slice: one lane per table row, one ballot (a scalar walk of the table costs one memory latency per block)
-  int blk = 0;
-  for (int b0 = 0; b0 < prm.n_blocks; b0 += 64) {
-    const int b = b0 + lane;
-    const bool mine = b < prm.n_blocks && (int)blockIdx.x >= prm.blocks[kWgTableInts * b + kWgFirstSlice] &&
-                      (int)blockIdx.x < prm.blocks[kWgTableInts * b + kWgFirstSlice] + prm.blocks[kWgTableInts * b + kWgSlices];
-    const unsigned long long hit = __ballot(mine);
-    if (hit) { blk = b0 + __builtin_ctzll(hit); break; }
+  // which job block owns this slice.  sr_wgrad_plan hands this kernel equal slices, the remainder to the first blocks: the block index
+  // follows from blockIdx by arithmetic, so the block's table row, this wave's duties, the scan list and the quadrant mask are all
+  // fetched at once (one memory latency instead of three dependent ones); the row confirms the guess -- any other plan falls back to a
+  // search (one lane per table row, one ballot) and fetches again
+  int blk;
+  int d[kWgTableInts], du[kDuties * kDutyInts], scan[2 * kScanEntries + 1], raw0[kDutyInts];
+  auto fetch_tables = [&](int b) {
+    const int* row = prm.blocks + kWgTableInts * b;
+    const int* lt = prm.loads + (long)b * prm.load_ints + kOldInts;
+#pragma unroll
+    for (int i = 0; i < kWgTableInts; ++i) d[i] = row[i];
+#pragma unroll
+    for (int i = 0; i < kDuties * kDutyInts; ++i) du[i] = lt[wave * kDuties * kDutyInts + i];
+#pragma unroll
+    for (int i = 0; i < kDutyInts; ++i) raw0[i] = lt[4 * kDutyInts + i];  // wave 0's raw duty (a bf16 row fragment, if the block has one)
+#pragma unroll
+    for (int i = 0; i < 2 * kScanEntries + 1; ++i) scan[i] = lt[4 * kDuties * kDutyInts + i];
+  };
+  {
+    const int q = (int)gridDim.x / prm.n_blocks, r = (int)gridDim.x % prm.n_blocks, idx = (int)blockIdx.x;
+    blk = q == 0 ? 0 : idx < r * (q + 1) ? idx / (q + 1) : r + (idx - r * (q + 1)) / q;
+    blk = blk < prm.n_blocks ? blk : prm.n_blocks - 1;
+    fetch_tables(blk);
+    if (idx < d[kWgFirstSlice] || idx >= d[kWgFirstSlice] + d[kWgSlices]) {
+      blk = 0;
+      for (int b0 = 0; b0 < prm.n_blocks; b0 += 64) {
+        const int b = b0 + lane;
+        const bool mine = b < prm.n_blocks && idx >= prm.blocks[kWgTableInts * b + kWgFirstSlice] &&
+                          idx < prm.blocks[kWgTableInts * b + kWgFirstSlice] + prm.blocks[kWgTableInts * b + kWgSlices];
+        const unsigned long long hit = __ballot(mine);
+        if (hit) { blk = b0 + __builtin_ctzll(hit); break; }
+      }
+      blk = __builtin_amdgcn_readfirstlane(blk);
+      fetch_tables(blk);
+    }
   }
-  blk = __builtin_amdgcn_readfirstlane(blk);
-  const int* d = prm.blocks + kWgTableInts * blk;
   const int nr = d[1] + d[3], nc = d[5] + d[7];
   const bool col_mx = d[8] == 0;  // packing.KIND_BF16: the identity stage (feats) -> MX8 columns
   const long tiles_per_split = (prm.n_tiles + d[kWgSlices] - 1) / d[kWgSlices];
@@ -75,7 +100,6 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   const long t0 = t_begin < prm.n_tiles ? t_begin : 0;
 
   // ---- this wave's duties -> wave-uniform bases -------------------------------------------------------------------------------
-  const int* duty = prm.loads + (long)blk * prm.load_ints + kOldInts + wave * kDuties * kDutyInts;
   uint64_t base[kDuties], sbase[4];
   uint32_t wb[kDuties];
   bool on[kDuties];  // the duty feeds an operand fragment (not the dump area)
@@ -83,8 +107,8 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   int raw_src = 0;
 #pragma unroll
   for (int k = 0; k < kDuties; ++k) {
-    const int src = __builtin_amdgcn_readfirstlane(duty[kDutyInts * k]), unit = __builtin_amdgcn_readfirstlane(duty[kDutyInts * k + 1]);
-    const int dst = __builtin_amdgcn_readfirstlane(duty[kDutyInts * k + 2]), sc = __builtin_amdgcn_readfirstlane(duty[kDutyInts * k + 3]);
+    const int src = __builtin_amdgcn_readfirstlane(du[kDutyInts * k]), unit = __builtin_amdgcn_readfirstlane(du[kDutyInts * k + 1]);
+    const int dst = __builtin_amdgcn_readfirstlane(du[kDutyInts * k + 2]), sc = __builtin_amdgcn_readfirstlane(du[kDutyInts * k + 3]);
     const char* ws = src == 1 ? prm.dpre : prm.acts;
     base[k] = (uint64_t)(uintptr_t)(ws + (long)unit * 1024);
     if (k < 4) sbase[k] = (uint64_t)(uintptr_t)(ws + (long)(sc >> 4) * 1024 + (sc & 15));
@@ -114,12 +138,14 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
 
   // ---- fp16 range: the largest MX8 exponent / bf16 exponent of the rows (and of MX8 columns) over this workgroup's slice ----------
   // a value is < 2^(E - 126) for an MX8 lane with exponent byte E and for a bf16 with biased exponent E alike
+#ifdef SR_W9_TIMING
+  const uint64_t tk1 = __builtin_amdgcn_s_memrealtime() + (uint64_t)(d[0] & 0);  // (after the tables have arrived)
+#endif
   uint32_t er = 0, ec = 0;
   {
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     // the block's scan list (ints 100.. of its load-table row): where its MX8 exponent bytes live.  Wave w takes the tiles = w (mod 4) of
     // the slice; all of an entry's loads (one 16-byte lane slot per tile) are in flight at once.
-    const int* scan = prm.loads + (long)blk * prm.load_ints + kOldInts + 4 * kDuties * kDutyInts;
     const uint32_t n_mine = nt > (uint32_t)wave ? (nt - (uint32_t)wave + 3u) / 4u : 0u;  // tiles wave, wave + 4, ...
     // byte-wise running maximum without unpacking: a u16 maximum orders by the HIGH byte first, so pk_max(m, x) tracks bytes 1 and 3
     // exactly (in the high bytes of m's halves) and pk_max(m', x << 8) bytes 0 and 2
@@ -179,7 +205,6 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
     }
     // a bf16 row fragment (d_sigma_pre / d_head) is wave 0's raw duty: every wave scans its share of it.  |value| is ordered by the low
     // 15 bits of each half, exponent = bits 14:7
-    const int* raw0 = prm.loads + (long)blk * prm.load_ints + kOldInts + 4 * kDutyInts;
     const int r_src = __builtin_amdgcn_readfirstlane(raw0[0]), r_unit = __builtin_amdgcn_readfirstlane(raw0[1]);
     if (r_src == 1 && __builtin_amdgcn_readfirstlane(raw0[2]) != kDumpFrag && n_mine > 0) {
       u16x2 m = {0, 0};
@@ -248,7 +273,7 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
       [ecol] "s"(ecol), [sraw] "s"(sraw), [flags] "s"(flags)
   // a wave whose 128 x 128 quadrant nobody reads (narrow blocks: packing.wgrad9_duties' quadrant mask) runs the stream without the 32
   // main MFMAs and their operand reads: same loads, decode, rendezvous, aux tiles -- the time of a tile is unchanged, its energy is not
-  const bool quad_on = (__builtin_amdgcn_readfirstlane(prm.loads[(long)blk * prm.load_ints + kOldInts + 4 * kDuties * kDutyInts + 2 * kScanEntries]) >> wave) & 1;
+  const bool quad_on = (__builtin_amdgcn_readfirstlane(scan[2 * kScanEntries]) >> wave) & 1;
   if (col_mx && quad_on) {
     asm volatile(
 #include SR_W9_M_INC
@@ -291,6 +316,7 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
     prm.dbg[3 * blockIdx.x + 1] = (long long)(tr1 - tr0);
     prm.dbg[3 * blockIdx.x + 2] = nt_in;
     prm.dbg[3 * 1024 + 4 * blockIdx.x] = (long long)tk0, prm.dbg[3 * 1024 + 4 * blockIdx.x + 1] = (long long)tr0;
+    prm.dbg[7 * 1024 + blockIdx.x] = (long long)tk1;
     prm.dbg[3 * 1024 + 4 * blockIdx.x + 2] = (long long)tr1;
   }
 #endif

@@ -18,7 +18,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 rays, ts = data.synthetic_rays(n); rays, ts = rays.to(dev), ts.to(dev); tgt = torch.rand(n, 3, device=dev)
 dbg9 = None
 if os.environ.get("AB_TIMING9"):  # wgrad9.hip built with -DSR_W9_TIMING: per workgroup (shader cycles, 100-MHz ticks, tiles)
-    dbg9 = torch.zeros(7 * 1024, dtype=torch.int64, device=dev)
+    dbg9 = torch.zeros(8 * 1024, dtype=torch.int64, device=dev)
     os.environ["SR_W9_DBG"] = str(dbg9.data_ptr())
 for _ in range(10): tr.step(rays, ts, tgt)
 timer = ops.KernelTimer(); ops.kernel_timer = timer
@@ -27,7 +27,13 @@ torch.cuda.synchronize()
 print(os.path.basename(os.environ.get("SATRENDER_LIB", "default")), {k: round(timer.mean_ms(k) * 1e3, 1) for k in ("mlp_fwd", "mlp_bwd", "wgrad")})
 
 if dbg9 is not None:
-    st = dbg9.cpu()[3 * 1024:].view(-1, 4).double(); st = st[st[:, 0] > 0]
+    st = dbg9.cpu()[3 * 1024:7 * 1024].view(-1, 4).double()
+    t1 = dbg9.cpu()[7 * 1024:].double()[:st.shape[0]]
+    keep = st[:, 0] > 0
+    if keep.any():
+        k0_ = st[keep, 0].min()
+        print(f"  tables fetched {float((t1[keep] - k0_).median()) / 100:.1f} us (max {float((t1[keep] - k0_).max()) / 100:.1f})")
+    st = st[keep]
     if st.shape[0]:
         k0 = st[:, 0].min()
         f = lambda c: f"{float((st[:, c] - k0).median()) / 100:.1f} (max {float((st[:, c] - k0).max()) / 100:.1f})"

@@ -21,7 +21,7 @@ if os.environ.get("AB_TIMING"):  # kernel built with -DSR_W8_TIMING: per-wave s_
     os.environ["SR_W8_DBG"] = str(dbg.data_ptr())
 dbg9 = None
 if os.environ.get("AB_TIMING9"):  # wgrad9.hip built with -DSR_W9_TIMING: per workgroup (shader cycles, 100-MHz ticks, tiles)
-    dbg9 = torch.zeros(3 * 1024, dtype=torch.int64, device=dev)
+    dbg9 = torch.zeros(8 * 1024, dtype=torch.int64, device=dev)
     os.environ["SR_W9_DBG"] = str(dbg9.data_ptr())
 def make(n_wg):
     plan, n_slices = ops.wgrad_plan(blocks, n_points, n_wg)
@@ -58,7 +58,7 @@ if dbg is not None:
 
 if dbg9 is not None:
     torch.cuda.synchronize()
-    d = dbg9.cpu().view(-1, 3)[:n_slices].double()
+    d = dbg9.cpu()[:3 * 1024].view(-1, 3)[:n_slices].double()
     cyc, ticks, nt = d[:, 0], d[:, 1], d[:, 2]
     print(f"  wgrad9 stamps over {n_slices} workgroups: cycles/tile median {float((cyc / nt).median()):.0f} (min {float((cyc / nt).min()):.0f}, max {float((cyc / nt).max()):.0f}), "
           f"tiles {int(nt.min())}..{int(nt.max())}, slice loop {float(ticks.median()) / 100:.1f} us median / {float(ticks.max()) / 100:.1f} us max, "
