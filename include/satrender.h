@@ -181,8 +181,8 @@ int sr_render_points_per_block(int feat, int mode);
  * sr_wgrad_plan (host, no GPU work): fills n_slices / first_slice of a HOST copy of the table for n_points points and at
  * most n_wg workgroups (n_wg <= 0: the current device's CU count); *n_slices = total slices.  `fmt` = the workspace format of
  * the kernel that will run the plan: SR_FMT16 cuts every block into the same number of slices (that kernel's time per tile
- * does not depend on the block), SR_FMT8 hands the workgroups out by a per-block cost (its decode work grows with the
- * fragments a block moves), minimising the slowest workgroup's cost x tiles. */
+ * does not depend on the block), SR_FMT8 hands the workgroups out by a per-block cost x tiles (equal costs for the default 4-wave
+ * kernel; SATNERF_WGRAD_V1=1: the r02 kernel's decode work grows with the fragments a block moves). */
 int sr_satnerf_mlp_bwd(int feat, int tau, int64_t n_points, const uint16_t* bwd_stream, const uint16_t* acts,
                        const float* albedo, const float* sigma, const float* sun_v, const float* beta, const float* g_albedo,
                        const float* g_sigma, const float* g_sun_v, const float* g_beta, uint16_t* dpre, float* d_t, int fmt,
@@ -190,9 +190,14 @@ int sr_satnerf_mlp_bwd(int feat, int tau, int64_t n_points, const uint16_t* bwd_
 int sr_wgrad_plan(int32_t* blocks, int n_blocks, int64_t n_points, int n_wg, int fmt, int* n_slices);
 int sr_satnerf_wgrad(int feat, int tau, int64_t n_points, const uint16_t* dpre, const uint16_t* acts, const int32_t* blocks,
                      int n_blocks, int n_slices, float* partial, void* stream);
-/* the same contraction from SR_FMT8 workspaces: every wave fetches one 1-KiB double fragment per tile and expands it in LDS
- * (PHASE8 -> bf16 sin, MX8 -> bf16 value); `loads` (n_blocks x sr_wgrad8_load_ints() int32, device; packing.wgrad8_loads) says
- * which unit of which workspace each wave of a block fetches and where it goes; `blocks` is the same planned table. */
+/* the same contraction from SR_FMT8 workspaces (autograd's grad_weight / grad_bias of every nn.Linear, models/satnerf.py:104-153).
+ * Default kernel (csrc/wgrad9.hip): 4 waves per job block, each wave decodes its 8-bit double fragments in registers (PHASE8 -> fp16
+ * sine, MX8 -> fp16 value scaled per workgroup) and contracts 128 x 128 register tiles with fp16 MFMAs; SATNERF_WGRAD_V1=1 (and
+ * workspaces of 4 GiB or more) run the r02 kernel, which expands the fragments in the LDS to bf16.  `loads` (n_blocks x
+ * sr_wgrad8_load_ints() int32, device; packing.wgrad8_loads) says which unit of which workspace each wave of a block fetches and where
+ * it goes -- ints 0..19 for the r02 kernel, 20..108 the duty table, exponent scan list and quadrant mask of the default one; `blocks` is
+ * the same planned table.  sr_wgrad_plan hands the default kernel equal slices (it runs one instruction stream for every block) and the
+ * r02 kernel cost-weighted ones. */
 int sr_satnerf_wgrad8(int feat, int tau, int64_t n_points, const uint16_t* dpre, const uint16_t* acts, const int32_t* blocks,
                       const int32_t* loads, int n_blocks, int n_slices, float* partial, void* stream);
 int sr_wgrad8_load_ints(void);
