@@ -269,7 +269,15 @@ extern "C" int sr_wgrad_plan(int32_t* blocks, int n_blocks, int64_t n_points, in
   int first = 0;
   static thread_local int sl[4096];
   const bool weighted = fmt == SR_FMT8 && n_blocks <= n_wg;
-  if (weighted) {
+  if (weighted && !old_kernel) {
+    // equal split, the remainder to the first blocks: what wgrad9.hip's workgroup numbering (slice-major, blocks 8 positions apart on one
+    // XCD) assumes; a block never gets more slices than it has tiles
+    const long q = n_wg / n_blocks, r = n_wg % n_blocks;
+    for (int b = 0; b < n_blocks; ++b) {
+      long v = q + (b < r ? 1 : 0);
+      sl[b] = (int)(v > n_tiles ? n_tiles : v);
+    }
+  } else if (weighted) {
     double cost[4096];
     for (int b = 0; b < n_blocks; ++b) {
       const int32_t* t = blocks + kWgTableInts * b;

@@ -71,12 +71,25 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
 #pragma unroll
     for (int i = 0; i < 2 * kScanEntries + 1; ++i) scan[i] = lt[4 * kDuties * kDutyInts + i];
   };
+  int slice;  // this workgroup's slice of the block: partial block d[kWgFirstSlice] + slice
   {
+    // workgroup i = slice i / n_blocks of block i % n_blocks (the r blocks with one slice more take the last r workgroups): workgroup i
+    // runs on XCD i % 8, so blocks 8 table positions apart -- packing.backward_maps puts blocks that share an operand there -- stream the
+    // same tiles through the same L2 at the same time.  Valid for sr_wgrad_plan's equal split (q or q + 1 slices, the larger first)
     const int q = (int)gridDim.x / prm.n_blocks, r = (int)gridDim.x % prm.n_blocks, idx = (int)blockIdx.x;
-    blk = q == 0 ? 0 : idx < r * (q + 1) ? idx / (q + 1) : r + (idx - r * (q + 1)) / q;
-    blk = blk < prm.n_blocks ? blk : prm.n_blocks - 1;
+    if (q == 0) blk = idx < prm.n_blocks ? idx : prm.n_blocks - 1, slice = 0;
+    else if (idx < q * prm.n_blocks) blk = idx % prm.n_blocks, slice = idx / prm.n_blocks;
+    else blk = idx - q * prm.n_blocks, slice = q;
     fetch_tables(blk);
-    if (idx < d[kWgFirstSlice] || idx >= d[kWgFirstSlice] + d[kWgSlices]) {
+    // the arithmetic numbering is valid only if EVERY block has q (+ 1 for the first r) slices: all workgroups take the same decision from
+    // the whole table (one lane per row, fetched alongside the tables above)
+    bool equal_split = q > 0;
+    for (int b0 = 0; b0 < prm.n_blocks; b0 += 64) {
+      const int b = b0 + lane;
+      const bool bad = b < prm.n_blocks && prm.blocks[kWgTableInts * b + kWgSlices] != q + (b < r ? 1 : 0);
+      if (__ballot(bad)) equal_split = false;
+    }
+    if (!equal_split) {  // some other plan: block-major numbering, found by search
       blk = 0;
       for (int b0 = 0; b0 < prm.n_blocks; b0 += 64) {
         const int b = b0 + lane;
@@ -87,12 +100,13 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
       }
       blk = __builtin_amdgcn_readfirstlane(blk);
       fetch_tables(blk);
+      slice = idx - d[kWgFirstSlice];
     }
   }
   const int nr = d[1] + d[3], nc = d[5] + d[7];
   const bool col_mx = d[8] == 0;  // packing.KIND_BF16: the identity stage (feats) -> MX8 columns
   const long tiles_per_split = (prm.n_tiles + d[kWgSlices] - 1) / d[kWgSlices];
-  const long t_begin = (long)((int)blockIdx.x - d[kWgFirstSlice]) * tiles_per_split;
+  const long t_begin = (long)slice * tiles_per_split;
   long t_end = t_begin + tiles_per_split;
   if (t_end > prm.n_tiles) t_end = prm.n_tiles;
   uint32_t nt = t_end > t_begin ? (uint32_t)(t_end - t_begin) : 0u;
@@ -322,7 +336,7 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
 #endif
 
   // ---- partial block of this slice ------------------------------------------------------------------------------------------------
-  float* out = prm.partial + (long)blockIdx.x * kWgBlockFloats;
+  float* out = prm.partial + (long)(d[kWgFirstSlice] + slice) * kWgBlockFloats;
   const int n_rows = 16 * nr, n_cols = 16 * nc;
   const f32x32w* cc[8] = {&c0, &c1, &c2, &c3, &c4, &c5, &c6, &c7};
 #pragma unroll

@@ -324,31 +324,54 @@ def backward_maps(feat=256, tau=4):
     DP_RGBH = DP_SIGMA + 1
     DP_S1, DP_E1, DP_S2, DP_S3, DP_HEAD = (DP_RGBH + k * HS for k in range(1, 6))
     tab = _Blocks()
+    todo = []  # (row ranges, column ranges, kind, sharing key): added below in an order that puts blocks sharing operands 8 positions apart
     if feat == 256:
         for l in range(1, 8):
-            tab.add([(16 * l, 16)], [(a_frag(l - 1), 16)], KIND_PHASE)
-        tab.add([(DP_FEATS, 16)], [(a_frag(7), 16)], KIND_PHASE)                          # feats_from_xyz
-        tab.add([(DP_SIGMA, 1), (0, 8)], [(a_frag(7), 16)], KIND_PHASE)                   # sigma head + first half of fc_net.0 (aux columns only)
-        tab.add([(DP_RGBH, 16)], [(ACT_FEATS, 16)], KIND_BF16)                            # rgb hidden + sun hidden 1
-        tab.add([(DP_RGBH + 16, 8), (8, 8)], [(ACT_FEATS, 16)], KIND_BF16)                # beta hidden + second half of fc_net.0
-        tab.add([(DP_S2, 8), (DP_S3, 8)], [(ACT_S1, 8), (ACT_S2, 8)], KIND_PHASE)         # sun hidden 2 and 3
-        tab.add([(DP_HEAD, 1)], [(ACT_RGBH, 8), (ACT_S3, 8)], KIND_PHASE)                 # rgb and sun output rows
-        tab.add([(DP_HEAD, 1)], [(ACT_E1, 8)], KIND_PHASE)                                # beta output row
+            todo.append(([(16 * l, 16)], [(a_frag(l - 1), 16)], KIND_PHASE, None))
+        todo.append(([(DP_FEATS, 16)], [(a_frag(7), 16)], KIND_PHASE, "a7"))                          # feats_from_xyz
+        todo.append(([(DP_SIGMA, 1), (0, 8)], [(a_frag(7), 16)], KIND_PHASE, "a7"))                   # sigma head + first half of fc_net.0 (aux columns only)
+        todo.append(([(DP_RGBH, 16)], [(ACT_FEATS, 16)], KIND_BF16, "feats"))                         # rgb hidden + sun hidden 1
+        todo.append(([(DP_RGBH + 16, 8), (8, 8)], [(ACT_FEATS, 16)], KIND_BF16, "feats"))             # beta hidden + second half of fc_net.0
+        todo.append(([(DP_S2, 8), (DP_S3, 8)], [(ACT_S1, 8), (ACT_S2, 8)], KIND_PHASE, None))         # sun hidden 2 and 3
+        todo.append(([(DP_HEAD, 1)], [(ACT_RGBH, 8), (ACT_S3, 8)], KIND_PHASE, None))                 # rgb and sun output rows
+        todo.append(([(DP_HEAD, 1)], [(ACT_E1, 8)], KIND_PHASE, None))                                # beta output row
     else:  # every job cut into blocks of <= 16 row fragments x <= 16 column fragments
-        def tile_job(r0, nr, c0, nc, kind):
+        def tile_job(r0, nr, c0, nc, kind, key=None):
             for rb in range(0, nr, 16):
                 for cb in range(0, max(nc, 1), 16):
-                    tab.add([(r0 + rb, min(16, nr - rb))], [(c0 + cb, min(16, nc - cb))] if nc else [], kind)
+                    todo.append(([(r0 + rb, min(16, nr - rb))], [(c0 + cb, min(16, nc - cb))] if nc else [], kind, key))
         for l in range(1, 8):
-            tile_job(KS * l, KS, a_frag(l - 1), KS, KIND_PHASE)
-        tile_job(DP_FEATS, KS, a_frag(7), KS, KIND_PHASE)      # feats_from_xyz
-        tile_job(DP_SIGMA, 1, a_frag(7), KS, KIND_PHASE)       # sigma head
-        tile_job(0, KS, 0, 0, KIND_PHASE)                      # fc_net.0: aux columns only
-        tile_job(DP_RGBH, 3 * HS, ACT_FEATS, KS, KIND_BF16)    # rgb / sun-1 / beta hidden layers
+            tile_job(KS * l, KS, a_frag(l - 1), KS, KIND_PHASE, f"L{l}")
+        tile_job(DP_FEATS, KS, a_frag(7), KS, KIND_PHASE, "G1")  # feats_from_xyz
+        tile_job(DP_SIGMA, 1, a_frag(7), KS, KIND_PHASE)         # sigma head
+        tile_job(0, KS, 0, 0, KIND_PHASE)                        # fc_net.0: aux columns only
+        tile_job(DP_RGBH, 3 * HS, ACT_FEATS, KS, KIND_BF16)      # rgb / sun-1 / beta hidden layers
         tile_job(DP_S2, HS, ACT_S1, HS, KIND_PHASE)
         tile_job(DP_S3, HS, ACT_S2, HS, KIND_PHASE)
-        for c0 in (ACT_RGBH, ACT_S3, ACT_E1):                  # output rows
+        for c0 in (ACT_RGBH, ACT_S3, ACT_E1):                    # output rows
             tile_job(DP_HEAD, 1, c0, HS, KIND_PHASE)
+    # Table order.  The 4-wave weight-gradient kernel (csrc/wgrad9.hip) maps workgroup i to slice i // n_blocks of block i % n_blocks, and
+    # workgroup i runs on XCD i % 8 (MI355X_MICROARCH.md: observed dispatch order): blocks 8 table positions apart work on the same tiles on
+    # the same XCD at the same time, so an operand both of them read (a7: feats_from_xyz and the sigma head; feats: the three hidden heads;
+    # at width 512 the four 256 x 256 blocks of a layer share rows and columns pairwise) comes from HBM once and from that XCD's L2 after.
+    # Members of a sharing group therefore go to positions p, p + 8, p + 16, ...; everything else fills the gaps in its old order.
+    groups = {}
+    for i, t in enumerate(todo):
+        if t[3] is not None:
+            groups.setdefault(t[3], []).append(i)
+    order = [None] * len(todo)
+    free = lambda p: p < len(order) and order[p] is None  # noqa: E731
+    for members in groups.values():
+        p = next((p for p in range(len(order)) if all(free(p + 8 * j) for j in range(len(members)))), None)
+        if p is None:
+            continue  # (no aligned run left: these blocks keep whatever position remains)
+        for j, i in enumerate(members):
+            order[p + 8 * j] = i
+    rest = iter(i for i in range(len(todo)) if i not in order)
+    order = [i if i is not None else next(rest) for i in order]
+    assert sorted(order) == list(range(len(todo)))
+    for i in order:
+        tab.add(*todo[i][:3])
     jobs = {"L0": _Job(tab, 0, [])}
     for l in range(1, 8):
         jobs[f"L{l}"] = _Job(tab, KS * l, [a_frag(l - 1)])
