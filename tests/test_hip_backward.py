@@ -181,13 +181,21 @@ def test_direct_step_matches_autograd_path_and_graph_replay():
     assert maxnorm_rel(trg.state.params.cpu(), tre.state.params.cpu()) < 5e-2
 
 
-@pytest.mark.parametrize("tau,n_samples", [(16, 64), (4, 128), (4, 50)])
-def test_gradients_vs_oracle_autograd_variants(tau, n_samples):
+@pytest.mark.parametrize("tau,n_samples,mode,n_rays", [(16, 64, "bf16x3", 48), (4, 128, "bf16x3", 48), (4, 50, "bf16x3", 48),
+                                                       # the 8-bit state = the 4-wave weight-gradient kernel (csrc/wgrad9.hip): two aux fragments
+                                                       # (tau 16: raw duties on two waves), a ragged point count (37 x 50 = 1,850 points:
+                                                       # 58 tiles, the last one partial, most slices one tile or none), one ray
+                                                       # -- on these tiny batches the 8-BIT STATE itself moves the small sun-visibility
+                                                       # gradients by 4e-2 .. 1.2e-1 (the r02 kernel, SATNERF_WGRAD_V1=1, measures the same
+                                                       # 5.4e-2 / 4.3e-2 / 1.2e-1): the gate is 1.5x that, what is tested is the kernel's
+                                                       # handling of the shapes
+                                                       (16, 64, "bf16", 48), (4, 50, "bf16", 37), (16, 64, "f16", 1)])
+def test_gradients_vs_oracle_autograd_variants(tau, n_samples, mode, n_rays):
     """Two aux k-steps (tau=16) and sample counts that are not one 64-lane wave, against autograd through the oracle."""
     from satnerf_amd import rendering
     from satnerf_amd.models import load_model
 
-    args = O.default_args(t_embbeding_tau=tau, n_samples=n_samples, mlp_mode="bf16x3")
+    args = O.default_args(t_embbeding_tau=tau, n_samples=n_samples, mlp_mode=mode)
     params = O.procedural_satnerf_params(256, tau, seed=21)
     embw = O.procedural_uniform((30, tau), 1.0, 22)
     m = load_model(args)
@@ -195,10 +203,10 @@ def test_gradients_vs_oracle_autograd_variants(tau, n_samples):
     emb = torch.nn.Embedding(30, tau)
     emb.load_state_dict({"weight": embw})
     models = {"coarse": m.to(DEV), "t": emb.to(DEV)}
-    rays, ts = O.synthetic_rays(48, seed=23)
+    rays, ts = O.synthetic_rays(n_rays, seed=23)
     g = torch.Generator().manual_seed(24)
-    u, nz = torch.rand(48, n_samples, generator=g), torch.randn(48, n_samples, generator=g)
-    target = torch.rand(48, 3, generator=g)
+    u, nz = torch.rand(n_rays, n_samples, generator=g), torch.randn(n_rays, n_samples, generator=g)
+    target = torch.rand(n_rays, 3, generator=g)
     loss_of = lambda r, t: ((r["rgb_coarse"] - t) ** 2).sum() + r["depth_coarse"].sum() + (r["weights_coarse"].unsqueeze(-1) * r["beta_coarse"]).sum()  # noqa: E731
     po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     eo = embw.clone().requires_grad_(True)
@@ -210,8 +218,10 @@ def test_gradients_vs_oracle_autograd_variants(tau, n_samples):
     errs = {k: maxnorm_rel(sd[k].grad.cpu(), po[k].grad) for k in po}
     errs["embedding"] = maxnorm_rel(models["t"].weight.grad.cpu(), eo.grad)
     worst = max(errs, key=errs.get)
-    print(tau, n_samples, "worst", worst, f"{errs[worst]:.1e}")
-    assert errs[worst] < GRAD_TOL, errs
+    print(tau, n_samples, mode, n_rays, "worst", worst, f"{errs[worst]:.1e}")
+    tol = GRAD_TOL if mode == "bf16x3" else {48: 8e-2, 37: 6.5e-2, 1: 1.8e-1}[n_rays]
+    assert errs[worst] < tol, errs
+    assert all(torch.isfinite(sd[k].grad).all() for k in po)
 
 
 def test_trainer_direct_step_with_128_samples_uses_separate_kernels():
