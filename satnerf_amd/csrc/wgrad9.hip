@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int row0 = 32 * (4 * wr + ((a + 2 * wc) & 3));
-    if (row0 >= n_rows) continue;  // (wave-uniform) row tiles the block does not have: stale-LDS results, never read
+    if (row0 >= n_rows || !quad_on) continue;  // (wave-uniform) tiles the block does not have / nobody reads: never written, never summed
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int col = 128 * wc + 32 * c + (lane & 31);
