@@ -474,8 +474,8 @@ class Trainer:
         if capture_collective and self._any_rank(failed):
             # the collective could not be captured on SOME rank: every rank drops its graph and re-captures without it (eager all-reduce +
             # Adam after the replay), together -- the warm-up passes of the retry issue collectives, so a rank retrying alone would
-            # leave the job with mismatched collectives.  The vote goes over a gloo side group: the RCCL communicator of a
-            # failed capture is not to be trusted with it.
+            # leave the job with mismatched collectives.  The vote goes through the rendezvous store, not a collective: the
+            # RCCL communicator of a failed capture is not to be trusted with it.
             self._collective_capture_failed = True
             self._graph = None
             torch.cuda.synchronize()
@@ -484,14 +484,32 @@ class Trainer:
         self.state.zero_grad()  # capture does not execute
 
     def _any_rank(self, flag):
-        """logical OR of ``flag`` over the ranks (host-side vote on a gloo group; a single process answers for itself)"""
+        """Logical OR of ``flag`` over the ranks, host-side and without a collective: every rank adds its flag and a tick to two counters
+        of the job's rendezvous store (the TCPStore torch.distributed was initialised through) and waits for all ticks.  A single process
+        answers for itself; if the store cannot be reached the vote falls back to a gloo side group."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return bool(flag)
-        if getattr(self, "_vote_group", None) is None:
-            self._vote_group = dist.new_group(backend="gloo")  # (collective: every rank reaches its first capture)
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._vote_group)
-        return bool(t.item())
+        world = dist.get_world_size()
+        self._vote_no = getattr(self, "_vote_no", 0) + 1  # (captures happen in the same order on every rank)
+        try:
+            import time
+
+            store = dist.distributed_c10d._get_default_store()
+            key = f"satnerf_amd/capture_vote/{self._vote_no}"
+            store.add(key + "/failed", 1 if flag else 0)
+            store.add(key + "/ticks", 1)
+            deadline = time.time() + 300.0
+            while int(store.add(key + "/ticks", 0)) < world:
+                if time.time() > deadline:
+                    raise TimeoutError("capture vote: a rank never arrived")
+                time.sleep(0.002)
+            return int(store.add(key + "/failed", 0)) > 0
+        except (AttributeError, RuntimeError):
+            if getattr(self, "_vote_group", None) is None:
+                self._vote_group = dist.new_group(backend="gloo")
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._vote_group)
+            return bool(t.item())
 
     def step_from_bank(self, bank, depth_bank=None):
         """One step on the banks' next batches; with a captured graph the batches are gathered straight into its static inputs."""

@@ -95,3 +95,24 @@ def test_sharded_batched_inference_gathers_contiguous_row_blocks():
         out = mgr.dict()
         mp.spawn(_shard_worker, args=(world, _free_port(), out), nprocs=world, join=True)
         assert dict(out) == {0: True, 1: True}
+
+
+def _vote_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from satnerf_amd.train import Trainer
+
+    tr = Trainer.__new__(Trainer)  # the vote needs no trainer state: only the process group's rendezvous store
+    votes = [tr._any_rank(False), tr._any_rank(rank == 1), tr._any_rank(True), tr._any_rank(False)]
+    out[rank] = votes
+    dist.destroy_process_group()
+
+
+def test_capture_failure_vote_is_the_same_on_every_rank():
+    """Trainer._any_rank: if the RCCL all-reduce cannot be captured on ANY rank, EVERY rank must re-capture without it (a rank retrying
+    alone would issue warm-up collectives nobody matches).  The vote goes through the rendezvous store, not a collective."""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_vote_worker, args=(world, port, out), nprocs=world, join=True)
+        assert dict(out) == {0: [False, True, True, False], 1: [False, True, True, False]}
