@@ -433,11 +433,13 @@ class Trainer:
     def _capture(self, inputs, banks=None):
         self._static = tuple(t.clone() for t in inputs)
         self._graph_banks = tuple(banks) if banks else None
-        # data parallel: with the RCCL backend ("nccl") the gradient all-reduce and the Adam update are captured INTO the step's graph
-        # (NCCL / RCCL collectives are capturable): a step is one replay, no eager launches between steps.  Other backends (gloo
-        # cannot be captured) -- or SATNERF_GRAPH_ALLREDUCE=0, or a capture that fails -- fall back to the eager all-reduce + Adam
-        # issued after the replay.
-        capture_collective = (self._collective and os.environ.get("SATNERF_GRAPH_ALLREDUCE", "1") != "0" and dist.is_initialized()
+        # data parallel: with the RCCL backend ("nccl") the gradient all-reduce and the Adam update CAN be captured into the step's graph
+        # (NCCL / RCCL collectives are capturable): a step is then one replay, no eager launches between steps.  It is OPT-IN
+        # (SATNERF_GRAPH_ALLREDUCE=1) until a job with two or more GPUs has run it: so far it has only executed on a 1-rank group
+        # (tests/test_hip_training.py), and a collective that misbehaves inside a replayed graph hangs the job instead of raising
+        # (ADVICE r03).  Default, other backends (gloo cannot be captured), or a capture that fails on any rank: the eager all-reduce +
+        # Adam issued after the replay.
+        capture_collective = (self._collective and os.environ.get("SATNERF_GRAPH_ALLREDUCE", "0") == "1" and dist.is_initialized()
                               and dist.get_backend() == "nccl" and not getattr(self, "_collective_capture_failed", False))
         self._adam_in_graph = (not self._collective) or capture_collective
         self._kernel_rng = float(self.args.noise_std) == 0.0  # (a noisy step still draws randn from torch's generator)

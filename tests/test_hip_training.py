@@ -258,7 +258,8 @@ def _nccl_one_rank_worker(rank, port, out_path, force):
     from satnerf_amd.models import load_model
     from satnerf_amd.train import Trainer
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", SATNERF_FORCE_ALLREDUCE="1" if force else "0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", SATNERF_FORCE_ALLREDUCE="1" if force else "0",
+                      SATNERF_GRAPH_ALLREDUCE="1")  # (the captured collective is opt-in until a multi-GPU job has run it)
     torch.cuda.set_device(0)
     if force:
         dist.init_process_group("nccl", rank=0, world_size=1)
@@ -277,8 +278,9 @@ def _nccl_one_rank_worker(rank, port, out_path, force):
 
 
 def test_rccl_allreduce_is_captured_into_the_step_graph(tmp_path):
-    """The data-parallel step's default with the RCCL backend: the all-reduce of the flat gradient and the Adam update are captured
-    into the step's hipGraph.  Exercised on the single GPU with a 1-rank "nccl" process group (SATNERF_FORCE_ALLREDUCE=1 makes the
+    """The data-parallel step with SATNERF_GRAPH_ALLREDUCE=1 and the RCCL backend: the all-reduce of the flat gradient and the Adam update
+    are captured into the step's hipGraph (opt-in until a job with two or more GPUs has run it; the default issues both eagerly after the
+    replay).  Exercised on the single GPU with a 1-rank "nccl" process group (SATNERF_FORCE_ALLREDUCE=1 makes the
     1-rank trainer issue the collective): the capture succeeds, replays run, and the result equals the plain single-GPU trainer's
     (an all-reduce over one rank is the identity, grad_scale 1)."""
     import torch.multiprocessing as mp
