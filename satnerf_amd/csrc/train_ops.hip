@@ -240,25 +240,54 @@ __global__ void __launch_bounds__(256) gather_setup_kernel(const float* __restri
   if (lane == 0) sky[b * 3 + 0] = k0, sky[b * 3 + 1] = k1, sky[b * 3 + 2] = k2;
 }
 
-// torch.optim.Adam (main.py:84: lr 5e-4, betas (0.9, 0.999), eps 1e-8, no weight decay), one launch over the flat buffer.
+// torch.optim.Adam (main.py:84: lr 5e-4, betas (0.9, 0.999), eps 1e-8, no weight decay), one launch over the flat buffer: four elements per
+// thread (16-byte loads / stores; the launcher checks the alignment), the last block's first n % 4 threads take the scalar tail.
+__device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, float step_size, float b1, float b2, float eps, float grad_scale,
+                                         float sqrt_bc2, int zero_grad) {
+  const float gi = g * grad_scale;
+  const float mi = b1 * m + (1.0f - b1) * gi;
+  const float vi = b2 * v + (1.0f - b2) * gi * gi;
+  m = mi, v = vi;
+  p -= step_size * (mi / (sqrtf(vi) / sqrt_bc2 + eps));  // torch: denom = sqrt(v) / sqrt(bc2) + eps; p.addcdiv_(m, denom, -lr / bc1)
+  if (zero_grad) g = 0.f;
+}
+template <bool VEC>
+__device__ __forceinline__ void adam_body(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                                          float lr, float b1, float b2, float eps, float grad_scale, float bc1, float bc2, int zero_grad) {
+  const float step_size = lr / bc1, sqrt_bc2 = sqrtf(bc2);  // once per thread; the arithmetic per element is torch.optim.Adam's
+  if constexpr (VEC) {
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x, n4 = n >> 2;
+    if (i4 < n4) {
+      float4 pp = reinterpret_cast<float4*>(p)[i4], gg = reinterpret_cast<float4*>(g)[i4], mm = reinterpret_cast<float4*>(m)[i4],
+             vv = reinterpret_cast<float4*>(v)[i4];
+      adam_one(pp.x, gg.x, mm.x, vv.x, step_size, b1, b2, eps, grad_scale, sqrt_bc2, zero_grad);
+      adam_one(pp.y, gg.y, mm.y, vv.y, step_size, b1, b2, eps, grad_scale, sqrt_bc2, zero_grad);
+      adam_one(pp.z, gg.z, mm.z, vv.z, step_size, b1, b2, eps, grad_scale, sqrt_bc2, zero_grad);
+      adam_one(pp.w, gg.w, mm.w, vv.w, step_size, b1, b2, eps, grad_scale, sqrt_bc2, zero_grad);
+      reinterpret_cast<float4*>(p)[i4] = pp, reinterpret_cast<float4*>(m)[i4] = mm, reinterpret_cast<float4*>(v)[i4] = vv;
+      if (zero_grad) reinterpret_cast<float4*>(g)[i4] = gg;
+    }
+    if (blockIdx.x == gridDim.x - 1 && (long)threadIdx.x < (n & 3)) {
+      const long i = (n4 << 2) + threadIdx.x;
+      adam_one(p[i], g[i], m[i], v[i], step_size, b1, b2, eps, grad_scale, sqrt_bc2, zero_grad);
+    }
+  } else {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) adam_one(p[i], g[i], m[i], v[i], step_size, b1, b2, eps, grad_scale, sqrt_bc2, zero_grad);
+  }
+}
 // The 1-based step count arrives by value (the update is launched eagerly after the gradient all-reduce, outside the
 // captured forward/backward graph); grad is optionally zeroed for the next step.
+template <bool VEC>
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                   long n, float lr, float b1, float b2, float eps, float grad_scale, float bc1,
                                                   float bc2, int zero_grad) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float gi = g[i] * grad_scale;
-  const float mi = b1 * m[i] + (1.0f - b1) * gi;
-  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-  m[i] = mi, v[i] = vi;
-  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-  p[i] -= (lr / bc1) * (mi / denom);
-  if (zero_grad) g[i] = 0.f;
+  adam_body<VEC>(p, g, m, v, n, lr, b1, b2, eps, grad_scale, bc1, bc2, zero_grad);
 }
 
 // Graph-capturable Adam: the 1-based step count is read from state[0]; it is advanced earlier in the same graph by the step's
 // first kernel (sr_pack_all's `tick`), so no kernel both reads and writes it.  Bias corrections once per block.
+template <bool VEC>
 __global__ void __launch_bounds__(256) adam_graph_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
                                                         float grad_scale, const float* __restrict__ state, int zero_grad) {
@@ -269,14 +298,7 @@ __global__ void __launch_bounds__(256) adam_graph_kernel(float* __restrict__ p, 
   }
   __syncthreads();
   if (lr < 0.f) lr = state[kSchedLr];  // the scheduler's current rate (StepLR per epoch, main.py:86-94) under graph replay
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float gi = g[i] * grad_scale;
-  const float mi = b1 * m[i] + (1.0f - b1) * gi;
-  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-  m[i] = mi, v[i] = vi;
-  p[i] -= (lr / bc[0]) * (mi / (sqrtf(vi) / sqrtf(bc[1]) + eps));
-  if (zero_grad) g[i] = 0.f;
+  adam_body<VEC>(p, g, m, v, n, lr, b1, b2, eps, grad_scale, bc[0], bc[1], zero_grad);
 }
 
 }  // namespace sr
@@ -400,14 +422,26 @@ extern "C" int sr_gather_setup(const float* rays, const float* rgbs, const int64
   return check_launch("gather_setup_kernel");
 }
 
+static bool adam_vectorisable(const float* a, const float* b, const float* c, const float* d) {
+  return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15u) == 0;
+}
+static unsigned adam_vec_blocks(int64_t n) {  // one thread per four elements; at least one block (it takes the scalar tail)
+  const int64_t n4 = n >> 2;
+  return (unsigned)(n4 > 0 ? (n4 + 255) / 256 : 1);
+}
+
 extern "C" int sr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                             float eps, float grad_scale, int64_t step, int zero_grad, void* stream) {
   SR_REQUIRE(params && grads && exp_avg && exp_avg_sq, "sr_adam_step: null pointer");
   SR_REQUIRE(step >= 1, "sr_adam_step: step is 1-based");
   if (n <= 0) return 0;
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step)), bc2 = (float)(1.0 - pow((double)beta2, (double)step));
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
-                     (long)n, lr, beta1, beta2, eps, grad_scale, bc1, bc2, zero_grad);
+  if (adam_vectorisable(params, grads, exp_avg, exp_avg_sq))
+    hipLaunchKernelGGL(adam_kernel<true>, dim3(adam_vec_blocks(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, (long)n, lr,
+                       beta1, beta2, eps, grad_scale, bc1, bc2, zero_grad);
+  else
+    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
+                       (long)n, lr, beta1, beta2, eps, grad_scale, bc1, bc2, zero_grad);
   return check_launch("adam_kernel");
 }
 
@@ -415,7 +449,11 @@ extern "C" int sr_adam_step_graph(float* params, float* grads, float* exp_avg, f
                                   float eps, float grad_scale, float* state, int zero_grad, void* stream) {
   SR_REQUIRE(params && grads && exp_avg && exp_avg_sq && state, "sr_adam_step_graph: null pointer");
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(adam_graph_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
-                     (long)n, lr, beta1, beta2, eps, grad_scale, state, zero_grad);
+  if (adam_vectorisable(params, grads, exp_avg, exp_avg_sq))
+    hipLaunchKernelGGL(adam_graph_kernel<true>, dim3(adam_vec_blocks(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
+                       (long)n, lr, beta1, beta2, eps, grad_scale, state, zero_grad);
+  else
+    hipLaunchKernelGGL(adam_graph_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, (long)n, lr, beta1, beta2, eps, grad_scale, state, zero_grad);
   return check_launch("adam_graph_kernel");
 }
