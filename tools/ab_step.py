@@ -33,6 +33,15 @@ if dbg9 is not None:
     if keep.any():
         k0_ = st[keep, 0].min()
         print(f"  tables fetched {float((t1[keep] - k0_).median()) / 100:.1f} us (max {float((t1[keep] - k0_).max()) / 100:.1f})")
+    if os.environ.get("AB_PER_BLOCK"):  # slice-major numbering: workgroup i works on block i % 14 (the last 4: blocks 0..3)
+        nb = 14
+        idx = torch.arange(st.shape[0])
+        blk = torch.where(idx < (st.shape[0] // nb) * nb, idx % nb, idx - (st.shape[0] // nb) * nb)
+        for b in range(nb):
+            sel = (blk == b) & keep
+            if sel.any():
+                print(f"    block {b:2d}: loop start {float((st[sel, 1] - k0_).mean()) / 100:5.1f}  loop end {float((st[sel, 2] - k0_).mean()) / 100:6.1f} "
+                      f"(max {float((st[sel, 2] - k0_).max()) / 100:6.1f})  tiles {int(dbg9.cpu()[:3 * 1024].view(-1, 3)[sel][:, 2].float().mean())}")
     st = st[keep]
     if st.shape[0]:
         k0 = st[:, 0].min()
