@@ -337,8 +337,10 @@ int launch_wgrad8f(const uint4* dpre, const uint4* acts, const int* blocks, cons
   Wgrad8Params p;
   p.dpre = dpre, p.acts = acts, p.blocks = blocks, p.loads = loads, p.partial = partial;
   p.n_tiles = n_tiles, p.n_blocks = n_blocks, p.ak = ak, p.auxs = auxs, p.dk = dk;
-  const char* dbg = getenv("SR_W8_DBG");
-  p.dbg = dbg ? (long long*)strtoull(dbg, nullptr, 10) : nullptr;
+  p.dbg = nullptr;
+#ifdef SR_W8_TIMING  // timing builds only (tools/ab_wgrad8.py passes the address of its stamp buffer): a product build never takes a pointer from the environment
+  if (const char* dbg = getenv("SR_W8_DBG")) p.dbg = (long long*)strtoull(dbg, nullptr, 10);
+#endif
   const size_t lds = (size_t)kSlotsF * kSlotBytes;
   static bool attr_set = false;
   if (!attr_set) {

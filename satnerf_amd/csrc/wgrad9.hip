@@ -382,8 +382,10 @@ int launch_wgrad9(const uint4* dpre, const uint4* acts, const int* blocks, const
   Wgrad9Params p;
   p.dpre = (const char*)dpre, p.acts = (const char*)acts, p.blocks = blocks, p.loads = loads, p.partial = partial;
   p.n_tiles = n_tiles, p.n_blocks = n_blocks, p.ak = ak, p.dk = dk, p.load_ints = load_ints;
-  const char* dbg = getenv("SR_W9_DBG");
-  p.dbg = dbg ? (long long*)strtoull(dbg, nullptr, 10) : nullptr;
+  p.dbg = nullptr;
+#ifdef SR_W9_TIMING  // timing builds only (tools/ab_wgrad8.py passes the address of its stamp buffer): a product build never takes a pointer from the environment
+  if (const char* dbg = getenv("SR_W9_DBG")) p.dbg = (long long*)strtoull(dbg, nullptr, 10);
+#endif
   const size_t lds = (size_t)kSlots9 * kSlot9 + 16;  // four operand slots + their publish counters
   static bool attr_set = false;
   if (!attr_set) {
