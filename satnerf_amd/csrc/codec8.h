@@ -31,23 +31,49 @@ __device__ __forceinline__ float phase8_rev(uint32_t w, int k) {
 
 // ---- MX8 --------------------------------------------------------------------------------------------------------------
 // E = biased exponent of max|v| * (1 + 2^-7) (so that max|v| / 2^(E-133) <= 127.008 rounds to <= 127), clamped to >= 6.
+// The maximum of the 16 magnitudes is a tree of v_max3_f32 with |.| source modifiers, 8 instructions (left to the compiler: 15, it
+// canonicalises every fmaxf operand) in ONE asm statement (between dependent asm statements the compiler pads with s_nop).
+// `after` = any value the caller has ALREADY derived from v by an ordinary instruction (e.g. the bf16 pack of v[0], v[1]): the asm lists
+// it as an input, so it is scheduled behind that instruction and inherits the wait states the compiler put in front of it -- the compiler
+// does not pad an asm statement that reads a register an MFMA has just written (an identity stage feeds its accumulators straight in:
+// the maximum was taken of registers still in flight and d feats came out with the wrong exponent).
 template <class V>
-__device__ __forceinline__ uint32_t mx8_exponent(const V& v) {
-  float m = 0.f;
-#pragma unroll
-  for (int g = 0; g < 16; g += 2) m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v[g]), __builtin_fabsf(v[g + 1])));
+__device__ __forceinline__ uint32_t mx8_exponent(const V& v, uint32_t after) {
+  float m, t1, t2;
+  asm("v_max3_f32 %0, |%3|, |%4|, |%5|\n\t"
+      "v_max3_f32 %1, |%6|, |%7|, |%8|\n\t"
+      "v_max3_f32 %2, |%9|, |%10|, |%11|\n\t"
+      "v_max3_f32 %0, %0, %1, %2\n\t"
+      "v_max3_f32 %1, |%12|, |%13|, |%14|\n\t"
+      "v_max3_f32 %2, |%15|, |%16|, |%17|\n\t"
+      "v_max3_f32 %1, %1, %2, |%18|\n\t"
+      "v_max_f32 %0, %0, %1"
+      : "=&v"(m), "=&v"(t1), "=&v"(t2)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]),
+        "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(after));
   m = __builtin_fmaf(m, 0.0078125f, m);
   uint32_t e = __builtin_bit_cast(uint32_t, m) >> 23;
   return e < 6u ? 6u : (e > 254u ? 254u : e);
 }
+// u = RNE(v / 2^(E-133)) + 128 by ONE rounding: v * 2^(133-E) + (1.5 * 2^23 + 128) has ulp 1, so the fma rounds to the integer and the
+// low mantissa byte of the sum is u (|v| 2^(133-E) <= 127.008 by the choice of E: 1 <= u <= 255, no saturation needed).  Two values per
+// v_pk_fma_f32, then three v_perm_b32 per four bytes (bytes4): 20 instructions per 16 values (fma + v_cvt_pk_u8_f32 per value: 32).
+// (The elements of the packed result are copied to floats before the bit cast: __builtin_bit_cast(uint32_t, r[1]) on a vector ELEMENT
+// reads the first four bytes of the vector, i.e. r[0], with hipcc 7.2 / clang 22 -- tools/probe_perm_fold.hip.)
 template <class V>
 __device__ __forceinline__ uint4 mx8_encode(const V& v, uint32_t e) {
   const float inv = __builtin_bit_cast(float, (260u - e) << 23);  // 2^(133 - E)
-  uint32_t w[4] = {0u, 0u, 0u, 0u};
+  const f32x2 inv2 = {inv, inv}, magic = {12583040.0f, 12583040.0f};
+  uint32_t t[16];
 #pragma unroll
-  for (int g = 0; g < 16; ++g)  // v_cvt_pk_u8_f32 rounds to nearest even and saturates (tools/probe_cvt.hip)
-    w[g >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(v[g], inv, 128.0f), g & 3, w[g >> 2]);
-  return make_uint4(w[0], w[1], w[2], w[3]);
+  for (int g = 0; g < 16; g += 2) {
+    const f32x2 pair = {v[g], v[g + 1]};
+    const f32x2 r = __builtin_elementwise_fma(pair, inv2, magic);
+    const float r0 = r[0], r1 = r[1];
+    t[g] = __builtin_bit_cast(uint32_t, r0), t[g + 1] = __builtin_bit_cast(uint32_t, r1);
+  }
+  return make_uint4(bytes4(t[0], t[1], t[2], t[3]), bytes4(t[4], t[5], t[6], t[7]), bytes4(t[8], t[9], t[10], t[11]),
+                    bytes4(t[12], t[13], t[14], t[15]));
 }
 __device__ __forceinline__ float mx8_scale(uint32_t e) { return __builtin_bit_cast(float, (e - 6u) << 23); }  // 2^(E - 133)
 __device__ __forceinline__ float mx8_value(uint32_t w, int k, float s, float bias) { return __builtin_fmaf(ubyte_f32(w, k), s, bias); }  // bias = -128 s
