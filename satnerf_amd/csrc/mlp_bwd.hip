@@ -1,5 +1,11 @@
 // C ABI of the fused Sat-NeRF MLP backward (dX chain): argument checks + dispatch to the per-width builds of mlp_bwd.inc
 // (this translation unit holds the 256-wide one; mlp_bwd512.hip the 512-wide one, 8-bit workspaces only).
+#ifndef SR_BWD_TILES
+#define SR_BWD_TILES 1  // 32-point tiles per wave (mlp_bwd.inc): 8 waves of one tile.  2 = 4 waves of two tiles (one A-fragment read per two
+#endif                  // MFMAs), correct and measured 30 % slower as compiler-scheduled code (profiles/r04_ab_variants.txt)
+#if SR_BWD_TILES == 2
+#define SR_MODE1_NW 4
+#endif
 #include "mlp_bwd.inc"
 
 namespace sr {

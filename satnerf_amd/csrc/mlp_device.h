@@ -32,7 +32,11 @@ template <int NPASS>
 struct Mode {
   // waves per workgroup: 8 (two per SIMD, <= 256 VGPRs) when a wave's activations fit 256 registers, else 4 (<= 512 VGPRs): the
   // parity mode (hi + lo planes) and the 512-wide forward (32 + 32 B fragments = 256 registers before anything else)
+#ifdef SR_MODE1_NW  // a translation unit's own choice for its single-pass kernels (mlp_bwd.hip: 4 waves of two tiles each)
+  static constexpr int NW = NPASS == 1 ? SR_MODE1_NW : 4;
+#else
   static constexpr int NW = (NPASS == 1 && kFeat <= 256) ? 8 : 4;
+#endif
   static constexpr int NPA = NPASS == 1 ? 1 : 2;  // A planes (hi[, lo])
   static constexpr int PIECE_BYTES = 1024 * NPA;
 };

@@ -7,6 +7,7 @@ from satnerf_amd.train import Trainer
 dev = "cuda:0"
 args = data.default_args(mlp_mode=os.environ.get("AB_MODE", "bf16"))
 if os.environ.get("AB_FMT"): args.bwd_fmt = int(os.environ["AB_FMT"])
+if os.environ.get("AB_WIDTH"): args.fc_units = int(os.environ["AB_WIDTH"])  # 512: opt.py:50's default width
 torch.manual_seed(0)
 models = {"coarse": load_model(args).to(dev), "t": torch.nn.Embedding(30, 4).to(dev)}
 if os.environ.get("ZERO_WEIGHTS"):  # DVFS experiment: zero operands draw far less power (lr = 0 keeps them zero)
