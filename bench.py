@@ -283,6 +283,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    # (before the first device call, i.e. before the HSA runtime starts: RCCL's cross-process buffers need dmabuf IPC on this driver)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # SATNERF_BENCH_BACKEND=gloo is a TEST hook: it lets two ranks share one GPU so the N>1 code path can be exercised on a
     # single-GPU box (gloo stages the all-reduce through the host; never use it for measurements)
     backend = os.environ.get("SATNERF_BENCH_BACKEND", "nccl")
@@ -293,7 +295,6 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
