@@ -10,13 +10,23 @@ Only DATA is written (inputs, captured random draws, expected outputs).  Model w
 stored: they are procedural (``oracle.satnerf_oracle.procedural_satnerf_params``: an integer hash
 mapped to the SIREN init ranges) and are loaded into the reference modules via ``load_state_dict``.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py            # rewrite every fixture
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py --check    # regenerate in memory, compare with the committed files bit for bit
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py --check --replay
+                                                                            # ... feeding the STORED draws to the reference instead of drawing
+
+Every case seeds torch's generator for itself (``CASES``: crc32 of its name), so a case regenerates the same arrays whatever ran
+before it and ``--only`` reproduces exactly what a full run writes.  Archives are written with fixed zip timestamps: the same arrays
+give the same file bytes.
 """
 import argparse
 import importlib.machinery
+import io
 import os
 import sys
 import types
+import zipfile
+import zlib
 
 import numpy as np
 import torch
@@ -58,8 +68,28 @@ from models import satnerf as ref_satnerf  # noqa: E402
 from oracle import satnerf_oracle as O  # noqa: E402
 
 
+MODE = {"check": False, "replay": False, "failures": []}
+
+
+def _stored(name):
+    z = np.load(os.path.join(HERE, name + ".npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
 class Capture:
-    """Record every draw of the three RNG entry points on the path (rendering.py:33,77; models/*.py randn)."""
+    """Record every draw of the three RNG entry points on the path (rendering.py:33,77; models/*.py randn).  With ``--replay`` the
+    draws are not drawn but taken, in order, from the committed fixture ``fixture`` (keys ``keys``, default draw0, draw1, ...): the
+    reference then runs on the STORED draws, and ``save`` compares what it returns with the stored outputs."""
+
+    def __init__(self, fixture=None, keys=None):
+        self.replay = None
+        if MODE["replay"] and fixture is not None:
+            st = _stored(fixture)
+            if keys is None:
+                keys = []
+                while f"draw{len(keys)}" in st:
+                    keys.append(f"draw{len(keys)}")
+            self.replay = [torch.from_numpy(st[k]) for k in keys]
 
     def __enter__(self):
         self.draws = []
@@ -67,7 +97,13 @@ class Capture:
 
         def wrap(fn):
             def inner(*a, **k):
-                out = fn(*a, **k)
+                if self.replay is not None:
+                    assert self.replay, "the reference draws more often than the fixture stores draws"
+                    want = fn(*a, **k)  # (shape / dtype check; the generator's state is irrelevant in this mode)
+                    out = self.replay.pop(0)
+                    assert out.shape == want.shape and out.dtype == want.dtype, (out.shape, want.shape)
+                else:
+                    out = fn(*a, **k)
                 self.draws.append(out.clone())
                 return out
             return inner
@@ -77,6 +113,8 @@ class Capture:
 
     def __exit__(self, *exc):
         torch.rand_like, torch.randn, torch.rand = self._orig
+        if exc[0] is None and self.replay is not None:
+            assert not self.replay, f"{len(self.replay)} stored draws were never consumed"
 
 
 def ref_models(args, seed_coarse=1, seed_fine=2, emb_seed=7):
@@ -108,7 +146,26 @@ def save(name, **arrays):
             v = v.detach().cpu().numpy()
         out[k] = v
     path = os.path.join(HERE, name + ".npz")
-    np.savez_compressed(path, **out)
+    if MODE["check"]:
+        st = _stored(name)
+        bad = sorted(set(st) ^ set(out))
+        for k in sorted(set(st) & set(out)):
+            a, b = np.asarray(out[k]), st[k]
+            if a.shape != b.shape or a.dtype != b.dtype or a.tobytes() != b.tobytes():
+                bad.append(k)
+        print(f"{name}.npz  {'OK: ' + str(len(out)) + ' arrays bit-equal' if not bad else 'MISMATCH: ' + ', '.join(bad)}"
+              + ("  (stored draws replayed)" if MODE["replay"] else ""))
+        if bad:
+            MODE["failures"].append((name, bad))
+        return
+    # np.savez_compressed with fixed member timestamps: equal arrays -> equal file bytes
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED) as zf:
+        for k, v in out.items():
+            buf = io.BytesIO()
+            np.lib.format.write_array(buf, np.asanyarray(v), allow_pickle=False)
+            info = zipfile.ZipInfo(k + ".npy", date_time=(1980, 1, 1, 0, 0, 0))
+            info.compress_type = zipfile.ZIP_DEFLATED
+            zf.writestr(info, buf.getvalue())
     print(f"{name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
 
 
@@ -117,7 +174,7 @@ def render_case(name, n_rays, ray_seed, **kw):
     classic = args.model == "nerf"
     rays, ts = O.synthetic_rays(n_rays, seed=ray_seed, classic=classic)
     models = ref_models(args)
-    with torch.no_grad(), Capture() as cap:
+    with torch.no_grad(), Capture(name) as cap:
         res = ref_rendering.render_rays(models, args, rays, ts)
     arrays = {"rays": rays, "cfg": np.array(repr(vars(args)))}
     if ts is not None:
@@ -136,7 +193,7 @@ def snerf_case():
     args = O.default_args(model="s-nerf", sc_lambda=0.05)
     rays, ts = O.synthetic_rays(48, seed=31)
     models = ref_models(args)
-    with Capture() as cap:
+    with Capture("snerf_sc") as cap:
         res = ref_rendering.render_rays(models, args, rays, ts)
     target = torch.rand(48, 3, generator=torch.Generator().manual_seed(32))
     loss, _ = ref_metrics.SNerfLoss(lambda_sc=0.05)(res, target)
@@ -224,33 +281,8 @@ def rpc_rays_case():
     save("rpc_rays", **arrays)
 
 
-def main():
-    ap = argparse.ArgumentParser(description=__doc__)
-    ap.add_argument("--only", default=None, help="regenerate one fixture group (latlonalt | snerf | rpc)")
-    only = ap.parse_args().only
-    torch.manual_seed(0)
-    torch.set_num_threads(8)
-    if only == "latlonalt":
-        return latlonalt_case()
-    if only == "snerf":
-        return snerf_case()
-    if only == "rpc":
-        return rpc_rays_case()
-    latlonalt_case()
-    rpc_rays_case()
-    snerf_case()
-
-    # full render_rays variants (SURVEY.md 8c)
-    render_case("satnerf_coarse", 96, 11)
-    render_case("satnerf_sc", 40, 12, sc_lambda=0.1)
-    render_case("satnerf_fine", 40, 13, n_importance=64)
-    render_case("satnerf_noise", 40, 14, noise_std=0.5)
-    render_case("satnerf_s128", 24, 15, n_samples=128)
-    render_case("satnerf_feat512", 24, 16, fc_units=512, t_embbeding_tau=16)
-    render_case("satnerf_s50_ragged", 37, 17, n_samples=50, chunk=999)
-    render_case("nerf_coarse_fine", 32, 18, model="nerf", n_importance=32)
-
-    # SatNeRF.forward alone on a ragged batch of points
+def mlp_forward_case():
+    """SatNeRF.forward alone on a ragged batch of points"""
     args = O.default_args()
     model = ref_models(args)["coarse"]
     g = torch.Generator().manual_seed(21)
@@ -263,18 +295,23 @@ def main():
         sig = model(xyz, input_sun_dir=sun, input_t=t, sigma_only=True)
     save("mlp_forward", xyz=xyz, sun=sun, t=t, out=out, sigma_only=sig)
 
-    # sample_pdf alone, random and deterministic
+
+def sample_pdf_case():
+    """sample_pdf alone, random and deterministic"""
     g = torch.Generator().manual_seed(22)
     bins = torch.sort(torch.rand(33, 63, generator=g), -1)[0]
     w = torch.rand(33, 62, generator=g) ** 4
     w[3] = 0.0  # an all-zero row: every bin hits the eps floor
     w[4, 10:40] = 0.0  # flat stretches inside the cdf (denom<eps branch)
-    with Capture() as cap:
+    with Capture("sample_pdf", ["u"]) as cap:
         z_rand = ref_rendering.sample_pdf(bins, w, 48, det=False)
     z_det = ref_rendering.sample_pdf(bins, w, 48, det=True)
     save("sample_pdf", bins=bins, weights=w, u=cap.draws[0], z_rand=z_rand, z_det=z_det)
 
-    # compositing alone with extreme sigmas, through the reference's inference() around a canned model
+
+def composite_extreme_case():
+    """compositing alone with extreme sigmas, through the reference's inference() around a canned model"""
+
     class Canned(torch.nn.Module):
         number_of_outputs = 9
 
@@ -299,16 +336,18 @@ def main():
     z = torch.sort(torch.rand(n, s, generator=g), -1)[0]
     z[5, 10] = z[5, 11]  # a zero-length interval
     a2 = O.default_args(noise_std=0.7, chunk=1000)
-    with torch.no_grad(), Capture() as cap:
+    with torch.no_grad(), Capture("composite_extreme", ["noise"]) as cap:
         res = ref_satnerf.inference(Canned(raw), a2, torch.zeros(n, s, 3), z, sun_d=torch.zeros(n, 3), rays_t=torch.zeros(n, 4))
     save("composite_extreme", raw=raw.view(n, s, 9), z=z, noise=cap.draws[0], noise_std=np.float32(0.7),
          **{"out_" + k: v.contiguous() for k, v in res.items()})
 
-    # backward: grads of sum(rgb)+sum(depth)+sum(beta*w) wrt representative params + the embedding
+
+def backward_case():
+    """backward: grads of sum(rgb)+sum(depth)+sum(beta*w) wrt representative params + the embedding"""
     args = O.default_args()
     rays, ts = O.synthetic_rays(64, seed=24)
     models = ref_models(args)
-    with Capture() as cap:
+    with Capture("backward") as cap:
         res = ref_rendering.render_rays(models, args, rays, ts)
     loss = res["rgb_coarse"].sum() + res["depth_coarse"].sum() + (res["weights_coarse"].unsqueeze(-1) * res["beta_coarse"]).sum()
     loss.backward()
@@ -319,14 +358,16 @@ def main():
     save("backward", rays=rays, ts=ts, loss=loss.detach(), grad_embedding=models["t"].weight.grad,
          **{f"draw{i}": d for i, d in enumerate(cap.draws)}, **grads)
 
-    # batched_inference with a ragged last chunk + the three losses and a few loss gradients
+
+def batched_losses_case():
+    """batched_inference with a ragged last chunk + the three losses and a few loss gradients"""
     import eval_satnerf as ref_eval  # noqa: E402  (imports the stubs above)
     import metrics as ref_metrics  # noqa: E402
 
     args = O.default_args(chunk=100, sc_lambda=0.05)
     rays, ts = O.synthetic_rays(250, seed=25)
     models = ref_models(args)
-    with Capture() as cap:
+    with Capture("batched_losses") as cap:
         res = ref_eval.batched_inference(models, rays, ts, args)
     arrays = {"rays": rays, "ts": ts}
     arrays.update({f"draw{i}": d for i, d in enumerate(cap.draws)})
@@ -370,5 +411,50 @@ def main():
     save("batched_losses", **arrays)
 
 
+# every fixture and the function that makes it; a case seeds torch's global generator with crc32(fixture name) before it runs, so its
+# draws do not depend on which cases ran before it
+CASES = {
+    "latlonalt": latlonalt_case,
+    "rpc_rays": rpc_rays_case,
+    "snerf_sc": snerf_case,
+    # full render_rays variants (SURVEY.md 8c)
+    "satnerf_coarse": lambda: render_case("satnerf_coarse", 96, 11),
+    "satnerf_sc": lambda: render_case("satnerf_sc", 40, 12, sc_lambda=0.1),
+    "satnerf_fine": lambda: render_case("satnerf_fine", 40, 13, n_importance=64),
+    "satnerf_noise": lambda: render_case("satnerf_noise", 40, 14, noise_std=0.5),
+    "satnerf_s128": lambda: render_case("satnerf_s128", 24, 15, n_samples=128),
+    "satnerf_feat512": lambda: render_case("satnerf_feat512", 24, 16, fc_units=512, t_embbeding_tau=16),
+    "satnerf_s50_ragged": lambda: render_case("satnerf_s50_ragged", 37, 17, n_samples=50, chunk=999),
+    "nerf_coarse_fine": lambda: render_case("nerf_coarse_fine", 32, 18, model="nerf", n_importance=32),
+    "mlp_forward": mlp_forward_case,
+    "sample_pdf": sample_pdf_case,
+    "composite_extreme": composite_extreme_case,
+    "backward": backward_case,
+    "batched_losses": batched_losses_case,
+}
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--only", default=None, help="comma-separated fixture names (default: all): " + " ".join(CASES))
+    ap.add_argument("--check", action="store_true", help="write nothing: regenerate in memory and compare with the committed fixtures, bit for bit")
+    ap.add_argument("--replay", action="store_true", help="with --check: feed the reference the fixtures' STORED draws instead of drawing")
+    a = ap.parse_args()
+    assert a.check or not a.replay, "--replay belongs to --check"
+    MODE["check"], MODE["replay"] = a.check, a.replay
+    torch.set_num_threads(8)
+    aliases = {"snerf": "snerf_sc", "rpc": "rpc_rays"}
+    names = list(CASES) if a.only is None else [aliases.get(n, n) for n in a.only.split(",")]
+    for name in names:
+        torch.manual_seed(zlib.crc32(name.encode()))
+        CASES[name]()
+    extra = sorted(set(f[:-4] for f in os.listdir(HERE) if f.endswith(".npz")) - set(CASES))
+    assert not extra, f"fixtures without a recipe: {extra}"
+    if MODE["failures"]:
+        print("FAILED:", MODE["failures"])
+        return 1
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -3,6 +3,8 @@
 The reference has no tests for this path; these vectors were produced by tests/golden/make_golden.py
 importing /root/reference in the build container.  CPU only.
 """
+import os
+
 import pytest
 import torch
 
@@ -152,3 +154,17 @@ def test_latlonalt_restatement_matches_reference():
     assert np.abs(lat - np.asarray(g["lats"])).max() < 1e-12
     assert np.abs(lon - np.asarray(g["lons"])).max() < 1e-12
     assert np.abs(alt - np.asarray(g["alts"])).max() < 1e-8  # metres; p/cos(lat) - N cancels ~6.4e6 m
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference only exists in the build container")
+def test_fixture_recipe_reproduces_the_committed_fixtures():
+    """tests/golden/make_golden.py --check: every fixture regenerates bit for bit from its own seed (any case order), and --replay
+    feeds the STORED draws through the imported reference with bit-equal outputs (Next #6)."""
+    import subprocess
+    import sys
+
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py")
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    for extra in ([], ["--replay", "--only", "batched_losses,satnerf_fine,backward"]):
+        r = subprocess.run([sys.executable, script, "--check", *extra], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and "MISMATCH" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
