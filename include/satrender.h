@@ -53,6 +53,10 @@ int64_t sr_dpre_elems_per_tile(int feat, int fmt);  /* pre-activation gradients 
 /* tiles both workspaces must hold for n_points points: ceil(n_points / 32) rounded up to the 8 tiles of a workgroup -- the forward and
  * dX kernels run whole workgroups, and the waves past the last point still store their (unused) tile */
 int64_t sr_workspace_tiles(int64_t n_points);
+/* 16-bit elements of the WHOLE dpre workspace for n_points points = sr_workspace_tiles * sr_dpre_elems_per_tile, plus (SR_FMT8) the table
+ * of exponent maxima the dX pass leaves behind the last tile for the weight-gradient pass: 16 bytes per 4 tiles, byte g = the largest MX8
+ * exponent byte of scale group g over those tiles (csrc/mlp_layout.h), rounded up to whole KiB.  -1 on an unsupported shape. */
+int64_t sr_dpre_workspace_elems(int64_t n_points, int feat, int fmt);
 
 /* ---- weight packing:  replaces nothing in the reference (its weights feed addmm directly) ---------
  * out_hi[i] = bf16_rne(src[idx[i]] * scale[i]);  out_lo[i] = bf16_rne(src[idx[i]]*scale[i] - out_hi[i])
@@ -171,7 +175,7 @@ int sr_render_points_per_block(int feat, int mode);
 /* ---- backward of the fused MLP: replaces autograd through SatNeRF.forward (models/satnerf.py:156-208) ------------
  * sr_satnerf_mlp_bwd: data-gradient chain.  Inputs: the forward's saved `acts`, its four outputs and the gradients of
  * those outputs (g_* may be NULL = 0); bwd_stream = packed transposed weights (sr_pack_stream with
- * packing.backward_maps).  Outputs: dpre (sr_dpre_elems_per_tile(feat, fmt) * sr_workspace_tiles(P) 16-bit elements) and d_t (P,tau)
+ * packing.backward_maps).  Outputs: dpre (sr_dpre_workspace_elems(P, feat, fmt) 16-bit elements) and d_t (P,tau)
  * fp32, the gradient w.r.t. each point's embedding vector (NULL to skip).  `fmt` = format of BOTH workspaces.
  * sr_satnerf_wgrad: weight-gradient GEMMs dpre x acts over all points.  `blocks` (n_blocks x 12 int32, device) lists the job
  * blocks (rf0 nr0 rf1 nr1 | cf0 nc0 cf1 nc1 | col_kind n_slices first_slice -: up to two ranges of dpre row fragments and of
@@ -195,7 +199,8 @@ int sr_satnerf_wgrad(int feat, int tau, int64_t n_points, const uint16_t* dpre, 
  * sine, MX8 -> fp16 value scaled per workgroup) and contracts 128 x 128 register tiles with fp16 MFMAs; SATNERF_WGRAD_V1=1 (and
  * workspaces of 4 GiB or more) run the r02 kernel, which expands the fragments in the LDS to bf16.  `loads` (n_blocks x
  * sr_wgrad8_load_ints() int32, device; packing.wgrad8_loads) says which unit of which workspace each wave of a block fetches and where
- * it goes -- ints 0..19 for the r02 kernel, 20..108 the duty table, exponent scan list and quadrant mask of the default one; `blocks` is
+ * it goes -- ints 0..19 for the r02 kernel, 20..108 the duty table, the exponent groups of the row pairs and the quadrant mask of the default one
+ * (which reads the exponent maxima behind the dpre workspace: dpre must be the buffer sr_satnerf_mlp_bwd wrote, sr_dpre_workspace_elems long); `blocks` is
  * the same planned table.  sr_wgrad_plan hands the default kernel equal slices (it runs one instruction stream for every block) and the
  * r02 kernel cost-weighted ones. */
 int sr_satnerf_wgrad8(int feat, int tau, int64_t n_points, const uint16_t* dpre, const uint16_t* acts, const int32_t* blocks,

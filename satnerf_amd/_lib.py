@@ -53,6 +53,7 @@ SIGNATURES = {
     "sr_pack_stream": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     "sr_dpre_elems_per_tile": (_i64, [_i, _i]),
     "sr_workspace_tiles": (_i64, [_i64]),
+    "sr_dpre_workspace_elems": (_i64, [_i64, _i, _i]),
     "sr_unpack_grads": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _vp]),
     "sr_composite_image": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp]),
     "sr_latlonalt_from_depth": (_i, [_vp, _i, _vp, _i64, _vp, _d, _vp, _vp, _vp, _vp]),

@@ -17,6 +17,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// hipFuncSetAttribute(max dynamic LDS) once per (kernel, device) of this process: false + sr_last_error on failure
+bool ensure_dynamic_lds(const void* kernel, size_t bytes);
+
 #define SR_REQUIRE(cond, ...)  \
   do {                         \
     if (!(cond)) {             \
@@ -27,6 +30,8 @@ int check_launch(const char* what);
 
 // tiles a training workspace holds for n_points points (sr_workspace_tiles): whole workgroups of 8 waves = 8 tiles
 constexpr long ws_tiles(long n_points) { return ((n_points + 31) / 32 + 7) / 8 * 8; }
+// bytes of the exponent-maxima table behind the dpre workspace (SR_FMT8; mlp_layout.h): 16 per 4 tiles, rounded up to whole 1-KiB units
+constexpr long ws_emax_bytes(long n_points) { return (ws_tiles(n_points) / 4 * 16 + 1023) / 1024 * 1024; }
 
 // ---- bf16 helpers -----------------------------------------------------------------------------
 // Two fp32 -> one dword of two bf16 (RNE): element 0 in the low half.  Lowers to v_cvt_pk_bf16_f32.

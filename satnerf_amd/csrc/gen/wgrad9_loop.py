@@ -19,9 +19,10 @@ or 8 fat waves, 64 x 64 / 128 x 64 register tiles, operands staged by LDS-DMA an
       PHASE8 sin(2 pi u / 256):    one v_perm builds the pair (4 + u0 / 256, 4 + u1 / 256) (0x4400 | u), two v_sin_f16 (SDWA, in
                                    place) take revolutions: 1.5 instructions per value instead of 2.5;
     the decoded fragments reach the LDS once (ds_write_b128), nothing is staged raw;
-  * fp16's range is fitted per workgroup: the kernel first scans the scale bytes of its slice (wgrad9.hip), the rows are scaled by
-    G = 2^(138 - Emax) (|value| < 2^12; a lane 2^-19 below the slice's largest flushes to zero) and the fp32 accumulators are
-    unscaled when the partial block is written.
+  * fp16's range is fitted per workgroup and per 32-row pair: wgrad9.hip reads the largest exponent of every pair's scale group over its
+    slice from the table the dX kernel leaves behind the workspace, the rows of a pair are scaled by G = 2^(138 - Emax) (|value| < 2^12;
+    a lane 2^-19 below its group's largest flushes to zero) -- %[erow0] / %[erow1] are the references of the wave's two row duties --
+    and the fp32 accumulators are unscaled tile by tile when the partial block is written.
 
 The whole slice loop is ONE asm statement (accumulators never leave the AGPRs), unrolled four tiles deep -- LDS slots and staging
 registers rotate with period 4, so every address is static:
@@ -187,7 +188,7 @@ class Stream:
         if codec == "mx":
             sc = SCS + 4 * sset + d
             # fp16 scale 2^(E - Eref - 15): exponent field E - Eref (Eref = Emax - 20), flushed to zero below fp16's normal range
-            V(f"v_subrev_u32 v{SCL}, %[{'erow' if d < 2 else 'ecol'}], v{sc}")
+            V(f"v_subrev_u32 v{SCL}, %[{f'erow{d}' if d < 2 else 'ecol'}], v{sc}")   # the reference exponent of this duty's row pair / of the columns
             V(f"v_max_i32 v{SCL}, 0, v{SCL}")
             V(f"v_lshlrev_b32 v{SCL}, 10, v{SCL}")
             V(f"v_mul_f16 v{BIAS}, 0xe480, v{SCL}")                            # bias = -1152 scale: the 1024 of the magic number + the 128 of the offset

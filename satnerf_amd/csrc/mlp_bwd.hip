@@ -32,6 +32,8 @@ extern "C" int sr_satnerf_mlp_bwd(int feat, int tau, int64_t n_points, const uin
   p.acts = (const uint4*)acts, p.dpre = (uint4*)dpre, p.d_t = d_t;
   p.stream = (const char*)bwd_stream;
   p.n_points = n_points, p.tau = tau, p.auxs = aux_steps(tau);
+  // SR_FMT8: the table of exponent maxima sits behind the workspace's last tile (sr_dpre_workspace_elems)
+  p.emax = fmt == SR_FMT8 ? (uint4*)(dpre + sr_workspace_tiles(n_points) * sr_dpre_elems_per_tile(feat, fmt)) : nullptr;
   if (feat == 512) return launch_bwd512(p, fmt, (hipStream_t)stream);
   return fmt == SR_FMT8 ? launch_bwd_fmt<SR_FMT8>(p, (hipStream_t)stream) : launch_bwd_fmt<SR_FMT16>(p, (hipStream_t)stream);
 }
@@ -48,6 +50,12 @@ extern "C" int64_t sr_dpre_elems_per_tile(int feat, int fmt) {
   if (feat == 512) return fmt == SR_FMT8 ? (int64_t)dpre8_units_512() * 64 * 8 : -1;
   if (feat != kFeat) return -1;
   return (int64_t)(fmt == SR_FMT8 ? kD8Units : kDpFrags) * 64 * 8;
+}
+
+extern "C" int64_t sr_dpre_workspace_elems(int64_t n_points, int feat, int fmt) {
+  const int64_t per_tile = sr_dpre_elems_per_tile(feat, fmt);
+  if (per_tile < 0 || n_points < 0) return -1;
+  return sr::ws_tiles(n_points) * per_tile + (fmt == SR_FMT8 ? sr::ws_emax_bytes(n_points) / 2 : 0);
 }
 
 extern "C" int64_t sr_act_elems_per_tile(int feat, int fmt) {

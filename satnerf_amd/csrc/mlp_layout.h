@@ -124,6 +124,15 @@ static_assert(kMT <= 16, "a scale slot must fit the lane's 16 bytes");
 constexpr int dp8_unit(int frag) { return frag < kDpSigma ? frag >> 1 : (frag - 1) >> 1; }  // d_sigma_pre sits between the logical fragments
 constexpr int dp8_group(int frag) { return frag < kDpFeats ? frag / kKS : frag < kDpSigma ? 8 : 9 + (frag - kDpRgbh) / kHS; }
 // SR_FMT16 / SR_FMT8 are defined in include/satrender.h
+//
+// Exponent maxima (SR_FMT8).  The 4-wave weight-gradient kernel (wgrad9.hip) contracts fp16 operands and has to know, before it decodes
+// its first value, the largest exponent its slice of points will show.  The dX kernel holds every MX8 exponent byte in a register when
+// it stores it, so it leaves the maxima behind: a table of 16-byte entries behind the last tile of the dpre workspace, one entry per
+// kEmaxTiles consecutive tiles, byte g = the largest exponent byte of scale group g (0..13, above) over those tiles' 64 lanes, byte
+// kEmaxFeats = the same for the feats exponents the FORWARD saved (the MX8 column operand), byte kEmaxRaw = the largest biased exponent
+// of the two bf16 row fragments d_sigma_pre / d_head.  (r04 scanned the exponent bytes in the weight-gradient kernel itself: 28 MB of
+// reads and a 9-us serial prologue per launch.)
+constexpr int kEmaxTiles = 4, kEmaxFeats = 14, kEmaxRaw = 15;
 
 // backward (dX) stream: transposed weights, scale 1, chunk list in consumption order.  A chunk is `tiles(st)` output
 // tiles of `ppt(st)` pieces each (pieces of a tile are contiguous); every chunk fits one ring slot of SLOTP pieces (24 at feat

@@ -54,6 +54,7 @@ struct BwdParams {
   const float* beta;
   const uint4* acts;      // saved activations, act_ksteps(auxs) fragments per 32-point tile
   uint4* dpre;            // out: pre-activation gradients, kDpFrags fragments per tile
+  uint4* emax;            // out (SR_FMT8): the table of exponent maxima behind the workspace's last tile (mlp_layout.h), one entry per 4 tiles
   float* d_t;             // out: (P, tau) gradient of the embedding vector per point (may be null)
   const char* stream;     // transposed weight stream (bf16)
   long n_points;

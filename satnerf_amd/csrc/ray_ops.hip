@@ -7,6 +7,8 @@
 
 #include "common.h"
 #include "mlp_layout.h"
+#include <mutex>
+
 #include "ray_device.h"
 
 namespace sr {
@@ -26,6 +28,26 @@ int check_launch(const char* what) {
     return 2;
   }
   return 0;
+}
+
+// one hipFuncSetAttribute per (kernel, device) of the process: several devices in one process (tests, notebooks) each need their own
+// call, which a function-local `static bool` would skip.  The table is tiny and only ever grows; a mutex keeps it sane.
+bool ensure_dynamic_lds(const void* kernel, size_t bytes) {
+  struct Ent { const void* k; int dev; size_t bytes; };
+  static Ent done[256];
+  static int n_done = 0;
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < n_done; ++i)
+    if (done[i].k == kernel && done[i].dev == dev && done[i].bytes >= bytes) return true;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+    set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed on device %d", bytes, dev);
+    return false;
+  }
+  if (n_done < 256) done[n_done++] = Ent{kernel, dev, bytes};
+  return true;
 }
 
 constexpr int kRaysPerBlock = 4;  // 4 waves = 256 threads

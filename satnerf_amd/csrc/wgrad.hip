@@ -319,14 +319,7 @@ extern "C" int sr_satnerf_wgrad(int feat, int tau, int64_t n_points, const uint1
   p.auxs = aux_steps(tau);
   p.ak = act_ksteps(p.auxs);
   const size_t lds = (size_t)kSlots * kSlotBytes;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
-      return 1;
-    }
-    attr_set = true;
-  }
+  if (!ensure_dynamic_lds((const void*)wgrad_kernel, lds)) return 1;
   hipLaunchKernelGGL(wgrad_kernel, dim3(n_slices), dim3(1024), lds, (hipStream_t)stream, p);
   return check_launch("wgrad_kernel");
 }

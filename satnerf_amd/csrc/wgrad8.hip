@@ -45,7 +45,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 //   bits 0-1 source (1 dpre, 2 acts) | 2-3 codec (0 RAW16, 1 PHASE8, 2 MX8) | 4-11 unit within the tile | 12-17 operand fragment
 //   (0..15 rows, 16..31 columns; a DF expands into fragment and fragment + 1) | 18-19 scale area | 20-23 byte within the lane's 16 B
 // ints 16..18: the scale unit fetched into scale area 0..2 (bits 0-1 source, 4-11 unit; 0 = none), by waves 2..4.
-// ints 20..99: the duty table of the 4-wave kernel (wgrad9.hip, packing.wgrad9_duties); ints 100..107: its exponent scan list, int 108: its quadrant mask.
+// ints 20..99: the duty table of the 4-wave kernel (wgrad9.hip, packing.wgrad9_duties); ints 100..107: the exponent groups of its row pairs, int 108: its quadrant mask.
 constexpr int kWg8LoadInts = 109;
 enum { kSrcDpre = 1, kSrcActs = 2, kRaw16 = 0, kPhase8 = 1, kMx8 = 2 };
 
@@ -267,8 +267,8 @@ __global__ void __launch_bounds__(1024) wgrad8_kernel(const Wgrad8Params prm) {
 namespace sr {
 int launch_wgrad8f(const uint4* dpre, const uint4* acts, const int* blocks, const int* loads, float* partial, long n_tiles, int n_blocks,
                    int ak, int auxs, int dk, int n_slices, hipStream_t st);  // wgrad8f.hip
-int launch_wgrad9(const uint4* dpre, const uint4* acts, const int* blocks, const int* loads, float* partial, long n_tiles, int n_blocks, int ak,
-                  int dk, int load_ints, int n_slices, hipStream_t st);  // wgrad9.hip
+int launch_wgrad9(const uint4* dpre, const uint4* acts, const uint4* emax, const int* blocks, const int* loads, float* partial, long n_tiles,
+                  int n_blocks, int ak, int dk, int load_ints, int n_slices, hipStream_t st);  // wgrad9.hip
 bool wgrad9_fits(long n_tiles, int ak, int dk);
 }
 using namespace sr;
@@ -291,18 +291,12 @@ extern "C" int sr_satnerf_wgrad8(int feat, int tau, int64_t n_points, const uint
   static const bool v1 = [] { const char* e = getenv("SATNERF_WGRAD_V1"); return e && e[0] == '1'; }();
   static const bool v2 = [] { const char* e = getenv("SATNERF_WGRAD_V2"); return e && e[0] == '1'; }();
   if (!v1 && !v2 && wgrad9_fits(p.n_tiles, p.ak, p.dk))
-    return launch_wgrad9(p.dpre, p.acts, blocks, loads, partial, p.n_tiles, n_blocks, p.ak, p.dk, kWg8LoadInts, n_slices, (hipStream_t)stream);
+    return launch_wgrad9(p.dpre, p.acts, p.dpre + sr::ws_tiles(n_points) * p.dk * 64 /* the exponent maxima behind the last tile */, blocks, loads,
+                         partial, p.n_tiles, n_blocks, p.ak, p.dk, kWg8LoadInts, n_slices, (hipStream_t)stream);
   if (feat == 256 && v2)
     return launch_wgrad8f(p.dpre, p.acts, blocks, loads, partial, p.n_tiles, n_blocks, p.ak, p.auxs, p.dk, n_slices, (hipStream_t)stream);
   const size_t lds = (size_t)kSlots8 * kSlot8Bytes;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)wgrad8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
-      return 1;
-    }
-    attr_set = true;
-  }
+  if (!ensure_dynamic_lds((const void*)wgrad8_kernel, lds)) return 1;
   hipLaunchKernelGGL(wgrad8_kernel, dim3(n_slices), dim3(1024), lds, (hipStream_t)stream, p);
   return check_launch("wgrad8_kernel");
 }

@@ -342,14 +342,7 @@ int launch_wgrad8f(const uint4* dpre, const uint4* acts, const int* blocks, cons
   if (const char* dbg = getenv("SR_W8_DBG")) p.dbg = (long long*)strtoull(dbg, nullptr, 10);
 #endif
   const size_t lds = (size_t)kSlotsF * kSlotBytes;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)wgrad8f_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
-      return 1;
-    }
-    attr_set = true;
-  }
+  if (!ensure_dynamic_lds((const void*)wgrad8f_kernel, lds)) return 1;
   hipLaunchKernelGGL(wgrad8f_kernel, dim3(n_slices), dim3(512), lds, st, p);
   return check_launch("wgrad8f_kernel");
 }

@@ -8,10 +8,12 @@
 //   * The 8-bit operands go HBM -> VGPRs, are decoded in registers with packed fp16 arithmetic (MX8: v_perm + v_pk_fma_f16 per pair;
 //     PHASE8: v_perm + two v_sin_f16 per pair) and reach the LDS once, as fp16 fragments; the MFMAs take fp16 operands.  With one wave
 //     per SIMD a wave's time is the sum of its issue slots (tools/probe_lds.hip), so the instruction count per MFMA is what matters.
-//   * fp16's range is fitted per workgroup: before the loop the workgroup scans the MX8 exponent bytes (and the bf16 row fragment) of
-//     ITS slice of points for the largest one, Emax; rows are decoded times G = 2^(138 - Emax) (|value| < 2^12; lanes 2^-19 below the
-//     slice's largest flush to zero), MX8 columns (feats) likewise with their own Emax, and the fp32 accumulators are unscaled when
-//     the partial block is written.
+//   * fp16's range is fitted per workgroup AND per 32-row pair (= per accumulator row tile, one scale group of the dpre workspace): the
+//     dX kernel leaves the largest MX8 exponent byte of every scale group per 4 tiles in a table behind the dpre workspace
+//     (mlp_layout.h); the workgroup reads the entries of ITS slice of points (a few dozen 16-byte loads; r04 scanned the exponent bytes
+//     themselves: 28 MB and 9 us per launch), the rows of pair p are decoded times G_p = 2^(138 - Emax_p) (|value| < 2^12; lanes 2^-19
+//     below the largest of their own group flush to zero -- rows of another layer that share the block no longer matter), MX8 columns
+//     (feats) likewise with their own Emax, and the fp32 accumulators are unscaled tile by tile when the partial block is written.
 //   * The whole slice loop is one generated, hand-placed asm statement (csrc/gen/wgrad9_loop.py -> wgrad9_loop_{p,m}.inc): 36 MFMAs per
 //     tile, the decode of tile i + 2, the global loads of tile i + 5 and the operand reads of the next k-step in their gaps; LDS ring
 //     of four fp16 slots, waves synchronise through per-slot publish counters in the LDS (no s_barrier in the loop).
@@ -30,11 +32,13 @@ typedef float f32x32w __attribute__((ext_vector_type(32)));
 
 namespace {
 constexpr int kFrag9 = 1088, kPair9 = 2 * kFrag9, kSlotFrags9 = 36, kSlot9 = kSlotFrags9 * kFrag9, kSlots9 = 4;  // = gen/wgrad9_loop.py
-constexpr int kOldInts = 20, kDutyInts = 4, kDuties = 5, kDumpFrag = 34, kScanEntries = 4;
+constexpr int kEmaxFeatsByte = 14;  // = mlp_layout.h kEmaxFeats (this translation unit is width-agnostic and does not include the layout's namespace)
+constexpr int kOldInts = 20, kDutyInts = 4, kDuties = 5, kDumpFrag = 34, kPairs = 8;
 
 struct Wgrad9Params {
   const char* dpre;
   const char* acts;
+  const uint4* emax;  // table of exponent maxima behind the dpre workspace: one 16-byte entry per 4 tiles (mlp_layout.h)
   const int* blocks;  // planned job table (mlp_layout.h kWgTableInts ints per block)
   const int* loads;   // load_ints ints per block; ints 20.. = the duty table
   float* partial;
@@ -58,7 +62,7 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   // fetched at once (one memory latency instead of three dependent ones); the row confirms the guess -- any other plan falls back to a
   // search (one lane per table row, one ballot) and fetches again
   int blk;
-  int d[kWgTableInts], du[kDuties * kDutyInts], scan[2 * kScanEntries + 1], raw0[kDutyInts];
+  int d[kWgTableInts], du[kDuties * kDutyInts], pairs[kPairs + 1];  // pairs[]: exponent group of each 32-row pair; [kPairs]: the quadrant mask
   auto fetch_tables = [&](int b) {
     const int* row = prm.blocks + kWgTableInts * b;
     const int* lt = prm.loads + (long)b * prm.load_ints + kOldInts;
@@ -67,9 +71,31 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
 #pragma unroll
     for (int i = 0; i < kDuties * kDutyInts; ++i) du[i] = lt[wave * kDuties * kDutyInts + i];
 #pragma unroll
-    for (int i = 0; i < kDutyInts; ++i) raw0[i] = lt[4 * kDutyInts + i];  // wave 0's raw duty (a bf16 row fragment, if the block has one)
+    for (int i = 0; i < kPairs + 1; ++i) pairs[i] = lt[4 * kDuties * kDutyInts + i];
+  };
+  // the entries of the exponent-maxima table that cover tiles [first, last]: lane i takes entries first / 4 + i, + 64, ...; folded byte-wise
+  // (a u16 maximum orders by the HIGH byte, so pk_max tracks bytes 1 and 3 of a dword exactly in the high bytes of its halves; the same
+  // on the dword shifted left by 8 tracks bytes 0 and 2): mx[2 k] / mx[2 k + 1] = odd / even bytes of dword k
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  u16x2 mx[8];
+  auto fetch_emax = [&](long first, long last) {
 #pragma unroll
-    for (int i = 0; i < 2 * kScanEntries + 1; ++i) scan[i] = lt[4 * kDuties * kDutyInts + i];
+    for (int k = 0; k < 8; ++k) mx[k] = u16x2{0, 0};
+    for (long e = first / 4 + lane; e <= last / 4; e += 64) {
+      const uint4 w = prm.emax[e];
+      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        mx[2 * k] = __builtin_elementwise_max(mx[2 * k], __builtin_bit_cast(u16x2, ww[k]));
+        mx[2 * k + 1] = __builtin_elementwise_max(mx[2 * k + 1], __builtin_bit_cast(u16x2, ww[k] << 8));
+      }
+    }
+  };
+  auto slice_of = [&](int n_slices, int sl, long& first, long& last) {  // tiles [first, last] of slice sl of n_slices; false: empty
+    const long per = (prm.n_tiles + n_slices - 1) / n_slices;
+    first = (long)sl * per, last = first + per - 1;
+    if (last > prm.n_tiles - 1) last = prm.n_tiles - 1;
+    return first <= last;
   };
   int slice;  // this workgroup's slice of the block: partial block d[kWgFirstSlice] + slice
   {
@@ -81,6 +107,11 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
     else if (idx < q * prm.n_blocks) blk = idx % prm.n_blocks, slice = idx / prm.n_blocks;
     else blk = idx - q * prm.n_blocks, slice = q;
     fetch_tables(blk);
+    {  // the slice's entries of the exponent maxima, on the same guess (in flight together with the tables)
+      long first, last;
+      if (q > 0 && slice_of(q + (blk < r ? 1 : 0), slice, first, last)) fetch_emax(first, last);
+      else fetch_emax(1, 0);
+    }
     // the arithmetic numbering is valid only if EVERY block has q (+ 1 for the first r) slices: all workgroups take the same decision from
     // the whole table (one lane per row, fetched alongside the tables above)
     bool equal_split = q > 0;
@@ -101,6 +132,9 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
       blk = __builtin_amdgcn_readfirstlane(blk);
       fetch_tables(blk);
       slice = idx - d[kWgFirstSlice];
+      long first, last;
+      if (slice_of(d[kWgSlices], slice, first, last)) fetch_emax(first, last);
+      else fetch_emax(1, 0);
     }
   }
   const int nr = d[1] + d[3], nc = d[5] + d[7];
@@ -109,8 +143,10 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   const long t_begin = (long)slice * tiles_per_split;
   long t_end = t_begin + tiles_per_split;
   if (t_end > prm.n_tiles) t_end = prm.n_tiles;
-  uint32_t nt = t_end > t_begin ? (uint32_t)(t_end - t_begin) : 0u;
-  const uint32_t tleft = t_begin < prm.n_tiles ? (uint32_t)(prm.n_tiles - 1 - t_begin) : 0u;
+  // (every value the slice loop takes as a scalar operand is forced into an SGPR: the table reads above are scalar loads only as long as
+  // the compiler can prove them uniform, and an "s" operand held in a VGPR is passed in that VGPR without a diagnostic)
+  uint32_t nt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t_end > t_begin ? (uint32_t)(t_end - t_begin) : 0u));
+  const uint32_t tleft = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t_begin < prm.n_tiles ? (uint32_t)(prm.n_tiles - 1 - t_begin) : 0u));
   const long t0 = t_begin < prm.n_tiles ? t_begin : 0;
 
   // ---- this wave's duties -> wave-uniform bases -------------------------------------------------------------------------------
@@ -124,13 +160,17 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
     const int src = __builtin_amdgcn_readfirstlane(du[kDutyInts * k]), unit = __builtin_amdgcn_readfirstlane(du[kDutyInts * k + 1]);
     const int dst = __builtin_amdgcn_readfirstlane(du[kDutyInts * k + 2]), sc = __builtin_amdgcn_readfirstlane(du[kDutyInts * k + 3]);
     const char* ws = src == 1 ? prm.dpre : prm.acts;
-    base[k] = (uint64_t)(uintptr_t)(ws + (long)unit * 1024);
-    if (k < 4) sbase[k] = (uint64_t)(uintptr_t)(ws + (long)(sc >> 4) * 1024 + (sc & 15));
+    auto uni64 = [](uint64_t v) {
+      return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    };
+    base[k] = uni64((uint64_t)(uintptr_t)(ws + (long)unit * 1024));
+    if (k < 4) sbase[k] = uni64((uint64_t)(uintptr_t)(ws + (long)(sc >> 4) * 1024 + (sc & 15)));
     wb[k] = ring + (uint32_t)dst * kFrag9;
     on[k] = dst != kDumpFrag;
     if (k == 4) raw_src = src;
   }
-  const uint32_t strd = (uint32_t)prm.dk * 1024u, stra = (uint32_t)prm.ak * 1024u, strx = raw_src == 1 ? strd : stra;
+  const uint32_t strd = (uint32_t)__builtin_amdgcn_readfirstlane(prm.dk * 1024), stra = (uint32_t)__builtin_amdgcn_readfirstlane(prm.ak * 1024);
+  const uint32_t strx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(raw_src == 1 ? strd : stra));
   // rotated image (as wgrad8): LDS position `lane` of a fragment holds source lane src_unit's 16 bytes, so that the transposed reads
   // spread over the banks; every global load fetches that lane's bytes, every LDS write goes to lane * 16
   const uint32_t src_unit = lane < 32 ? lane : 32 + ((lane - 8) & 31);
@@ -150,119 +190,56 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   const uint32_t aofl = (uint32_t)(4 * wr + 2 * wc) * kPair9, aofh = (uint32_t)(4 * wr + ((2 * wc + 2) & 3)) * kPair9;
   const uint32_t bof = (uint32_t)(8 + 4 * wc) * kPair9;
 
-  // ---- fp16 range: the largest MX8 exponent / bf16 exponent of the rows (and of MX8 columns) over this workgroup's slice ----------
+  // ---- fp16 range per row pair (and of MX8 columns) over this workgroup's slice: the byte-wise maxima over the lanes' entries ----------
   // a value is < 2^(E - 126) for an MX8 lane with exponent byte E and for a bf16 with biased exponent E alike
 #ifdef SR_W9_TIMING
   const uint64_t tk1 = __builtin_amdgcn_s_memrealtime() + (uint64_t)(d[0] & 0);  // (after the tables have arrived)
 #endif
-  uint32_t er = 0, ec = 0;
-  {
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    // the block's scan list (ints 100.. of its load-table row): where its MX8 exponent bytes live.  Wave w takes the tiles = w (mod 4) of
-    // the slice; all of an entry's loads (one 16-byte lane slot per tile) are in flight at once.
-    const uint32_t n_mine = nt > (uint32_t)wave ? (nt - (uint32_t)wave + 3u) / 4u : 0u;  // tiles wave, wave + 4, ...
-    // byte-wise running maximum without unpacking: a u16 maximum orders by the HIGH byte first, so pk_max(m, x) tracks bytes 1 and 3
-    // exactly (in the high bytes of m's halves) and pk_max(m', x << 8) bytes 0 and 2
-    auto bytes_max = [](u16x2& mh, u16x2& ml, uint32_t x) {
-      mh = __builtin_elementwise_max(mh, __builtin_bit_cast(u16x2, x));
-      ml = __builtin_elementwise_max(ml, __builtin_bit_cast(u16x2, x << 8));
-    };
-    auto top_byte = [](u16x2 mh, u16x2 ml) {
-      const uint32_t a = mh[0] > mh[1] ? mh[0] : mh[1], b = ml[0] > ml[1] ? ml[0] : ml[1];
-      return (a > b ? a : b) >> 8;
-    };
-    constexpr int kPass = 32;  // tiles of a wave per pass: one pass covers a slice of up to 128 tiles (65,536 points over 18 slices: 114)
-    // loads of one entry: wave-uniform tile base (scalar arithmetic) + the lane's 16 bytes; clamped, not predicated
-    auto fetch = [&](const char* ws, uint32_t unit, uint32_t stride, uint32_t jb, uint4 (&w)[kPass]) {
 #pragma unroll
-      for (int j = 0; j < kPass; ++j) {
-        const uint32_t jj = jb + j < n_mine ? jb + j : n_mine - 1;
-        const char* pt = ws + (uint64_t)unit * 1024 + (uint64_t)((uint32_t)t0 + (uint32_t)wave + 4u * jj) * stride;
-        w[j] = *reinterpret_cast<const uint4*>(pt + lane16);
-      }
-    };
-    for (int i = 0; i < kScanEntries && n_mine > 0; ++i) {
-      const int e0 = __builtin_amdgcn_readfirstlane(scan[2 * i]), e1 = __builtin_amdgcn_readfirstlane(scan[2 * i + 1]);
-      if (e0 == 0) break;
-      const char* ws = (e0 & 255) == 1 ? prm.dpre : prm.acts;
-      const uint32_t stride = (e0 & 255) == 1 ? strd : stra;
-      uint32_t mk[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t nib = ((uint32_t)e1 >> (4 * k)) & 15u;
-        mk[k] = (nib & 1u ? 0xffu : 0u) | (nib & 2u ? 0xff00u : 0u) | (nib & 4u ? 0xff0000u : 0u) | (nib & 8u ? 0xff000000u : 0u);
-      }
-      u16x2 mh = {0, 0}, ml = {0, 0};
-      for (uint32_t jb = 0; jb < n_mine; jb += kPass) {
-        uint4 w[kPass];
-        fetch(ws, (uint32_t)e0 >> 8, stride, jb, w);
-        if (mk[0]) {  // (wave-uniform: one branch per dword of the slot, not per element)
-#pragma unroll
-          for (int j = 0; j < kPass; ++j) bytes_max(mh, ml, w[j].x & mk[0]);
-        }
-        if (mk[1]) {
-#pragma unroll
-          for (int j = 0; j < kPass; ++j) bytes_max(mh, ml, w[j].y & mk[1]);
-        }
-        if (mk[2]) {
-#pragma unroll
-          for (int j = 0; j < kPass; ++j) bytes_max(mh, ml, w[j].z & mk[2]);
-        }
-        if (mk[3]) {
-#pragma unroll
-          for (int j = 0; j < kPass; ++j) bytes_max(mh, ml, w[j].w & mk[3]);
-        }
-      }
-      const uint32_t e = top_byte(mh, ml);
-      if ((e1 >> 16) & 1) ec = ec > e ? ec : e;
-      else er = er > e ? er : e;
-    }
-    // a bf16 row fragment (d_sigma_pre / d_head) is wave 0's raw duty: every wave scans its share of it.  |value| is ordered by the low
-    // 15 bits of each half, exponent = bits 14:7
-    const int r_src = __builtin_amdgcn_readfirstlane(raw0[0]), r_unit = __builtin_amdgcn_readfirstlane(raw0[1]);
-    if (r_src == 1 && __builtin_amdgcn_readfirstlane(raw0[2]) != kDumpFrag && n_mine > 0) {
-      u16x2 m = {0, 0};
-      for (uint32_t jb = 0; jb < n_mine; jb += kPass) {
-        uint4 w[kPass];
-        fetch(prm.dpre, (uint32_t)r_unit, strd, jb, w);
-#pragma unroll
-        for (int j = 0; j < kPass; ++j) {
-          const uint32_t ww[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
-#pragma unroll
-          for (int k = 0; k < 4; ++k) m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2, ww[k] & 0x7fff7fffu));
-        }
-      }
-      const uint32_t eb = (uint32_t)(m[0] > m[1] ? m[0] : m[1]) >> 7;
-      er = er > eb ? er : eb;
-    }
+  for (int k = 0; k < 8; ++k) {
 #pragma unroll
     for (int sh = 32; sh >= 1; sh >>= 1) {
-      const uint32_t o = (uint32_t)__shfl_xor((int)er, sh), p = (uint32_t)__shfl_xor((int)ec, sh);
-      er = er > o ? er : o, ec = ec > p ? ec : p;
+      const uint32_t o = (uint32_t)__shfl_xor((int)__builtin_bit_cast(uint32_t, mx[k]), sh);
+      mx[k] = __builtin_elementwise_max(mx[k], __builtin_bit_cast(u16x2, o));
     }
-    uint32_t* red = reinterpret_cast<uint32_t*>(lds);
-    if (lane == 0) red[2 * wave] = er, red[2 * wave + 1] = ec;
-    __syncthreads();
-    er = ec = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      er = er > red[2 * w] ? er : red[2 * w], ec = ec > red[2 * w + 1] ? ec : red[2 * w + 1];
-    }
-    er = (uint32_t)__builtin_amdgcn_readfirstlane((int)er), ec = (uint32_t)__builtin_amdgcn_readfirstlane((int)ec);
-    if (tid < kSlots9) reinterpret_cast<uint32_t*>(lds + kSlots9 * kSlot9)[tid] = 0u;  // the slots' publish counters (gen/wgrad9_loop.py)
-    __syncthreads();  // the reduction scratch is the first LDS slot
-    er = er < 32u ? 32u : er > 254u ? 254u : er;  // (gradients below 2^-94 are zero for every purpose; keeps the scales normal floats)
-    ec = ec < 32u ? 32u : ec > 254u ? 254u : ec;
   }
-  // rows: value * G, G = 2^(138 - er); the stream forms the fp16 scale of a lane as exponent field E - erow.  Everything handed to the
-  // stream as a scalar is made one explicitly: an "s" operand fed a value the compiler holds in a VGPR is silently passed in that VGPR,
-  // which may be one of the statement's output registers (the stream zeroes them first)
-  const uint32_t erow = (uint32_t)__builtin_amdgcn_readfirstlane((int)(er - 20u)), ecol = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ec - 20u));
-  const uint32_t g_row_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)((265u - er) << 23));
-  const uint32_t g_col_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)(col_mx ? (265u - ec) << 23 : 0x3f800000u));
-  const float g_row = __builtin_bit_cast(float, g_row_bits), g_col = __builtin_bit_cast(float, g_col_bits);
-  const uint32_t sraw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(raw_src == 1 ? g_row_bits : 0x3f800000u));  // the raw fragment: a dpre row (x G) or the aux columns (x 1)
-  const float un_row = 1.0f / g_row, un_col = 1.0f / g_col;  // (powers of two: exact)
+  auto emax_of = [&](int g) -> uint32_t {  // byte g of the folded entry (g wave-uniform; < 0: no such pair); clamped: gradients below
+    uint32_t w = 0;                        // 2^-94 are zero for every purpose, and the scales stay normal floats
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w = (g >> 2) == (k >> 1) && ((g & 1) != (k & 1)) ? __builtin_bit_cast(uint32_t, mx[k]) : w;
+    uint32_t e = g < 0 ? 0u : (g & 2) ? w >> 24 : (w >> 8) & 0xffu;
+    e = e < 32u ? 32u : e > 254u ? 254u : e;
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
+  };
+  uint32_t ep[kPairs];  // Emax of row pair p
+#pragma unroll
+  for (int p = 0; p < kPairs; ++p) ep[p] = emax_of(__builtin_amdgcn_readfirstlane(pairs[p]));
+  const uint32_t ec = emax_of(kEmaxFeatsByte);
+  auto pair_emax = [&](int p) -> uint32_t {  // (p wave-uniform)
+    uint32_t e = ep[0];
+#pragma unroll
+    for (int k = 1; k < kPairs; ++k) e = p == k ? ep[k] : e;
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
+  };
+  if (tid < kSlots9) reinterpret_cast<uint32_t*>(lds + kSlots9 * kSlot9)[tid] = 0u;  // the slots' publish counters (gen/wgrad9_loop.py)
+  __syncthreads();
+  // rows of pair p: value * G_p, G_p = 2^(138 - Emax_p); the stream forms the fp16 scale of a lane as exponent field E - erow.  Everything
+  // handed to the stream as a scalar is made one explicitly: an "s" operand fed a value the compiler holds in a VGPR is silently passed in
+  // that VGPR, which may be one of the statement's output registers (the stream zeroes them first)
+  auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+  // this wave's two row duties decode into LDS fragments (wb - ring) / kFrag9: pair = fragment / 2 (a dump duty: any scale will do)
+  const int dpair0 = __builtin_amdgcn_readfirstlane(du[2]) >> 1, dpair1 = __builtin_amdgcn_readfirstlane(du[kDutyInts + 2]) >> 1;
+  const int dpairx = __builtin_amdgcn_readfirstlane(du[4 * kDutyInts + 2]) >> 1;  // ... and the raw duty, when it is a dpre row
+  const uint32_t erow0 = uni(pair_emax(dpair0 < kPairs ? dpair0 : 0) - 20u), erow1 = uni(pair_emax(dpair1 < kPairs ? dpair1 : 0) - 20u);
+  const uint32_t ecol = uni(ec - 20u);
+  const uint32_t g_col_bits = uni(col_mx ? (265u - ec) << 23 : 0x3f800000u);
+  const float g_col = __builtin_bit_cast(float, g_col_bits);
+  // the raw fragment: a dpre row (x G of its pair) or the aux columns (x 1)
+  const uint32_t sraw = uni(raw_src == 1 ? (265u - pair_emax(dpairx < kPairs ? dpairx : 0)) << 23 : 0x3f800000u);
+  const float un_col = 1.0f / g_col;  // (powers of two: exact)
+  float un_row[4];                    // accumulator row tile a of this wave = pair 4 wr + ((a + 2 wc) & 3)
+#pragma unroll
+  for (int a = 0; a < 4; ++a) un_row[a] = __builtin_bit_cast(float, uni((pair_emax(4 * wr + ((a + 2 * wc) & 3)) - 11u) << 23));  // 2^(Emax - 138)
 
   const uint32_t flags = ring + (uint32_t)(kSlots9 * kSlot9);
   f32x32w c0, c1, c2, c3, c4, c5, c6, c7, cx;
@@ -283,11 +260,11 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   "{v240}"(rdo[0]), "{v241}"(rdo[1]), "{v242}"(lane16), "{v243}"(vd), "{v244}"(va), "{v245}"(vx), [b0] "s"(base[0]), [b1] "s"(base[1]), \
       [b2] "s"(base[2]), [b3] "s"(base[3]), [bx] "s"(base[4]), [sb0] "s"(sbase[0]), [sb1] "s"(sbase[1]), [sb2] "s"(sbase[2]),        \
       [sb3] "s"(sbase[3]), [w0] "s"(wb[0]), [w1] "s"(wb[1]), [w2] "s"(wb[2]), [w3] "s"(wb[3]), [wx] "s"(wb[4]), [aofl] "s"(aofl),    \
-      [aofh] "s"(aofh), [bof] "s"(bof), [strd] "s"(strd), [stra] "s"(stra), [strx] "s"(strx), [tleft] "s"(tleft), [erow] "s"(erow),   \
-      [ecol] "s"(ecol), [sraw] "s"(sraw), [flags] "s"(flags)
+      [aofh] "s"(aofh), [bof] "s"(bof), [strd] "s"(strd), [stra] "s"(stra), [strx] "s"(strx), [tleft] "s"(tleft), [erow0] "s"(erow0), \
+      [erow1] "s"(erow1), [ecol] "s"(ecol), [sraw] "s"(sraw), [flags] "s"(flags)
   // a wave whose 128 x 128 quadrant nobody reads (narrow blocks: packing.wgrad9_duties' quadrant mask) runs the stream without the 32
   // main MFMAs and their operand reads: same loads, decode, rendezvous, aux tiles -- the time of a tile is unchanged, its energy is not
-  const bool quad_on = (__builtin_amdgcn_readfirstlane(scan[2 * kScanEntries]) >> wave) & 1;
+  const bool quad_on = (__builtin_amdgcn_readfirstlane(pairs[kPairs]) >> wave) & 1;
   if (col_mx && quad_on) {
     asm volatile(
 #include SR_W9_M_INC
@@ -350,7 +327,7 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const int row = row0 + (g & 3) + 8 * (g >> 2) + 4 * hh;
-        out[row * 256 + col] = (*cc[2 * a + (c >> 1)])[16 * (c & 1) + g] * un_row * un_col;
+        out[row * 256 + col] = (*cc[2 * a + (c >> 1)])[16 * (c & 1) + g] * un_row[a] * un_col;
       }
     }
   }
@@ -362,7 +339,7 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int row = row0 + (g & 3) + 8 * (g >> 2) + 4 * hh;
-      oa[row * 32 + (lane & 31)] = cx[16 * a + g] * un_row;
+      oa[row * 32 + (lane & 31)] = cx[16 * a + g] * un_row[a];
     }
   }
 #ifdef SR_W9_TIMING
@@ -377,24 +354,17 @@ bool wgrad9_fits(long n_tiles, int ak, int dk) {
   return n_tiles * big * 1024l < (1l << 32);
 }
 
-int launch_wgrad9(const uint4* dpre, const uint4* acts, const int* blocks, const int* loads, float* partial, long n_tiles, int n_blocks,
-                  int ak, int dk, int load_ints, int n_slices, hipStream_t st) {
+int launch_wgrad9(const uint4* dpre, const uint4* acts, const uint4* emax, const int* blocks, const int* loads, float* partial, long n_tiles,
+                  int n_blocks, int ak, int dk, int load_ints, int n_slices, hipStream_t st) {
   Wgrad9Params p;
-  p.dpre = (const char*)dpre, p.acts = (const char*)acts, p.blocks = blocks, p.loads = loads, p.partial = partial;
+  p.dpre = (const char*)dpre, p.acts = (const char*)acts, p.emax = emax, p.blocks = blocks, p.loads = loads, p.partial = partial;
   p.n_tiles = n_tiles, p.n_blocks = n_blocks, p.ak = ak, p.dk = dk, p.load_ints = load_ints;
   p.dbg = nullptr;
 #ifdef SR_W9_TIMING  // timing builds only (tools/ab_wgrad8.py passes the address of its stamp buffer): a product build never takes a pointer from the environment
   if (const char* dbg = getenv("SR_W9_DBG")) p.dbg = (long long*)strtoull(dbg, nullptr, 10);
 #endif
   const size_t lds = (size_t)kSlots9 * kSlot9 + 16;  // four operand slots + their publish counters
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)wgrad9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      set_error("hipFuncSetAttribute(max dynamic LDS = %zu) failed", lds);
-      return 1;
-    }
-    attr_set = true;
-  }
+  if (!ensure_dynamic_lds((const void*)wgrad9_kernel, lds)) return 1;
   hipLaunchKernelGGL(wgrad9_kernel, dim3(n_slices), dim3(256), lds, st, p);
   return check_launch("wgrad9_kernel");
 }

@@ -401,8 +401,10 @@ def acts_workspace(n_points, feat, device, fmt=16):
 def satnerf_mlp_bwd(feat, tau, n_points, bwd_stream, acts, albedo, sigma, sun_v, beta, g_albedo, g_sigma, g_sun_v, g_beta, want_dt=True, fmt=16):
     """dX chain: returns (dpre workspace, d_t (P,tau) or None); ``fmt`` = format of ``acts`` and of the returned workspace."""
     dev = albedo.device
-    per_tile = _lib.lib().sr_dpre_elems_per_tile(feat, int(fmt))
-    dpre = _ws_empty(_lib.lib().sr_workspace_tiles(n_points) * per_tile, torch.int16, dev, 2)
+    n_elems = _lib.lib().sr_dpre_workspace_elems(n_points, feat, int(fmt))  # (8-bit: + the table of exponent maxima behind the last tile)
+    if n_elems <= 0:
+        raise ValueError(f"unsupported workspace (feat={feat}, fmt={fmt})")
+    dpre = _ws_empty(n_elems, torch.int16, dev, 2)
     d_t = torch.empty(n_points, tau, dtype=torch.float32, device=dev) if want_dt else None
     opt = lambda t, nm: _p(_chk(t, nm, allow_none=True))  # noqa: E731
     ev = kernel_timer.span("mlp_bwd") if kernel_timer is not None else None

@@ -329,7 +329,9 @@ def backward_maps(feat=256, tau=4):
         for l in range(1, 8):
             todo.append(([(16 * l, 16)], [(a_frag(l - 1), 16)], KIND_PHASE, None))
         todo.append(([(DP_FEATS, 16)], [(a_frag(7), 16)], KIND_PHASE, "a7"))                          # feats_from_xyz
-        todo.append(([(DP_SIGMA, 1), (0, 8)], [(a_frag(7), 16)], KIND_PHASE, "a7"))                   # sigma head + first half of fc_net.0 (aux columns only)
+        # first half of fc_net.0 (aux columns only) + the sigma head.  Every 32-row pair of a block holds ONE double fragment or ONE raw
+        # bf16 fragment: the 4-wave kernel fits fp16's range per pair (wgrad9_pair_groups), so the lone sigma fragment sits in a pair of its own
+        todo.append(([(0, 8), (DP_SIGMA, 1)], [(a_frag(7), 16)], KIND_PHASE, "a7"))
         todo.append(([(DP_RGBH, 16)], [(ACT_FEATS, 16)], KIND_BF16, "feats"))                         # rgb hidden + sun hidden 1
         todo.append(([(DP_RGBH + 16, 8), (8, 8)], [(ACT_FEATS, 16)], KIND_BF16, "feats"))             # beta hidden + second half of fc_net.0
         todo.append(([(DP_S2, 8), (DP_S3, 8)], [(ACT_S1, 8), (ACT_S2, 8)], KIND_PHASE, None))         # sun hidden 2 and 3
@@ -442,7 +444,8 @@ SRC_DPRE, SRC_ACTS = 1, 2
 RAW16, PHASE8, MX8 = 0, 1, 2
 WG8_OLD_INTS = 20          # load table of the 16- / 8-wave kernels (wgrad8.hip, wgrad8f.hip)
 WG9_DUTY_INTS = 4 * 5 * 4  # duty table of the 4-wave kernel (wgrad9.hip): 4 waves x 5 duties x (source, unit, LDS fragment, scale)
-WG9_SCAN_INTS = 8          # ... + 4 x (source | unit << 8, byte mask | is_column << 16): where the block's MX8 exponent bytes live (range scan)
+WG9_SCAN_INTS = 8          # ... + the exponent group (byte of an entry of the dX kernel's table of exponent maxima) of each of the block's 8 row pairs; -1 = none
+EMAX_FEATS, EMAX_RAW = 14, 15   # ... bytes 0..13 = the dpre scale groups (mlp_layout.h), 14 = the saved feats (columns of the MX8 blocks), 15 = the bf16 rows d_sigma_pre / d_head
 WG9_MASK_INTS = 1          # ... + the mask of the 128 x 128 quadrants (bit = wave = 2 row half + column half) somebody reads
 WG8_LOAD_INTS = WG8_OLD_INTS + WG9_DUTY_INTS + WG9_SCAN_INTS + WG9_MASK_INTS
 WG9_DUMP_FRAG = 34         # LDS fragment an unused duty decodes into (csrc/gen/wgrad9_loop.py: 16 rows + 16 columns + 2 aux + 2 dump)
@@ -473,9 +476,9 @@ def dpre8_source(f, feat=256):
     """Logical dpre fragment -> dict(unit, codec, half[, scale_unit, scale_byte]) in the 8-bit layout."""
     g8 = fmt8_geometry(feat)
     if f == g8["DP_SIGMA"]:
-        return dict(unit=g8["D8_SIGMA"], codec=RAW16, half=0)
+        return dict(unit=g8["D8_SIGMA"], codec=RAW16, half=0, group=EMAX_RAW)
     if f == g8["DP_HEAD"]:
-        return dict(unit=g8["D8_HEAD"], codec=RAW16, half=0)
+        return dict(unit=g8["D8_HEAD"], codec=RAW16, half=0, group=EMAX_RAW)
     if f < g8["DP_SIGMA"]:
         u, half = f >> 1, f & 1
         g, k = u // g8["MT"], u % g8["MT"]                 # trunk layers 0..7, d_feats = 8
@@ -484,7 +487,7 @@ def dpre8_source(f, feat=256):
         h = u - 9 * g8["MT"]
         g, k = 9 + h // g8["MTH"], h % g8["MTH"]
     gpu = g8["GROUPS_PER_UNIT"]
-    return dict(unit=u, codec=MX8, half=half, scale_unit=g8["D8_SCALE"] + g // gpu, scale_byte=(g % gpu) * g8["MT"] + k)
+    return dict(unit=u, codec=MX8, half=half, scale_unit=g8["D8_SCALE"] + g // gpu, scale_byte=(g % gpu) * g8["MT"] + k, group=g)
 
 
 def act8_source(f, auxs, feat=256):
@@ -537,21 +540,7 @@ def wgrad8_loads(feat=256, tau=4):
             out[b, 16 + k] = src | (unit << 4)
     duties = wgrad9_duties(feat, tau)
     out[:, WG8_OLD_INTS:WG8_OLD_INTS + WG9_DUTY_INTS] = duties
-    # scan list: the distinct (source, scale unit) of the enabled MX8 duties with the mask of their bytes in the lane's 16; rows and columns apart
-    for b in range(out.shape[0]):
-        ent = {}
-        for w in range(4):
-            for k in range(4):
-                src, unit, dst, sc = duties[b].reshape(4, 5, 4)[w, k]
-                is_col = k >= 2
-                if dst == WG9_DUMP_FRAG or (is_col and bm["blocks"][b, 8] != KIND_BF16):
-                    continue
-                key = (int(src), int(sc) >> 4, is_col)
-                ent[key] = ent.get(key, 0) | (1 << (int(sc) & 15))
-        assert len(ent) <= WG9_SCAN_INTS // 2, (b, ent)
-        for i, ((src, unit, is_col), mask) in enumerate(sorted(ent.items())):
-            out[b, WG8_OLD_INTS + WG9_DUTY_INTS + 2 * i] = src | (unit << 8)
-            out[b, WG8_OLD_INTS + WG9_DUTY_INTS + 2 * i + 1] = mask | (int(is_col) << 16)
+    out[:, WG8_OLD_INTS + WG9_DUTY_INTS:WG8_OLD_INTS + WG9_DUTY_INTS + WG9_SCAN_INTS] = wgrad9_pair_groups(feat, tau)
     # quadrant mask: which (row half, column half) of each 256 x 256 block holds a gradient the scatter map reads
     g = bm["gidx"][bm["gidx"] >= 0].astype(np.int64)
     blk, w = g // WG_BLOCK_FLOATS, g % WG_BLOCK_FLOATS
@@ -559,6 +548,30 @@ def wgrad8_loads(feat=256, tau=4):
     quad = 2 * ((w[main] // 256) // 128) + (w[main] % 256) // 128
     for b, q in zip(blk[main], quad):
         out[b, WG8_OLD_INTS + WG9_DUTY_INTS + WG9_SCAN_INTS] |= 1 << int(q)
+    return out
+
+
+@functools.lru_cache(maxsize=8)
+def wgrad9_pair_groups(feat=256, tau=4):
+    """int32 [n_blocks, 8]: the exponent group of each 32-row pair of a block's row operand (-1 = the block has no such pair).
+
+    csrc/wgrad9.hip contracts fp16 operands; fp16's range is fitted PER ROW PAIR (= per 32 x 32 accumulator tile): rows are decoded times
+    2^(138 - Emax) where Emax is the largest exponent of the pair's source over the workgroup's slice of points, read from the table the dX
+    kernel leaves behind the dpre workspace (one byte per group and 4 tiles; mlp_layout.h).  That needs every pair to have ONE source:
+    a double fragment at an even fragment position or a raw bf16 fragment alone -- asserted here."""
+    bm = backward_maps(feat, tau)
+    out = np.full((len(bm["block_rows"]), WG9_SCAN_INTS), -1, np.int32)
+    for b, rows in enumerate(bm["block_rows"]):
+        pos = 0
+        while pos < len(rows):
+            d = dpre8_source(rows[pos], feat)
+            assert pos % 2 == 0, (b, rows, "a row operand must start a 32-row pair")
+            out[b, pos // 2] = d["group"]
+            if d["codec"] == RAW16:
+                assert pos + 1 == len(rows), (b, rows, "a raw row fragment must be the last of its block")
+                pos += 1
+            else:
+                pos += 2
     return out
 
 

@@ -355,8 +355,11 @@ def _decoded(mem, base, unit_off, codec, scale_addr, g_bits):
     return out
 
 
-@pytest.mark.parametrize("blk,nt", [(2, 6), (1, 5), (8, 3)])
-def test_stream_computes_the_block_contraction(blk, nt):
+@pytest.mark.parametrize("blk,nt,spread", [(2, 6, 0), (1, 5, 0), (8, 3, 0), (1, 4, 44), (9, 3, 30)])
+def test_stream_computes_the_block_contraction(blk, nt, spread):
+    """``spread`` > 0: the exponent bytes of the block's SECOND row group lie that many binades below the first one's (two layers of very
+    different gradient scale sharing a block): with one Emax per block those rows would flush to zero; the range is fitted
+    per 32-row pair, and every accumulator row tile is checked against ITS OWN largest entry."""
     g = _gen()
     rng = np.random.default_rng(10 * blk + nt)
     loads = packing.wgrad8_loads(256, 4)
@@ -373,6 +376,13 @@ def test_stream_computes_the_block_contraction(blk, nt):
     for t in range(n_tiles):
         for u in range(g8["D8_SCALE"], g8["D8_UNITS"]):
             mem[D0 + (t * dk + u) * 1024: D0 + (t * dk + u + 1) * 1024] = rng.integers(96, 112, 1024, dtype=np.uint8)
+        if spread:   # the scale group of the block's last MX8 row pair: `spread` binades down (its 8 bytes of every lane's 16)
+            pg = packing.wgrad9_pair_groups(256, 4)[blk]
+            low = [int(x) for x in pg if 0 <= x < 14][-1]
+            assert low != int(pg[0])
+            u, b0 = g8["D8_SCALE"] + low // g8["GROUPS_PER_UNIT"], (low % g8["GROUPS_PER_UNIT"]) * g8["MT"]
+            unit = mem[D0 + (t * dk + u) * 1024: D0 + (t * dk + u + 1) * 1024].reshape(64, 16)
+            unit[:, b0:b0 + g8["MT"]] = rng.integers(96 - spread, 112 - spread, (64, g8["MT"]), dtype=np.uint8)
         u = 1 + g8["A8_SCALE"]
         mem[A0 + (t * ak + u) * 1024: A0 + (t * ak + u + 1) * 1024] = rng.integers(118, 130, 1024, dtype=np.uint8)
         def put_bf16(addr, lo, hi):
@@ -386,7 +396,9 @@ def test_stream_computes_the_block_contraction(blk, nt):
     lds = np.zeros(4 * slot_b + 16, np.uint8)
     lds[:] = rng.integers(0, 256, lds.size, dtype=np.uint8)   # stale LDS content must not matter ...
     lds[4 * slot_b:] = 0                                       # ... except the publish counters, which the kernel zeroes
-    er = ec = 0
+    # fp16 range per 32-row pair: the largest exponent of the pair's source over the slice (what the dX kernel's table of exponent maxima
+    # delivers per scale group; here taken from the bytes themselves), columns likewise when they are MX8
+    pair_e, ec = {}, 0
     for w in range(4):
         for k in range(4):
             src, unit, dst, sc = (int(x) for x in duties[w, k])
@@ -395,14 +407,24 @@ def test_stream_computes_the_block_contraction(blk, nt):
             base = D0 if src == 1 else A0
             stride = (dk if src == 1 else ak) * 1024
             e = max(int(mem[base + t * stride + (sc >> 4) * 1024 + (sc & 15) + 16 * np.arange(64)].max()) for t in range(nt))
-            er, ec = (max(er, e), ec) if k < 2 else (er, max(ec, e))
+            if k < 2:
+                assert dst % 2 == 0
+                pair_e[dst // 2] = max(pair_e.get(dst // 2, 0), e)
+            else:
+                ec = max(ec, e)
     src0, unit0, dst0, _ = (int(x) for x in duties[0, 4])
-    if src0 == 1 and dst0 != packing.WG9_DUMP_FRAG:   # a bf16 row fragment: its largest exponent
+    if src0 == 1 and dst0 != packing.WG9_DUMP_FRAG:   # a bf16 row fragment, alone in its pair: its largest exponent
+        assert dst0 % 2 == 0 and dst0 // 2 not in pair_e
+        e = 0
         for t in range(nt):
             h = mem[D0 + (t * dk + unit0) * 1024: D0 + (t * dk + unit0 + 1) * 1024].view(np.uint16)
-            er = max(er, int((h & 0x7fff).max()) >> 7)
-    er, ec = min(max(er, 32), 254), min(max(ec, 32), 254)
-    g_row = 2.0 ** (138 - er)
+            e = max(e, int((h & 0x7fff).max()) >> 7)
+        pair_e[dst0 // 2] = e
+    clamp = lambda e: min(max(e, 32), 254)  # noqa: E731
+    pair_e = {p: clamp(e) for p, e in pair_e.items()}
+    ec = clamp(ec)
+    er_of = lambda frag: pair_e.get(frag // 2, 32)  # noqa: E731  (a dump duty: any reference)
+    g_row_of = lambda frag: 2.0 ** (138 - er_of(frag))  # noqa: E731
     g_col = 2.0 ** (138 - ec) if col_mx else 1.0
     shared = {"barrier": 0}
     s = g.Stream("mx" if col_mx else "phase", main=True)
@@ -410,12 +432,13 @@ def test_stream_computes_the_block_contraction(blk, nt):
     waves = []
     for w in range(4):
         wr, wc = w >> 1, w & 1
-        ops = {"nt": nt, "tleft": n_tiles - 1, "erow": er - 20, "ecol": ec - 20, "flags": ring + 4 * slot_b,
+        ops = {"nt": nt, "tleft": n_tiles - 1, "erow0": er_of(int(duties[w, 0, 2])) - 20, "erow1": er_of(int(duties[w, 1, 2])) - 20,
+               "ecol": ec - 20, "flags": ring + 4 * slot_b,
                "strd": dk * 1024, "stra": ak * 1024, "aofl": (4 * wr + 2 * wc) * g.PAIR, "aofh": (4 * wr + ((2 * wc + 2) & 3)) * g.PAIR,
                "bof": (8 + 4 * wc) * g.PAIR}
         raw_src = int(duties[w, 4, 0])
         ops["strx"] = ops["strd"] if raw_src == 1 else ops["stra"]
-        ops["sraw"] = int(np.float32(g_row if raw_src == 1 else 1.0).view(np.uint32))
+        ops["sraw"] = int(np.float32(g_row_of(int(duties[w, 4, 2])) if raw_src == 1 else 1.0).view(np.uint32))
         for k in range(5):
             src, unit, dst, sc = (int(x) for x in duties[w, k])
             base = D0 if src == 1 else A0
@@ -457,7 +480,7 @@ def test_stream_computes_the_block_contraction(blk, nt):
                 base = (D0 if src == 1 else A0) + t * (dk if src == 1 else ak) * 1024
                 if k == 4:   # raw bf16 fragment: 8 values per lane = slots 8 h + j of point p
                     halves = mem[base + unit * 1024: base + (unit + 1) * 1024].view(np.uint16).astype(np.uint32) << 16
-                    vals = halves.view(np.float32).astype(np.float64).reshape(64, 8) * (g_row if src == 1 else 1.0)
+                    vals = halves.view(np.float32).astype(np.float64).reshape(64, 8) * (g_row_of(dst) if src == 1 else 1.0)
                     frag = np.zeros((16, 32))
                     for lane in range(64):
                         frag[8 * (lane >> 5): 8 * (lane >> 5) + 8, lane & 31] = vals[lane]
@@ -468,7 +491,7 @@ def test_stream_computes_the_block_contraction(blk, nt):
                         rows[16 * dst: 16 * dst + 16, sl] = frag
                     continue
                 codec = "mx" if k < 2 or col_mx else "phase"
-                dec = _decoded(mem, base, unit * 1024, codec, base + (sc >> 4) * 1024 + (sc & 15), (er if k < 2 else ec) - 20)
+                dec = _decoded(mem, base, unit * 1024, codec, base + (sc >> 4) * 1024 + (sc & 15), (er_of(dst) if k < 2 else ec) - 20)
                 dec = _f16(_to_f16_bits(dec))
                 tgt, f0 = (rows, dst) if dst < 16 else (cols, dst - 16)
                 tgt[16 * f0: 16 * f0 + 16, sl], tgt[16 * f0 + 16: 16 * f0 + 32, sl] = dec[0], dec[1]
@@ -486,8 +509,9 @@ def test_stream_computes_the_block_contraction(blk, nt):
                         got_rows[(gg & 3) + 8 * (gg >> 2) + 4 * (lane >> 5), 32 * c + (lane & 31)] = wave.a[16 * (4 * a + c) + gg, lane]
             nr_, nc_ = max(min(n_rows - row0, 32), 0), max(min(n_cols - 128 * wc, 128), 0)
             if (quad >> w) & 1 and nr_ and nc_:
-                err = np.abs(got_rows[:nr_, :nc_] - want[row0: row0 + nr_, 128 * wc: 128 * wc + nc_]).max()
-                assert err < 2e-3 * scale, (w, a, err, scale)
+                ref = want[row0: row0 + nr_, 128 * wc: 128 * wc + nc_]
+                err = np.abs(got_rows[:nr_, :nc_] - ref).max()
+                assert err < 2e-3 * np.abs(ref).max(), (w, a, err, np.abs(ref).max(), scale)   # relative to the TILE's own largest entry
             if a < 2 and nr_:   # the aux tiles of operand slots 0, 1
                 got_aux = np.zeros((32, 32))
                 for gg in range(16):
