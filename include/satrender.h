@@ -172,6 +172,29 @@ int sr_satnerf_render_fwd(const sr_render_args* in, int feat, int tau, int mode,
 /* points a workgroup of the fused kernel owns (256 / 128), or -1 when (feat, mode) has no fused build */
 int sr_render_points_per_block(int feat, int mode);
 
+/* ---- the training forward in ONE launch: replaces main.py:60-75,127 + metrics.py:21-25,36-44,56-73 + autograd through the compositing ---
+ * sr_satnerf_render_train = sr_ray_setup + sr_satnerf_mlp_fwd (saving the SR_FMT8 activations) + sr_render_loss: the render pass above
+ * with, in its epilogue, the colour loss (SatNerfLoss; SNerfLoss while sched[2] != 0) and the closed-form compositing backward of every
+ * ray by the wave that composited it (same per-ray function as sr_render_loss: bit-identical to the three launches).  n_samples <= 64,
+ * SR_MODE_BF16 / SR_MODE_F16, widths 256 and 512.  `out`: albedo / sigma / sun_v / beta (N,S[,3]) and sky (N,3) are required (the dX
+ * pass and the sky head's backward read them), z_vals optional, weights / transparency / depth / rgb unused.  `train` outputs: loss_parts
+ * (one per workgroup = ceil(N * S / sr_render_points_per_block) floats: the loss is their sum), rgb (N,3) or NULL, d_sigma (N,S),
+ * d_albedo (N,S,3), d_sun_v (N,S), g_beta (N,S), d_sky (N,3).  acts: the SR_FMT8 workspace of sr_satnerf_mlp_fwd. */
+typedef struct sr_train_args {
+  const float* target;   /* (N,3) */
+  const float* sched;    /* 4-float schedule block or NULL */
+  float beta_min;
+  float* loss_parts;
+  float* rgb;
+  float* d_sigma;
+  float* d_albedo;
+  float* d_sun_v;
+  float* g_beta;
+  float* d_sky;
+} sr_train_args;
+int sr_satnerf_render_train(const sr_render_args* in, int feat, int tau, int mode, const uint16_t* stream_hi, const uint16_t* stream_lo,
+                            const float* l0, const sr_render_outputs* out, const sr_train_args* train, uint16_t* acts, int act_fmt, void* stream);
+
 /* ---- backward of the fused MLP: replaces autograd through SatNeRF.forward (models/satnerf.py:156-208) ------------
  * sr_satnerf_mlp_bwd: data-gradient chain.  Inputs: the forward's saved `acts`, its four outputs and the gradients of
  * those outputs (g_* may be NULL = 0); bwd_stream = packed transposed weights (sr_pack_stream with

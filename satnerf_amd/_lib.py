@@ -34,6 +34,11 @@ class RenderOutputs(C.Structure):
     _fields_ = [(k, _vp) for k in ("z_vals", "albedo", "sigma", "sun_v", "beta", "sky", "weights", "transparency", "depth", "rgb")]
 
 
+class TrainArgs(C.Structure):
+    _fields_ = [("target", _vp), ("sched", _vp), ("beta_min", _f), ("loss_parts", _vp), ("rgb", _vp), ("d_sigma", _vp), ("d_albedo", _vp),
+                ("d_sun_v", _vp), ("g_beta", _vp), ("d_sky", _vp)]
+
+
 class LinearSrc(C.Structure):
     _fields_ = [("x", _vp), ("ld", _i), ("k", _i), ("act", _i), ("w0", _f), ("row_div", _i)]
 
@@ -50,6 +55,7 @@ SIGNATURES = {
     "sr_act_elems_per_tile": (_i64, [_i, _i]),
     "sr_satnerf_render_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sr_render_points_per_block": (_i, [_i, _i]),
+    "sr_satnerf_render_train": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sr_pack_stream": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     "sr_dpre_elems_per_tile": (_i64, [_i, _i]),
     "sr_workspace_tiles": (_i64, [_i64]),

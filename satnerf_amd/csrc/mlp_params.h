@@ -29,9 +29,26 @@ struct RenderParams {
   long bank_chunks;        // > 0: rays / ts hold bank_chunks x n_rays rows, this launch renders chunk step_counter[0] % bank_chunks
 };
 
+// the training epilogue of the fused render pass (sr_satnerf_render_train): with target != NULL the compositing of a ray is followed, in
+// the same wave, by the colour loss and the closed-form compositing backward (ray_device.h render_loss_ray) -- the launch then writes what
+// the dX kernel consumes instead of weights / transparency
+struct TrainParams {
+  const float* target;     // (N,3) ground-truth colours, or NULL: plain render
+  const float* sched;      // device-side schedule block ([2] != 0: SNerfLoss warm-up epochs) or NULL
+  float beta_min;
+  float* loss_parts;       // one partial sum per workgroup
+  float* rgb;              // (N,3) rendered colour (logging) or NULL
+  float* d_sigma;          // (N,S)
+  float* d_albedo;         // (N,S,3)
+  float* d_sun;            // (N,S)
+  float* g_beta;           // (N,S)
+  float* d_sky;            // (N,3)
+};
+
 struct FwdParams {
   sr_mlp_inputs in;
   RenderParams rend;
+  TrainParams train;
   const char* stream_hi;
   const char* stream_lo;
   const float4* l0;

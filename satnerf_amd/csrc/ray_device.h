@@ -188,4 +188,74 @@ __device__ __forceinline__ void composite_ray(const float* z, const float* sigma
   }
 }
 
+// ---- compositing forward -> SatNerf / SNerf colour loss -> compositing backward of ONE ray by one wave (lane = sample, S <= 64) ----------
+// models/satnerf.py:52-70 + metrics.py:21-25,36-44,56-73 + their autograd (closed form).  Inputs are the ray's own rows
+// (global memory or LDS); writes what the MLP backward consumes (d_sigma, d_albedo (S,3), d_sun, g_beta per sample; d_sky (3)), optionally the
+// rendered colour, and returns (every lane) the ray's share of the batch-mean loss.  `warm` = the SNerfLoss epochs (main.py:128-131: plain
+// MSE, no uncertainty term).  Shared by sr_render_loss and the epilogue of the fused training forward: the two are bit-identical.
+__device__ __forceinline__ float render_loss_ray(const float* z, const float* sigma, const float* noise, float noise_std, const float* albedo,
+                                                 const float* sun_v, const float* beta, float k0, float k1, float k2, const float* target, long r,
+                                                 long n_rays, int S, int lane, float beta_min, bool warm, float* __restrict__ rgb_out,
+                                                 float* __restrict__ d_sigma, float* __restrict__ d_albedo, float* __restrict__ d_sun,
+                                                 float* __restrict__ g_beta, float* __restrict__ d_sky) {
+  const bool on = lane < S;
+  const int i = lane < S ? lane : S - 1;
+  // forward: alpha, transmittance, weights (models/satnerf.py:52-63)
+  float delta = 0.f, dens = 0.f, alpha = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, sv = 0.f, bj = 0.f;
+  if (on) {
+#pragma clang fp contract(off)
+    const float zj = z[i];
+    delta = lane < S - 1 ? z[i + 1] - zj : 1e10f;
+    float s = sigma[i];
+    if (noise) s = s + noise[i] * noise_std;
+    dens = s;
+    alpha = 1.0f - expf(-delta * (s > 0.f ? s : 0.f));
+    a0 = albedo[i * 3], a1 = albedo[i * 3 + 1], a2 = albedo[i * 3 + 2];
+    sv = sun_v[i], bj = beta[i];
+  }
+  float f;
+  {
+#pragma clang fp contract(off)
+    f = on ? (1.0f - alpha) + 1e-10f : 1.f;
+  }
+  const float incl = wave_scan_mul(f, lane);
+  float T = __shfl_up(incl, 1, 64);
+  if (lane == 0) T = 1.f;
+  const float w = on ? alpha * T : 0.f;
+  const float i0 = sv + (1.f - sv) * k0, i1 = sv + (1.f - sv) * k1, i2 = sv + (1.f - sv) * k2;  // irradiance, :68
+  const float c0 = wave_sum(w * a0 * i0), c1 = wave_sum(w * a1 * i1), c2 = wave_sum(w * a2 * i2);
+  const float b = wave_sum(w * bj) + beta_min;
+  const float r0 = fminf(fmaxf(c0, 0.f), 1.f), r1 = fminf(fmaxf(c1, 0.f), 1.f), r2 = fminf(fmaxf(c2, 0.f), 1.f);
+  // loss (metrics.py:21-25) and its gradient w.r.t. rgb and beta_r
+  const float inv_n = 1.0f / (float)n_rays;
+  const float e0 = r0 - target[0], e1 = r1 - target[1], e2 = r2 - target[2];
+  const float sq = e0 * e0 + e1 * e1 + e2 * e2;
+  const float ib2 = warm ? 2.0f : 1.0f / (b * b);  // metrics.SNerfLoss colour term = the same expression with beta^2 = 1/2, no log term
+  float contrib = sq * ib2 * (0.5f / 3.0f) * inv_n + (warm ? 0.f : 0.5f * logf(b) * inv_n);
+  if (r == 0 && !warm) contrib += 1.5f;
+  if (lane == 0 && rgb_out) rgb_out[0] = r0, rgb_out[1] = r1, rgb_out[2] = r2;
+  const float kk = ib2 * (1.0f / 3.0f) * inv_n;
+  const float gr0 = (c0 >= 0.f && c0 <= 1.f) ? e0 * kk : 0.f;  // torch.clamp passes the gradient where min <= x <= max
+  const float gr1 = (c1 >= 0.f && c1 <= 1.f) ? e1 * kk : 0.f;
+  const float gr2 = (c2 >= 0.f && c2 <= 1.f) ? e2 * kk : 0.f;
+  const float db = warm ? 0.f : (-sq * ib2 / b * (1.0f / 3.0f) + 0.5f / b) * inv_n;  // d loss / d beta_r
+  // backward through compositing: G_j = dL/dw_j
+  const float G = db * bj + gr0 * a0 * i0 + gr1 * a1 * i1 + gr2 * a2 * i2;
+  const float tail = on ? G * w : 0.f;
+  const float suf = wave_rscan_add(tail, lane);
+  const float after = suf - tail;
+  const float q0 = w * gr0, q1 = w * gr1, q2 = w * gr2;
+  const float di0 = q0 * a0, di1 = q1 * a1, di2 = q2 * a2;
+  const float s0 = wave_sum(di0 * (1.f - sv)), s1 = wave_sum(di1 * (1.f - sv)), s2 = wave_sum(di2 * (1.f - sv));
+  if (lane == 0) d_sky[0] = s0, d_sky[1] = s1, d_sky[2] = s2;
+  if (on) {
+    const float dalpha = G * T - after / f;
+    d_sigma[i] = dens > 0.f ? dalpha * delta * expf(-delta * dens) : 0.f;
+    d_albedo[i * 3] = q0 * i0, d_albedo[i * 3 + 1] = q1 * i1, d_albedo[i * 3 + 2] = q2 * i2;
+    d_sun[i] = di0 * (1.f - k0) + di1 * (1.f - k1) + di2 * (1.f - k2);
+    g_beta[i] = db * w;
+  }
+  return contrib;
+}
+
 }  // namespace sr

@@ -87,23 +87,6 @@ __global__ void __launch_bounds__(256) depth_loss_kernel(const float* __restrict
 // launch: the wave already holds alpha, T, w for the whole ray, so the loss gradient (which needs the ray sums beta_r, rgb_r) and
 // the closed-form compositing backward run back to back in registers.  Writes what the MLP backward consumes
 // (d_sigma, d_albedo, d_sun_v, g_beta per sample; d_sky per ray), the loss partial sums and the rendered colour (for logging).
-__device__ __forceinline__ float wave_scan_mul_f(float v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_up(v, d, 64);
-    if (lane >= d) v *= o;
-  }
-  return v;
-}
-__device__ __forceinline__ float wave_rscan_add_f(float v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_down(v, d, 64);
-    if (lane + d < 64) v += o;
-  }
-  return v;
-}
-
 __global__ void __launch_bounds__(256) render_loss_kernel(const float* __restrict__ z, const float* __restrict__ sigma,
                                                          const float* __restrict__ noise, float noise_std, const float* __restrict__ albedo,
                                                          const float* __restrict__ sun_v, const float* __restrict__ beta,
@@ -115,74 +98,17 @@ __global__ void __launch_bounds__(256) render_loss_kernel(const float* __restric
   const bool warm = sched != nullptr && sched[kSchedWarm] != 0.f;  // SNerfLoss epochs (main.py:128-131): plain MSE, no beta
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long r = (long)blockIdx.x * 4 + wv;
-  if (lane == 0) part[wv] = 0.f;
-  const bool ray_on = r < n_rays;
-  const bool on = ray_on && lane < S;
-  const long i = ray_on ? r * S + (lane < S ? lane : S - 1) : 0;
-  // forward: alpha, transmittance, weights (models/satnerf.py:52-63)
-  float delta = 0.f, dens = 0.f, alpha = 0.f, zj = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, sv = 0.f, bj = 0.f;
-  float k0 = 0.f, k1 = 0.f, k2 = 0.f;
-  if (ray_on) k0 = sky[r * 3], k1 = sky[r * 3 + 1], k2 = sky[r * 3 + 2];
-  if (on) {
-#pragma clang fp contract(off)
-    zj = z[i];
-    delta = lane < S - 1 ? z[i + 1] - zj : 1e10f;
-    float s = sigma[i];
-    if (noise) s = s + noise[i] * noise_std;
-    dens = s;
-    alpha = 1.0f - expf(-delta * (s > 0.f ? s : 0.f));
-    a0 = albedo[i * 3], a1 = albedo[i * 3 + 1], a2 = albedo[i * 3 + 2];
-    sv = sun_v[i], bj = beta[i];
+  float contrib = 0.f;
+  if (r < n_rays) {
+    const long i = r * S;
+    // (the same per-ray function as the epilogue of the fused training forward, csrc/mlp_fwd_io.inc: bit-identical results)
+    contrib = render_loss_ray(z + i, sigma + i, noise ? noise + i : nullptr, noise_std, albedo + i * 3, sun_v + i, beta + i, sky[r * 3], sky[r * 3 + 1],
+                              sky[r * 3 + 2], target + r * 3, r, n_rays, S, lane, beta_min, warm, rgb_out ? rgb_out + r * 3 : nullptr, d_sigma + i,
+                              d_albedo + i * 3, d_sun + i, g_beta + i, d_sky + r * 3);
   }
-  float f;
-  {
-#pragma clang fp contract(off)
-    f = on ? (1.0f - alpha) + 1e-10f : 1.f;
-  }
-  const float incl = wave_scan_mul_f(f, lane);
-  float T = __shfl_up(incl, 1, 64);
-  if (lane == 0) T = 1.f;
-  const float w = on ? alpha * T : 0.f;
-  const float i0 = sv + (1.f - sv) * k0, i1 = sv + (1.f - sv) * k1, i2 = sv + (1.f - sv) * k2;  // irradiance, :68
-  const float c0 = wave_sum_f(w * a0 * i0), c1 = wave_sum_f(w * a1 * i1), c2 = wave_sum_f(w * a2 * i2);
-  const float b = wave_sum_f(w * bj) + beta_min;
-  const float r0 = fminf(fmaxf(c0, 0.f), 1.f), r1 = fminf(fmaxf(c1, 0.f), 1.f), r2 = fminf(fmaxf(c2, 0.f), 1.f);
-  // loss (metrics.py:21-25) and its gradient w.r.t. rgb and beta_r
-  const float inv_n = 1.0f / (float)n_rays;
-  float e0 = 0.f, e1 = 0.f, e2 = 0.f;
-  if (ray_on) e0 = r0 - target[r * 3], e1 = r1 - target[r * 3 + 1], e2 = r2 - target[r * 3 + 2];
-  const float sq = e0 * e0 + e1 * e1 + e2 * e2;
-  const float ib2 = warm ? 2.0f : 1.0f / (b * b);  // metrics.SNerfLoss colour term = the same expression with beta^2 = 1/2, no log term
-  if (lane == 0 && ray_on) {
-    float contrib = sq * ib2 * (0.5f / 3.0f) * inv_n + (warm ? 0.f : 0.5f * logf(b) * inv_n);
-    if (r == 0 && !warm) contrib += 1.5f;
-    part[wv] = contrib;
-    if (rgb_out) rgb_out[r * 3] = r0, rgb_out[r * 3 + 1] = r1, rgb_out[r * 3 + 2] = r2;
-  }
+  if (lane == 0) part[wv] = contrib;
   __syncthreads();
   if (threadIdx.x == 0) loss_parts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
-  if (!ray_on) return;
-  const float kk = ib2 * (1.0f / 3.0f) * inv_n;
-  const float gr0 = (c0 >= 0.f && c0 <= 1.f) ? e0 * kk : 0.f;  // torch.clamp passes the gradient where min <= x <= max
-  const float gr1 = (c1 >= 0.f && c1 <= 1.f) ? e1 * kk : 0.f;
-  const float gr2 = (c2 >= 0.f && c2 <= 1.f) ? e2 * kk : 0.f;
-  const float db = warm ? 0.f : (-sq * ib2 / b * (1.0f / 3.0f) + 0.5f / b) * inv_n;  // d loss / d beta_r
-  // backward through compositing: G_j = dL/dw_j
-  const float G = db * bj + gr0 * a0 * i0 + gr1 * a1 * i1 + gr2 * a2 * i2;
-  const float tail = on ? G * w : 0.f;
-  const float suf = wave_rscan_add_f(tail, lane);
-  const float after = suf - tail;
-  const float q0 = w * gr0, q1 = w * gr1, q2 = w * gr2;
-  const float di0 = q0 * a0, di1 = q1 * a1, di2 = q2 * a2;
-  const float s0 = wave_sum_f(di0 * (1.f - sv)), s1 = wave_sum_f(di1 * (1.f - sv)), s2 = wave_sum_f(di2 * (1.f - sv));
-  if (lane == 0) d_sky[r * 3] = s0, d_sky[r * 3 + 1] = s1, d_sky[r * 3 + 2] = s2;
-  if (on) {
-    const float dalpha = G * T - after / f;
-    d_sigma[i] = dens > 0.f ? dalpha * delta * expf(-delta * dens) : 0.f;
-    d_albedo[i * 3] = q0 * i0, d_albedo[i * 3 + 1] = q1 * i1, d_albedo[i * 3 + 2] = q2 * i2;
-    d_sun[i] = di0 * (1.f - k0) + di1 * (1.f - k1) + di2 * (1.f - k2);
-    g_beta[i] = db * w;
-  }
 }
 
 // ---- batch gather from the GPU-resident ray bank (replaces DataLoader collate + H2D copy, main.py:96-110) -----------------
@@ -347,7 +273,7 @@ __global__ void __launch_bounds__(256) sc_loss_kernel(const float* __restrict__ 
 #pragma clang fp contract(off)
       f = on ? (1.0f - alpha) + 1e-10f : 1.f;
     }
-    const float incl = wave_scan_mul_f(f, lane);
+    const float incl = wave_scan_mul(f, lane);
     float excl = __shfl_up(incl, 1, 64);
     if (lane == 0) excl = 1.f;
     const float T = carry * excl;

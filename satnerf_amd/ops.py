@@ -190,6 +190,42 @@ def render_fwd(rays, ts, temb, n_samples, feat, tau, mode, stream_hi, stream_lo,
     return out
 
 
+def render_train(rays, ts, temb, n_samples, feat, tau, mode, stream_hi, stream_lo, l0, sky_w1, sky_b1, sky_w2, sky_b2, target, acts, u=None,
+                 noise=None, noise_std=0.0, seed=0, step_counter=None, sched=None, beta_min=0.05, want_z=False):
+    """The training forward in ONE launch (sr_satnerf_render_train): stratified depths (``u`` (N,S) given, else drawn in the kernel from
+    ``seed`` / ``step_counter``) -> fused MLP saving the 8-bit activations into ``acts`` -> sky head, compositing, colour loss and the
+    compositing backward per ray.  Returns dict(albedo (N,S,3), sigma, sun_v, beta (N,S), sky (N,3), z (N,S) or None, loss (partial sums),
+    rgb (N,3), d_sigma, d_sun, g_beta (N,S), d_albedo (N,S,3), d_sky (N,3)) -- what ``ray_setup`` + ``satnerf_mlp`` + ``render_loss``
+    return, bit for bit."""
+    rays, stride = _rows(rays, "rays", 11)
+    n, s, dev = rays.shape[0], int(n_samples), rays.device
+    _chk(ts, "ts", torch.int64), _chk(temb, "temb")
+    for t, nm in ((u, "u"), (noise, "noise")):
+        if t is not None and tuple(_chk(t, nm).shape) != (n, s):
+            raise ValueError(f"{nm} must be ({n},{s}), got {tuple(t.shape)}")
+    per_block = _lib.lib().sr_render_points_per_block(int(feat), MODES[mode])
+    if per_block <= 0 or s > 64 or per_block % s:
+        raise ValueError(f"no fused training forward for feat={feat}, mode={mode}, n_samples={s}")
+    e = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+    out = {"z": e(n, s) if want_z else None, "albedo": e(n, s, 3), "sigma": e(n, s), "sun_v": e(n, s), "beta": e(n, s), "sky": e(n, 3),
+           "loss": e((n * s + per_block - 1) // per_block), "rgb": e(n, 3), "d_sigma": e(n, s), "d_albedo": e(n, s, 3), "d_sun": e(n, s),
+           "g_beta": e(n, s), "d_sky": e(n, 3)}
+    args = _lib.RenderArgs(_p(rays), stride, _p(ts), _p(temb), n, s, None, _p(u), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                           _p(_chk(step_counter, "step_counter", allow_none=True)), 0, _p(noise), float(noise_std), sky_w1.shape[0],
+                           _p(_chk(sky_w1, "w1")), _p(_chk(sky_b1, "b1")), _p(_chk(sky_w2, "w2")), _p(_chk(sky_b2, "b2")), 0)
+    outs = _lib.RenderOutputs(_p(out["z"]), _p(out["albedo"]), _p(out["sigma"]), _p(out["sun_v"]), _p(out["beta"]), _p(out["sky"]), None, None, None, None)
+    tr = _lib.TrainArgs(_p(_chk(target, "target")), _p(_chk(sched, "sched", allow_none=True)), float(beta_min), _p(out["loss"]), _p(out["rgb"]),
+                        _p(out["d_sigma"]), _p(out["d_albedo"]), _p(out["d_sun"]), _p(out["g_beta"]), _p(out["d_sky"]))
+    ev = kernel_timer.span("mlp_fwd") if kernel_timer is not None else None
+    if ev:
+        ev[0].record()
+    _lib.call("sr_satnerf_render_train", C.byref(args), feat, tau, MODES[mode], _p(stream_hi), _p(stream_lo), _p(_chk(l0, "l0")), C.byref(outs),
+              C.byref(tr), _p(acts), 8, _stream())
+    if ev:
+        ev[1].record()
+    return out
+
+
 def composite(z, sigma, noise, noise_std, albedo, sun_v, sky_rgb, clamp_rgb=True):
     n, s = z.shape
     dev = z.device

@@ -257,31 +257,44 @@ class Trainer:
         noise_std = float(args.noise_std)
         # models/satnerf.py:58 draws randn even when noise_std == 0; the draw is skipped then (results are identical)
         nz = torch.randn(n, s, device=rays.device) if noise_std != 0 else None
-        if self._pre_setup is not None:  # a captured step whose gather launch already produced them (_gather_from_banks)
-            (z, sky), self._pre_setup = self._pre_setup, None
-        else:
-            z, sky = ops.ray_setup(rays, u, s, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data, seed=self._seed,
-                                   step_counter=self.adam_state)
         fmt = _fmt_of(args)
         acts = ops.acts_workspace(n * s, feat, rays.device, fmt)
-        albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, 3:6], rays[:, 8:11], z, emb.weight.data, ts, n * s, s, feat, tau, mode,
-                                                     hi, lo, l0, acts=acts, fmt=fmt)
-        if s <= 64:  # one launch: compositing forward -> loss -> compositing backward
-            loss, self.last_rgb, d_sigma, d_albedo, d_sun, g_beta, d_sky = ops.render_loss(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3),
-                                                                                           sun_v.view(n, s), beta.view(n, s), sky, rgbs,
-                                                                                           sched=self.sched)
+        sc_on = float(getattr(args, "sc_lambda", 0.0)) > 0
+        # ONE launch for the forward (sr_satnerf_render_train): stratified depths + sky head in the prologue, MLP saving the 8-bit
+        # state, compositing + colour loss + compositing backward in the epilogue -- r04 ran sr_ray_setup, the MLP and sr_render_loss
+        # as three launches; the per-ray functions are the same, the results bit-identical.  SATNERF_TRAIN_FUSED=0: the three launches (A/B)
+        fused = self._pre_setup is None and self._fused_forward()
+        if fused:
+            r = ops.render_train(rays, ts, emb.weight.data, s, feat, tau, mode, hi, lo, l0, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data,
+                                 sk[2].bias.data, rgbs, acts, u=u, noise=nz, noise_std=noise_std, seed=self._seed, step_counter=self.adam_state,
+                                 sched=self.sched, want_z=sc_on)
+            z, sky, loss, self.last_rgb = r["z"], r["sky"], r["loss"], r["rgb"]
+            albedo, sigma, sun_v, beta = r["albedo"].view(-1, 3), r["sigma"].view(-1), r["sun_v"].view(-1), r["beta"].view(-1)
+            d_sigma, d_albedo, d_sun, g_beta, d_sky = r["d_sigma"], r["d_albedo"], r["d_sun"], r["g_beta"], r["d_sky"]
         else:
-            weights, transp, _, rgb = ops.composite(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky)
-            loss, g_rgb, g_w, g_beta = ops.satnerf_loss(rgb, weights, beta.view(n, s), rgbs, sched=self.sched)
-            d_sigma, d_albedo, d_sun, d_sky = ops.composite_bwd(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky,
-                                                               weights, transp, g_rgb, None, g_w, None)
-            self.last_rgb = rgb
+            if self._pre_setup is not None:  # a captured step whose gather launch already produced them (_gather_from_banks)
+                (z, sky), self._pre_setup = self._pre_setup, None
+            else:
+                z, sky = ops.ray_setup(rays, u, s, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data, seed=self._seed,
+                                       step_counter=self.adam_state)
+            albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, 3:6], rays[:, 8:11], z, emb.weight.data, ts, n * s, s, feat, tau, mode,
+                                                         hi, lo, l0, acts=acts, fmt=fmt)
+            if s <= 64:  # one launch: compositing forward -> loss -> compositing backward
+                loss, self.last_rgb, d_sigma, d_albedo, d_sun, g_beta, d_sky = ops.render_loss(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3),
+                                                                                               sun_v.view(n, s), beta.view(n, s), sky, rgbs,
+                                                                                               sched=self.sched)
+            else:
+                weights, transp, _, rgb = ops.composite(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky)
+                loss, g_rgb, g_w, g_beta = ops.satnerf_loss(rgb, weights, beta.view(n, s), rgbs, sched=self.sched)
+                d_sigma, d_albedo, d_sun, d_sky = ops.composite_bwd(z, sigma.view(n, s), nz, noise_std, albedo.view(n, s, 3), sun_v.view(n, s), sky,
+                                                                   weights, transp, g_rgb, None, g_w, None)
+                self.last_rgb = rgb
         dpre, d_t = ops.satnerf_mlp_bwd(feat, tau, n * s, bstream, acts, albedo, sigma, sun_v, beta, d_albedo, d_sigma, d_sun, g_beta.view(-1), fmt=fmt)
         partial, plan = ops.wgrad_partials(feat, tau, n * s, dpre, acts, maps["blocks"], fmt, maps["loads8"])
         ops.grad_tail(partial, plan, maps["gidx"], maps["gscale"], model.flat_grads(), rays[:, 8:11], sk[0].weight.data, sk[0].bias.data,
                       sk[2].weight.data, sky, d_sky, sk[0].weight.grad, sk[0].bias.grad, sk[2].weight.grad, sk[2].bias.grad, d_t, ts, n, s, tau,
                       emb.weight.grad)
-        if float(getattr(args, "sc_lambda", 0.0)) > 0:
+        if sc_on:
             loss = torch.cat([loss.view(-1), self._sc_pass(rays, ts, z, noise_std).view(-1)])
         if depth is not None:
             loss = torch.cat([loss.view(-1), self._depth_pass(*depth, noise_std * 0.9).view(-1)])  # main.py:132 decays the noise first
@@ -292,6 +305,16 @@ class Trainer:
             ops.adam_step_graph(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.adam_state, lr=-1.0,
                                 grad_scale=1.0 / self.world, zero_grad=True)
         return loss
+
+    def _fused_forward(self):
+        """True when the colour pass's forward is ONE launch (sr_satnerf_render_train): 8-bit saved state, <= 64 samples dividing a
+        workgroup's points, a generated-core build for (width, mode)."""
+        from . import ops
+        from .rendering import _mode_of
+
+        s, mode = self.args.n_samples, _mode_of(self.args)
+        return (_fmt_of(self.args) == 8 and s <= 64 and ops.render_fused_ok(self.models["coarse"].feat, mode, s)
+                and os.environ.get("SATNERF_TRAIN_FUSED", "1") != "0" and os.environ.get("SATNERF_FWD_V1", "0") != "1")
 
     def _sc_pass(self, rays, ts, z, noise_std):
         """Solar correction (rendering.py:102-108, metrics.py:27-34): the SAME depths along the sun direction; transparency and
@@ -416,9 +439,10 @@ class Trainer:
         for k, b in enumerate(self._graph_banks):
             idx, cursor, batches = b.graph_source()
             out = self._static[3 * k:3 * k + 3]
-            if k == 0 and self._kernel_rng:
+            if k == 0 and self._kernel_rng and not self._fused_forward():
                 # the colour batch: gather + stratified depths + sky colour in ONE launch (sr_gather_setup); _forward_backward then
-                # skips its ray set-up launch.  step_offset 1: this runs before sr_pack_all ticks the step counter
+                # skips its ray set-up launch (when the forward is not the one-launch training render, which sets the rays up itself).
+                # step_offset 1: this runs before sr_pack_all ticks the step counter
                 model, n, s = self.models["coarse"], out[0].shape[0], self.args.n_samples
                 if self._pre_bufs is None or self._pre_bufs[0].shape != (n, s):
                     dev = out[0].device

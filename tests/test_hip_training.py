@@ -449,3 +449,69 @@ def test_workspaces_hold_the_tail_waves_tiles(monkeypatch, mode, fmt):
     for c in canaries:
         assert bool((c == 0x5A5A).all()), "a kernel wrote behind its workspace"
     assert torch.isfinite(tr.state.params).all()
+
+
+@pytest.mark.parametrize("feat,mode,n_rays,warm", [(256, "bf16", 130, 0.0), (256, "f16", 64, 1.0), (512, "bf16", 37, 0.0)])
+def test_one_launch_training_forward_is_bit_identical_to_the_three_launches(feat, mode, n_rays, warm):
+    """sr_satnerf_render_train (stratified depths + sky head in the prologue, MLP saving the 8-bit state, compositing + colour loss +
+    compositing backward in the epilogue) against sr_ray_setup -> sr_satnerf_mlp_fwd -> sr_render_loss: the same per-ray device functions
+    on the same fp32 values, so every output -- and the saved activations -- must agree bit for bit (Next #3)."""
+    from satnerf_amd import ops
+    from satnerf_amd.models import load_model
+
+    torch.manual_seed(0)
+    s, tau = 64, 4
+    args = O.default_args(mlp_mode=mode, fc_units=feat)
+    model = load_model(args).to(DEV)
+    emb = torch.nn.Embedding(30, tau).to(DEV)
+    rays, ts = O.synthetic_rays(n_rays, seed=9)
+    rays, ts = rays.to(DEV), ts.to(DEV)
+    target = torch.rand(n_rays, 3, device=DEV)
+    sched = torch.tensor([3.0, 5e-4, warm, 0.0], device=DEV)
+    model.repack(mode, backward=True)
+    hi, lo, l0 = model.packed(mode)
+    sk = model.sky_color
+    w = (sk[0].weight.data, sk[0].bias.data, sk[2].weight.data, sk[2].bias.data)
+    for u in (torch.rand(n_rays, s, device=DEV), None):  # given jitter / drawn in the kernel (Philox keyed by seed and sched[0])
+        acts_a = ops.acts_workspace(n_rays * s, feat, DEV, 8).zero_()
+        acts_b = torch.zeros_like(acts_a)
+        z, sky = ops.ray_setup(rays, u, s, *w, seed=77, step_counter=sched)
+        albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, 3:6], rays[:, 8:11], z, emb.weight.data, ts, n_rays * s, s, feat, tau, mode,
+                                                     hi, lo, l0, acts=acts_a, fmt=8)
+        loss, rgb, d_sigma, d_albedo, d_sun, g_beta, d_sky = ops.render_loss(z, sigma.view(n_rays, s), None, 0.0, albedo.view(n_rays, s, 3),
+                                                                             sun_v.view(n_rays, s), beta.view(n_rays, s), sky, target, sched=sched)
+        r = ops.render_train(rays, ts, emb.weight.data, s, feat, tau, mode, hi, lo, l0, *w, target, acts_b, u=u, seed=77, step_counter=sched,
+                             sched=sched, want_z=True)
+        torch.cuda.synchronize()
+        want = dict(z=z, sky=sky, albedo=albedo.view(n_rays, s, 3), sigma=sigma.view(n_rays, s), sun_v=sun_v.view(n_rays, s), beta=beta.view(n_rays, s),
+                    rgb=rgb, d_sigma=d_sigma, d_albedo=d_albedo, d_sun=d_sun, g_beta=g_beta, d_sky=d_sky)
+        for k, v in want.items():
+            assert torch.equal(r[k], v), (k, u is None, (r[k] - v).abs().max().item())
+        # the loss: the same per-ray terms, summed per workgroup instead of per 4 rays
+        assert abs(r["loss"].sum().item() - loss.sum().item()) <= 1e-6 * abs(loss.sum().item())
+        tiles = (n_rays * s + 31) // 32  # (the padding tiles of the last workgroup hold whatever its idle waves computed)
+        per_tile = acts_a.numel() // ((tiles + 7) // 8 * 8)
+        assert torch.equal(acts_a[:tiles * per_tile], acts_b[:tiles * per_tile])
+
+
+def test_trainer_step_with_one_launch_forward_matches_three_launch_step(monkeypatch):
+    """The kernel-direct step with the fused forward (default) against SATNERF_TRAIN_FUSED=0 on identical draws: identical MLP gradients."""
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    rays, ts = O.synthetic_rays(200, seed=5)
+    target = torch.rand(200, 3, generator=torch.Generator().manual_seed(6))
+    u = torch.rand(200, 64, generator=torch.Generator().manual_seed(7))
+    grads = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SATNERF_TRAIN_FUSED", fused)
+        torch.manual_seed(0)
+        args = O.default_args(mlp_mode="bf16")
+        tr = Trainer({"coarse": load_model(args).to(DEV), "t": torch.nn.Embedding(30, 4).to(DEV)}, args, use_graph=False)
+        assert tr._fused_forward() == (fused == "1")
+        tr.jitter = lambda n, s, device: u.to(device)
+        loss = tr._forward_backward(rays.to(DEV), ts.to(DEV), target.to(DEV))
+        grads.append((loss.sum().item(), tr.state.grads.clone()))
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * abs(grads[1][0])
+    # (sky head and embedding gradients are accumulated with float atomics: equal to rounding, not bit for bit)
+    assert maxnorm_rel(grads[0][1].cpu(), grads[1][1].cpu()) < 1e-6
