@@ -277,6 +277,17 @@ int sr_grad_tail(const float* partial, const int32_t* gidx, const float* gscale,
                  float* grad, int accumulate, const float* sun, int sun_stride, int64_t n_rays, int hidden,
                  const float* w1, const float* b1, const float* w2, const float* sky, const float* d_sky, float* g_w1, float* g_b1,
                  float* g_w2, float* g_b2, const float* d_t, const int64_t* ts, int n_samples, int tau, float* g_emb, void* stream);
+/* sr_grad_tail + sr_adam_step_graph in one launch (the single-GPU captured step): the thread that reduces a parameter's slices applies
+ * torch.optim.Adam to it (params / exp_avg / exp_avg_sq are aligned with grad: element i of all four is parameter i) and zeroes its
+ * gradient slot; `late_idx` (n_late flat indices relative to grad) lists the parameters whose gradients arrive by atomics -- the sky head
+ * and the embedding rows: the last atomics block to finish updates them.  `state` = the 4-float schedule block ([0] 1-based step, [1]
+ * rate used when lr < 0, [3] arrival counter, zero between launches). */
+int sr_grad_tail_adam(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, const int32_t* blocks, float* grad,
+                      int accumulate, const float* sun, int sun_stride, int64_t n_rays, int hidden, const float* w1, const float* b1,
+                      const float* w2, const float* sky, const float* d_sky, float* g_w1, float* g_b1, float* g_w2, float* g_b2,
+                      const float* d_t, const int64_t* ts, int n_samples, int tau, float* g_emb, float* params, float* exp_avg,
+                      float* exp_avg_sq, const int32_t* late_idx, int n_late, float* state, float lr, float beta1, float beta2, float eps,
+                      float grad_scale, void* stream);
 int sr_adam_step_graph(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                        float beta2, float eps, float grad_scale, float* state, int zero_grad, void* stream);
 

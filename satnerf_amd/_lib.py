@@ -86,6 +86,8 @@ SIGNATURES = {
     "sr_gather_batch": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sr_grad_tail": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
                           _vp, _vp]),
+    "sr_grad_tail_adam": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
+                               _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _f, _f, _vp]),
     "sr_adam_step_graph": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp, _i, _vp]),
     "sr_pack_all": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     "sr_gather_scale_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),

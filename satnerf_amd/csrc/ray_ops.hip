@@ -9,6 +9,7 @@
 #include "mlp_layout.h"
 #include <mutex>
 
+#include "adam_device.h"
 #include "ray_device.h"
 
 namespace sr {
@@ -555,6 +556,65 @@ __global__ void __launch_bounds__(256) grad_tail_kernel(const GradTailParams q) 
   q.grad[i] = q.accumulate ? q.grad[i] + s : s;
 }
 
+// ---- gradient tail + Adam in ONE launch (single-GPU captured step) -------------------------------------------------------------------
+// grad_tail_kernel followed by adam_graph_kernel streamed the same flat buffers back to back (grad written, read, zeroed: 8 MB and a
+// launch).  Here the thread that reduces a parameter's split-K slices applies torch.optim.Adam to that parameter on the spot and leaves
+// the gradient slot zero for the next step.  The parameters whose gradients arrive by float atomics from OTHER blocks -- the sky head
+// (models/satnerf.py:138-143) and the embedding rows -- are listed in `late`: the last of the atomics' blocks to finish (arrival counter
+// behind a __threadfence, reset for the next launch) updates them.  Same adam_one as the stand-alone launches; the bias corrections come
+// from the device-side step counter state[0] (ticked by sr_pack_all earlier in the captured step), lr < 0 reads state[1].
+struct TailAdamParams {
+  GradTailParams q;
+  float* p; float* m; float* v;   // flat parameter / moment buffers, aligned with q.grad (element i of all four = parameter i)
+  const int* late; int n_late;    // flat indices (relative to q.grad) updated by the last atomics block
+  const float* state; unsigned* arrive;
+  float lr, b1, b2, eps, grad_scale;
+};
+__global__ void __launch_bounds__(256) grad_tail_adam_kernel(const TailAdamParams a) {
+  const GradTailParams& q = a.q;
+  __shared__ float bc[2];
+  __shared__ int last;
+  if (threadIdx.x == 0) {
+    const float t = a.state[0];
+    bc[0] = 1.0f - powf(a.b1, t), bc[1] = 1.0f - powf(a.b2, t);
+  }
+  __syncthreads();
+  const float lr = a.lr < 0.f ? a.state[1] : a.lr;
+  const float step_size = lr / bc[0], sqrt_bc2 = sqrtf(bc[1]);
+  int b = blockIdx.x;
+  const int n_atomic = q.blocks_sky + q.blocks_emb;
+  if (b < n_atomic) {
+    if (b < q.blocks_sky) sky_bwd_body(b, q.sun, q.sun_stride, q.n_rays, q.hidden, q.w1, q.b1, q.w2, q.sky, q.d_sky, q.g_w1, q.g_b1, q.g_w2, q.g_b2);
+    else embedding_bwd_body(b - q.blocks_sky, q.d_t, q.ts, q.n_rays, q.S, q.tau, q.g_emb);
+    // this block's atomics have been PERFORMED (acknowledged: vmcnt) before it checks in.  Deliberately not __threadfence(): an agent-scope
+    // release writes the XCD's whole L2 back (buffer_wbl2) -- 288 of them while the other blocks stream 18 MB of moments made this launch
+    // 64 us instead of 28.  Nothing but device-scope atomics (performed at the memory side, not in an XCD's L2) is published here, and
+    // the last block reads them back with device-scope atomic loads.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n_atomic - 1);
+    __syncthreads();
+    if (!last) return;
+    for (int k = threadIdx.x; k < a.n_late; k += 256) {
+      const int i = a.late[k];
+      float g = __hip_atomic_load(q.grad + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the atomics live in L2)
+      adam_one(a.p[i], g, a.m[i], a.v[i], step_size, a.b1, a.b2, a.eps, a.grad_scale, sqrt_bc2, 1);
+      q.grad[i] = 0.f;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  b -= n_atomic;
+  const long i = (long)b * 256 + threadIdx.x;
+  if (i >= q.n_params) return;
+  const int k = q.gidx[i];
+  if (k < 0) return;  // (no weight-gradient GEMM produces it: on the `late` list)
+  float g = wg_sum_slices(q.partial, q.blocks, k) * q.gscale[i];
+  if (q.accumulate) g += q.grad[i];  // what the solar-correction / depth-supervision passes of this step left
+  adam_one(a.p[i], g, a.m[i], a.v[i], step_size, a.b1, a.b2, a.eps, a.grad_scale, sqrt_bc2, 1);
+  q.grad[i] = 0.f;
+}
+
 }  // namespace sr
 
 using namespace sr;
@@ -736,6 +796,32 @@ extern "C" int sr_grad_tail(const float* partial, const int32_t* gidx, const flo
   q.blocks_emb = (int)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
   hipLaunchKernelGGL(grad_tail_kernel, dim3(q.blocks_unpack + q.blocks_sky + q.blocks_emb), dim3(256), 0, (hipStream_t)stream, q);
   return check_launch("grad_tail_kernel");
+}
+
+extern "C" int sr_grad_tail_adam(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, const int32_t* blocks,
+                                 float* grad, int accumulate, const float* sun, int sun_stride, int64_t n_rays, int hidden, const float* w1,
+                                 const float* b1, const float* w2, const float* sky, const float* d_sky, float* g_w1, float* g_b1, float* g_w2,
+                                 float* g_b2, const float* d_t, const int64_t* ts, int n_samples, int tau, float* g_emb, float* params,
+                                 float* exp_avg, float* exp_avg_sq, const int32_t* late_idx, int n_late, float* state, float lr, float beta1,
+                                 float beta2, float eps, float grad_scale, void* stream) {
+  SR_REQUIRE(partial && gidx && gscale && blocks && grad && sun && w1 && b1 && w2 && sky && d_sky && g_w1 && g_b1 && g_w2 && g_b2 && d_t && ts && g_emb,
+             "sr_grad_tail_adam: null pointer");
+  SR_REQUIRE(params && exp_avg && exp_avg_sq && state && (late_idx || n_late == 0) && n_late >= 0, "sr_grad_tail_adam: null optimizer pointer");
+  if (n_rays <= 0) return 0;
+  TailAdamParams a;
+  GradTailParams& q = a.q;
+  q.partial = partial, q.gidx = gidx, q.gscale = gscale, q.n_params = n_params, q.blocks = blocks, q.grad = grad;
+  q.accumulate = accumulate, q.sun = sun, q.sun_stride = sun_stride, q.n_rays = n_rays, q.hidden = hidden, q.w1 = w1, q.b1 = b1, q.w2 = w2;
+  q.sky = sky, q.d_sky = d_sky, q.g_w1 = g_w1, q.g_b1 = g_b1, q.g_w2 = g_w2, q.g_b2 = g_b2, q.d_t = d_t, q.ts = (const long long*)ts;
+  q.S = n_samples, q.tau = tau, q.g_emb = g_emb;
+  q.blocks_unpack = (int)((n_params + 255) / 256);
+  q.blocks_sky = (int)((n_rays + kSkyRays - 1) / kSkyRays);
+  q.blocks_emb = (int)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
+  a.p = params, a.m = exp_avg, a.v = exp_avg_sq, a.late = late_idx, a.n_late = n_late, a.state = state;
+  a.arrive = reinterpret_cast<unsigned*>(state + 3);  // the schedule block's arrival counter (ray_device.h tick_when_all_read: unused by training steps)
+  a.lr = lr, a.b1 = beta1, a.b2 = beta2, a.eps = eps, a.grad_scale = grad_scale;
+  hipLaunchKernelGGL(grad_tail_adam_kernel, dim3(q.blocks_unpack + q.blocks_sky + q.blocks_emb), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("grad_tail_adam_kernel");
 }
 
 extern "C" int sr_embedding_bwd(const float* d_t, const int64_t* ts, int64_t n_rays, int n_samples, int tau, float* g_emb, void* stream) {

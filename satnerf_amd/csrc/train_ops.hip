@@ -3,6 +3,7 @@
 #include <math.h>
 
 #include "common.h"
+#include "adam_device.h"
 #include "ray_device.h"
 
 namespace sr {
@@ -168,15 +169,7 @@ __global__ void __launch_bounds__(256) gather_setup_kernel(const float* __restri
 
 // torch.optim.Adam (main.py:84: lr 5e-4, betas (0.9, 0.999), eps 1e-8, no weight decay), one launch over the flat buffer: four elements per
 // thread (16-byte loads / stores; the launcher checks the alignment), the last block's first n % 4 threads take the scalar tail.
-__device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, float step_size, float b1, float b2, float eps, float grad_scale,
-                                         float sqrt_bc2, int zero_grad) {
-  const float gi = g * grad_scale;
-  const float mi = b1 * m + (1.0f - b1) * gi;
-  const float vi = b2 * v + (1.0f - b2) * gi * gi;
-  m = mi, v = vi;
-  p -= step_size * (mi / (sqrtf(vi) / sqrt_bc2 + eps));  // torch: denom = sqrt(v) / sqrt(bc2) + eps; p.addcdiv_(m, denom, -lr / bc1)
-  if (zero_grad) g = 0.f;
-}
+// (adam_one: adam_device.h)
 template <bool VEC>
 __device__ __forceinline__ void adam_body(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                                           float lr, float b1, float b2, float eps, float grad_scale, float bc1, float bc2, int zero_grad) {

@@ -637,6 +637,19 @@ def grad_tail(partial, plan, gidx, gscale, grad_flat, sun, w1, b1, w2, sky_rgb, 
               _p(_chk(g_emb, "g_emb")), _stream())
 
 
+def grad_tail_adam(partial, plan, gidx, gscale, grad_flat, sun, w1, b1, w2, sky_rgb, d_sky, g_w1, g_b1, g_w2, g_b2, d_t, ts, n_rays, n_samples, tau,
+                   g_emb, params, exp_avg, exp_avg_sq, late_idx, state, lr=-1.0, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+    """``grad_tail`` + ``adam_step_graph`` in one launch (sr_grad_tail_adam): ``params`` / ``exp_avg`` / ``exp_avg_sq`` are the flat buffers
+    aligned with ``grad_flat`` (they may extend past it: ``late_idx`` addresses the embedding rows behind the model's parameters)."""
+    sun, stride = _rows(sun, "sun", 3)
+    _lib.call("sr_grad_tail_adam", _p(partial), _p(_chk(gidx, "gidx", torch.int32)), _p(_chk(gscale, "gscale")), gidx.numel(), _p(plan),
+              _p(_chk(grad_flat, "grad_flat")), 1, _p(sun), stride, n_rays, w1.shape[0], _p(w1), _p(b1), _p(w2), _p(_chk(sky_rgb, "sky")),
+              _p(_chk(d_sky, "d_sky")), _p(g_w1), _p(g_b1), _p(g_w2), _p(g_b2), _p(_chk(d_t, "d_t")), _p(_chk(ts, "ts", torch.int64)), n_samples, tau,
+              _p(_chk(g_emb, "g_emb")), _p(_chk(params, "params")), _p(_chk(exp_avg, "exp_avg")), _p(_chk(exp_avg_sq, "exp_avg_sq")),
+              _p(_chk(late_idx, "late_idx", torch.int32)), late_idx.numel(), _p(_chk(state, "state")), float(lr), float(betas[0]), float(betas[1]),
+              float(eps), float(grad_scale), _stream())
+
+
 def adam_step_graph(params, grads, exp_avg, exp_avg_sq, state, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, zero_grad=True):
     _lib.call("sr_adam_step_graph", _p(_chk(params, "params")), _p(_chk(grads, "grads")), _p(_chk(exp_avg, "exp_avg")), _p(_chk(exp_avg_sq, "exp_avg_sq")),
               params.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), float(grad_scale), _p(_chk(state, "state")), int(zero_grad),

@@ -221,6 +221,17 @@ class Trainer:
         self.direct = (loss_fn is None and p.is_cuda and args.n_importance == 0 and args.model == "sat-nerf"
                        and hasattr(models["coarse"], "fused_training") and models["coarse"].fused_training(_mode_of(args), _fmt_of(args)))
         self.use_graph = use_graph and self.direct
+        # parameters whose gradients arrive by float atomics (no weight-gradient GEMM produces them: the sky head; the embedding rows
+        # behind the model in the flat buffer): the fused tail + Adam launch updates them from its last atomics block
+        self._late_idx = None
+        if self.direct and mods[0] is models["coarse"] and len(mods) == 2 and mods[1] is models.get("t"):
+            import numpy as np
+
+            from . import packing
+
+            gidx = packing.backward_maps(models["coarse"].feat, models["coarse"].t_embedding_dims)["gidx"]
+            late = np.concatenate([np.nonzero(gidx < 0)[0], np.arange(gidx.size, p.numel())])
+            self._late_idx = torch.from_numpy(late.astype(np.int32)).to(p.device)
         self._graph, self._static, self._graph_banks = None, None, None
         self._pre_setup, self._pre_bufs = None, None
         self.max_inflight = int(os.environ.get("SATNERF_MAX_INFLIGHT", "0"))
@@ -291,17 +302,26 @@ class Trainer:
                 self.last_rgb = rgb
         dpre, d_t = ops.satnerf_mlp_bwd(feat, tau, n * s, bstream, acts, albedo, sigma, sun_v, beta, d_albedo, d_sigma, d_sun, g_beta.view(-1), fmt=fmt)
         partial, plan = ops.wgrad_partials(feat, tau, n * s, dpre, acts, maps["blocks"], fmt, maps["loads8"])
-        ops.grad_tail(partial, plan, maps["gidx"], maps["gscale"], model.flat_grads(), rays[:, 8:11], sk[0].weight.data, sk[0].bias.data,
-                      sk[2].weight.data, sky, d_sky, sk[0].weight.grad, sk[0].bias.grad, sk[2].weight.grad, sk[2].bias.grad, d_t, ts, n, s, tau,
-                      emb.weight.grad)
+        # the colour pass's gradient tail comes LAST: the solar-correction and depth-supervision passes accumulate their weight gradients
+        # into the (zeroed) flat buffer first, the tail adds the colour pass's on top -- and, on a single GPU under graph capture, applies
+        # Adam in the same launch (sr_grad_tail_adam: the thread that reduces a parameter's split-K slices updates it and zeroes its
+        # gradient; r04 ran sr_grad_tail and sr_adam_step_graph back to back over the same flat buffers)
         if sc_on:
             loss = torch.cat([loss.view(-1), self._sc_pass(rays, ts, z, noise_std).view(-1)])
         if depth is not None:
             loss = torch.cat([loss.view(-1), self._depth_pass(*depth, noise_std * 0.9).view(-1)])  # main.py:132 decays the noise first
-        if self._adam_in_graph:  # the update rides in the same graph (single GPU, or the RCCL all-reduce captured with it)
+        tail = (partial, plan, maps["gidx"], maps["gscale"], model.flat_grads(), rays[:, 8:11], sk[0].weight.data, sk[0].bias.data,
+                sk[2].weight.data, sky, d_sky, sk[0].weight.grad, sk[0].bias.grad, sk[2].weight.grad, sk[2].bias.grad, d_t, ts, n, s, tau,
+                emb.weight.grad)
+        if self._adam_in_graph and not self._collective and self._late_idx is not None and os.environ.get("SATNERF_TAIL_ADAM", "1") != "0":
+            # lr < 0: the kernel reads the current rate from sched[1], so a scheduler can change it under graph replay
+            ops.grad_tail_adam(*tail, self.state.params, self.exp_avg, self.exp_avg_sq, self._late_idx, self.adam_state, lr=-1.0,
+                               grad_scale=1.0 / self.world)
+            return loss
+        ops.grad_tail(*tail)
+        if self._adam_in_graph:  # the update rides in the same graph (the RCCL all-reduce captured with it, or the A/B switch above)
             if self._collective:
                 dist.all_reduce(self.state.grads, op=dist.ReduceOp.SUM)
-            # lr < 0: the kernel reads the current rate from sched[1], so a scheduler can change it under graph replay
             ops.adam_step_graph(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.adam_state, lr=-1.0,
                                 grad_scale=1.0 / self.world, zero_grad=True)
         return loss

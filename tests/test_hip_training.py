@@ -515,3 +515,41 @@ def test_trainer_step_with_one_launch_forward_matches_three_launch_step(monkeypa
     assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * abs(grads[1][0])
     # (sky head and embedding gradients are accumulated with float atomics: equal to rounding, not bit for bit)
     assert maxnorm_rel(grads[0][1].cpu(), grads[1][1].cpu()) < 1e-6
+
+
+def test_fused_tail_adam_matches_tail_then_adam(monkeypatch):
+    """sr_grad_tail_adam (split-K reduction + scatter + Adam per parameter in one launch, the sky head and embedding rows by the last
+    atomics block) against sr_grad_tail followed by sr_adam_step_graph: graph-replayed steps of two trainers on identical batches and
+    in-kernel jitter (same seed, same device step counter) end with the same parameters and moments, the gradient buffer zeroed."""
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    rays, ts = O.synthetic_rays(256, seed=5)
+    rays, ts = rays.to(DEV), ts.to(DEV)
+    target = torch.rand(256, 3, generator=torch.Generator().manual_seed(6)).to(DEV)
+    out = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SATNERF_TAIL_ADAM", fused)
+        torch.manual_seed(0)
+        args = O.default_args(mlp_mode="bf16")
+        tr = Trainer({"coarse": load_model(args).to(DEV), "t": torch.nn.Embedding(30, 4).to(DEV)}, args, use_graph=True, steps_per_epoch=1000)
+        assert tr._late_idx is not None and tr._late_idx.numel() == 899 + 30 * 4  # sky head (3*128 + 128 + 3*128 + 3) + the embedding
+        snaps = []
+        for _ in range(3):
+            tr.step(rays, ts, target, validate=False)
+            torch.cuda.synchronize()
+            assert float(tr.state.grads.abs().max()) == 0.0  # zeroed for the next step, the atomics' slots included
+            assert int(tr.adam_state.view(torch.int32)[3].item()) == 0  # the arrival counter is back at zero
+            snaps.append((tr.state.params.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone()))
+        assert tr._graph is not None and tr._adam_in_graph
+        out.append(snaps)
+    late = tr._late_idx.long()
+    mlp = torch.ones(out[0][0][0].numel(), dtype=torch.bool, device=DEV)
+    mlp[late] = False
+    # after ONE step (same parameters in, same gradients): the weight-gradient parameters bit for bit -- same sums, same adam_one; the
+    # atomics' parameters to rounding.  Later steps only to a tolerance: the embedding rows differ in their last bits after step 1, and
+    # Adam's early updates (+-lr whatever the gradient's size) amplify that wherever a gradient is near zero
+    for a, b in zip(out[0][0], out[1][0]):
+        assert torch.equal(a[mlp], b[mlp])
+        assert maxnorm_rel(a[late].cpu(), b[late].cpu()) < 1e-5
+    assert maxnorm_rel(out[0][2][0].cpu(), out[1][2][0].cpu()) < 2e-3
