@@ -291,8 +291,11 @@ def test_rccl_allreduce_is_captured_into_the_step_graph(tmp_path):
     ra, rb = torch.load(a), torch.load(b)
     assert ra["graphed"] and ra["collective"] and ra["adam_in_graph"] and not ra["capture_failed"]
     assert rb["graphed"] and not rb["collective"]
-    # (two runs of the step are equal to rounding, not bit for bit: the embedding / loss reductions use atomics)
-    assert maxnorm_rel(ra["params"], rb["params"]) < 1e-6 and ra["losses"] == pytest.approx(rb["losses"], rel=1e-5)
+    # (two runs of the step are equal to rounding, not bit for bit: the embedding / loss reductions use atomics; r05: the plain trainer
+    # applies Adam inside the gradient-tail launch, the collective one in its own launch after the all-reduce -- another atomics order,
+    # and Adam's first updates (+-lr whatever a gradient's size) amplify last-bit differences wherever a gradient is near zero:
+    # measured 5.6e-5 after four steps)
+    assert maxnorm_rel(ra["params"], rb["params"]) < 5e-4 and ra["losses"] == pytest.approx(rb["losses"], rel=1e-4)
 
 
 def _initial_params(args):
