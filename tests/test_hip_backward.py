@@ -629,3 +629,50 @@ def test_direct_step_with_solar_correction_matches_autograd_path():
     trg = Trainer(models, O.default_args(mlp_mode="bf16", sc_lambda=0.1))
     losses = [trg.step(rays, ts, target).item() for _ in range(20)]
     assert trg._graph is not None and all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("tau,n_rays", [(4, 300), (16, 41)])
+def test_generated_dx_trunk_writes_the_same_bytes_as_the_compiler_scheduled_one(monkeypatch, tau, n_rays):
+    """csrc/gen/bwd_core.py's instruction stream (the seven trunk layers of the dX kernel, default) against the compiler-scheduled loop of
+    csrc/mlp_bwd.inc (SATNERF_BWD_V1=1): the same arithmetic per value in the same order, so the dpre workspace -- MX8 bytes, scale bytes,
+    the table of exponent maxima behind the last tile -- and d_t must be identical bit for bit.  tau 16 = two aux fragments (other phase units)."""
+    from satnerf_amd import ops
+    from satnerf_amd.models import load_model
+
+    torch.manual_seed(0)
+    s, feat, mode = 64, 256, "bf16"
+    args = O.default_args(mlp_mode=mode, t_embbeding_tau=tau)
+    model = load_model(args).to(DEV)
+    emb = torch.nn.Embedding(30, tau).to(DEV)
+    rays, ts = O.synthetic_rays(n_rays, seed=9)
+    rays, ts = rays.to(DEV), ts.to(DEV)
+    n = n_rays * s
+    model.repack(mode, backward=True)
+    hi, lo, l0 = model.packed(mode)
+    bstream, _ = model.packed_backward()
+    z = ops.ray_sample(rays, torch.rand(n_rays, s, device=DEV), s)
+    acts = ops.acts_workspace(n, feat, DEV, 8)
+    albedo, sigma, sun_v, beta = ops.satnerf_mlp(rays[:, 0:3], rays[:, 3:6], rays[:, 8:11], z, emb.weight.data, ts, n, s, feat, tau, mode, hi, lo, l0,
+                                                 acts=acts, fmt=8)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    ga, gs, gv, gb = (torch.randn(n, 3, device=DEV, generator=g) * 1e-3, torch.randn(n, device=DEV, generator=g) * 1e-3,
+                      torch.randn(n, device=DEV, generator=g) * 1e-3, torch.randn(n, device=DEV, generator=g) * 1e-4)
+    # (bytes no kernel writes -- the unused half of the head groups' scale slots -- must not be compared as garbage: zeroed workspaces)
+    monkeypatch.setattr(ops, "_ws_empty", lambda n_, dtype, device, slot: torch.zeros(n_, dtype=dtype, device=device))
+    outs = []
+    for v1 in ("1", "0"):
+        monkeypatch.setenv("SATNERF_BWD_V1", v1)
+        dpre, d_t = ops.satnerf_mlp_bwd(feat, tau, n, bstream, acts, albedo, sigma, sun_v, beta, ga, gs, gv, gb, fmt=8)
+        torch.cuda.synchronize()
+        outs.append((dpre.clone(), d_t.clone()))
+    tiles = (n + 31) // 32
+    from satnerf_amd import packing
+
+    per_tile = packing.dpre8_units(feat) * 512
+    assert torch.equal(outs[0][1], outs[1][1])
+    a, b = outs[0][0][:tiles * per_tile].view(tiles, -1), outs[1][0][:tiles * per_tile].view(tiles, -1)
+    bad = (a != b).any(1).nonzero().view(-1)
+    assert bad.numel() == 0, (bad[:8], (a != b).sum().item())
+    ws_tiles = (tiles + 7) // 8 * 8
+    ta, tb = outs[0][0][ws_tiles * per_tile:], outs[1][0][ws_tiles * per_tile:]
+    assert torch.equal(ta[:(tiles + 3) // 4 * 8], tb[:(tiles + 3) // 4 * 8])
