@@ -44,25 +44,61 @@ from __future__ import annotations
 import os
 import sys
 
-X, Y = 0, 64
-ACC = (128, 144)
-AR0, NA = 160, 6
-PH0, NPH = 184, 4
-T0 = 200
-SV = (204, 208)
-EB = 212
-M, E, INV, MAGIC, K43 = 214, 215, 216, 218, 220
-VL0, VL1, VOFF, POFF, SOFF = 221, 222, 223, 224, 225
-T1 = 226
-VCELL = 230
-TT = 232            # sixteen temporaries: the tile's cosines, then the rounded MX8 values (even-aligned pairs)
-N_VGPR = 248
-IN_REGS = (MAGIC, K43, VL0, VL1, VOFF, POFF, SOFF, VCELL)   # operands of the statement (wired by mlp_bwd.inc)
+A0 = 256                     # unified register numbering: 0..255 = v, 256..511 = a (the 512-wide kernel: one wave per SIMD, both files)
+
+
+def rn(r, n=1):
+    f, i = ("v", r) if r < A0 else ("a", r - A0)
+    return f"{f}{i}" if n == 1 else f"{f}[{i}:{i + n - 1}]"
+
+
+class Geo:
+    """register map and sizes of one trunk width.  256: 8 waves x <= 256 VGPRs, both d pre vectors in VGPRs.  512: 4 waves x (256 VGPRs + 256
+    AGPRs): a 32-point vector is 128 registers -- X in v[0:127], Y and the A-fragment ring in AGPRs (MFMA reads A / B from either file,
+    ds_read_b128 writes either); what an epilogue produces for Y goes through v_accvgpr_write (as in gen/fwd_core512.py)."""
+
+    def __init__(self, feat):
+        assert feat in (256, 512)
+        self.feat = feat
+        self.KS, self.MT, self.NW, self.LAYERS = feat // 16, feat // 32, (8 if feat == 256 else 4), 7
+        self.R, self.GROUP, self.FILL = (96, 2, 6) if feat == 256 else (128, 1, 4)
+        self.NEB = self.MT // 4                      # registers of a layer's exponent bytes
+        if feat == 256:
+            self.X, self.Y = 0, 64
+            self.ACC = (128, 144)
+            self.AR0 = 160
+            self.PH0 = 184
+            self.T0 = 200                            # (unused since the producers-first epilogue; kept out of the clobbers' way)
+            self.SV = (204, 208)
+            self.EB = 212
+            self.M, self.E, self.INV, self.MAGIC, self.K43 = 214, 215, 216, 218, 220
+            self.VL0, self.VL1, self.VOFF, self.POFF, self.SOFF = 221, 222, 223, 224, 225
+            self.T1 = 226
+            self.VCELL = 230
+            self.TT = 232
+            self.N_VGPR, self.N_AGPR = 248, 0
+            self.D8_SCALE, self.GROUPS_PER_UNIT = 94, 2
+        else:
+            self.X, self.Y = 0, A0
+            self.ACC = (128, 144)
+            self.AR0 = A0 + 128
+            self.PH0 = 160
+            self.TT = 176
+            self.T1 = 192
+            self.SV = (196, 200)
+            self.EB = 204
+            self.M, self.E, self.INV, self.MAGIC, self.K43 = 208, 209, 210, 212, 214
+            self.VL0, self.VL1, self.VOFF, self.POFF, self.SOFF = 215, 216, 217, 218, 219
+            self.VCELL = 220
+            self.N_VGPR, self.N_AGPR = 222, 152
+            self.D8_SCALE, self.GROUPS_PER_UNIT = 186, 1
+        self.NA, self.NPH = 6, 4
+        self.IN_REGS = (self.MAGIC, self.K43, self.VL0, self.VL1, self.VOFF, self.POFF, self.SOFF, self.VCELL)   # operands (wired by mlp_bwd.inc)
+        self.XREGS = self.KS * 4                     # registers of a d pre vector
+
+
 S_SEL = ("s84", "s85", "s86", "s87")     # v_perm selectors of phase byte k: the byte lands in bits 8..15 of 0x43000000 (codec8.h phase8_rev)
 S_B4A, S_B4B, S_MAX = "s88", "s89", "s90"  # bytes4() selectors (codec8.h), the wave maximum
-NW, KS, MT, LAYERS = 8, 16, 8, 7
-D8_SCALE = 94      # kD8Scale (mlp_layout.h, width 256): unit of scale groups 0, 1
-GROUPS_PER_UNIT = 2
 
 
 class Ins:
@@ -73,16 +109,15 @@ class Ins:
 
 
 class Trunk:
-    def __init__(self, auxs, R=96, PF=5, GROUP=2, FILL=6, ablate=()):
-        assert R % NW == 0 and PF + 1 <= NA
-        self.auxs, self.R, self.PF, self.GROUP, self.FILL = auxs, R, PF, GROUP, FILL
+    def __init__(self, auxs, feat=256, PF=5, ablate=()):
+        self.g = g = Geo(feat)
+        self.auxs, self.R, self.PF, self.GROUP, self.FILL = auxs, g.R, PF, g.GROUP, g.FILL
+        assert self.R % g.NW == 0 and PF + 1 <= g.NA
         self.ablate = set(ablate)   # timing experiments (results wrong): noepi, nodma, nophase, nostore
         self.ins = []
         self.vm = []           # outstanding vector-memory LOADS in issue order (tags)
         self.p_unit = None     # unit POFF / SOFF currently point at
         self.s_unit = None
-        self.last_trans = {}   # register -> index of the v_cos that wrote it
-        self.last_valu = {}    # register -> index of the VALU instruction that wrote it
         self._build()
 
     def e(self, op, a, text):
@@ -101,39 +136,47 @@ class Trunk:
         return keep
 
     def dma_row(self, j):
-        imm = ((NW * j) % self.R) * 1024
+        g = self.g
+        imm = ((g.NW * j) % self.R) * 1024
         self.e("m0", (j,), f"s_add_u32 m0, %[wb], {imm}")
         self.e("nop", (0,), "s_nop 0")
-        self.e("dma", (j,), f"global_load_lds_dwordx4 v{VOFF}, %[sb]")
-        self.e("voff", (), f"v_add_u32 v{VOFF}, 0x2000, v{VOFF}")
+        self.e("dma", (j,), f"global_load_lds_dwordx4 v{g.VOFF}, %[sb]")
+        self.e("voff", (), f"v_add_u32 v{g.VOFF}, 0x{g.NW * 1024:x}, v{g.VOFF}")
         self.vm_issue(("row", j))
 
     def phase_unit(self, tau):
-        l, t = 7 - tau // MT, tau % MT           # layer bL_l multiplies by cos(phase a_{l-1}): unit A + 8 (l - 1) + t
-        return self.auxs + 8 * (l - 1) + t
+        g = self.g
+        l, t = 7 - tau // g.MT, tau % g.MT       # layer bL_l multiplies by cos(phase a_{l-1}): unit A + MT (l - 1) + t
+        return self.auxs + g.MT * (l - 1) + t
 
     def phase_load(self, tau):
+        g = self.g
         unit = self.phase_unit(tau)
         delta = (unit - self.p_unit) * 1024
         self.p_unit = unit
         if delta:
-            self.e("poff", (delta,), f"v_add_u32 v{POFF}, 0x{delta & 0xffffffff:x}, v{POFF}")
-        r = PH0 + 4 * (tau % NPH)
-        self.e("phload", (r, unit), f"global_load_dwordx4 v[{r}:{r + 3}], v{POFF}, %[ab] nt")
+            self.e("poff", (delta,), f"v_add_u32 v{g.POFF}, 0x{delta & 0xffffffff:x}, v{g.POFF}")
+        r = g.PH0 + 4 * (tau % g.NPH)
+        self.e("phload", (r, unit), f"global_load_dwordx4 v[{r}:{r + 3}], v{g.POFF}, %[ab] nt")
         self.vm_issue(("ph", tau))
 
     # ---- the epilogue of one tile: a list of closures, one instruction each ----------------------------------------------------------
     def epilogue_items(self, tau):
         """tile tau: accumulator ACC[tau & 1], phases PH[tau % 4]; d pre = acc * cos(2 pi u / 256) -> two bf16 B fragments of the next
         layer's input vector, MX8 bytes -> the dpre workspace (codec8.h: bit for bit what bpack / mx8_exponent / mx8_encode compute)"""
+        g = self.g
+        MT, TT, K43, EB, E, M, INV, MAGIC, T1, SOFF = g.MT, g.TT, g.K43, g.EB, g.E, g.M, g.INV, g.MAGIC, g.T1, g.SOFF
         l, t = 7 - tau // MT, tau % MT
-        a, ph = ACC[tau & 1], PH0 + 4 * (tau % NPH)
-        out = (Y if (7 - l) % 2 == 0 else X) + 8 * t
-        sv = SV[tau & 1]
+        a, ph = g.ACC[tau & 1], g.PH0 + 4 * (tau % g.NPH)
+        out = (g.Y if (7 - l) % 2 == 0 else g.X) + 8 * t
+        sv = g.SV[tau & 1]
         it = []
 
         def V(op, args, text):
             it.append(lambda: self.e(op, args, text))
+
+        def group(*parts):   # several instructions that must stay together (one epilogue item)
+            it.append(lambda: [self.e(op, args, text) for op, args, text in parts])
 
         def wait_phase():
             keep = self.vm_wait(("ph", tau))
@@ -144,19 +187,26 @@ class Trunk:
         # packs: every consumer sits >= 8 instructions behind its producer -- the wave issues in order, so an instruction waiting for the
         # transcendental unit (or for a packed-fp32 result) also holds back the wave's next MFMA (measured: the pair-wise pipelined order
         # perm perm cos cos perm perm pk_mul ... ran the trunk at 58 cycles per MFMA slot against 40 without the epilogue)
-        for g in range(16):
-            V("perm_ph", (TT + g, ph + (g >> 2), g & 3), f"v_perm_b32 v{TT + g}, v{K43}, v{ph + (g >> 2)}, {S_SEL[g & 3]}")
-        for g in range(16):
-            V("cos", (TT + g,), f"v_cos_f32 v{TT + g}, v{TT + g}")
+        for gg in range(16):
+            V("perm_ph", (TT + gg, ph + (gg >> 2), gg & 3), f"v_perm_b32 v{TT + gg}, v{K43}, v{ph + (gg >> 2)}, {S_SEL[gg & 3]}")
+        for gg in range(16):
+            V("cos", (TT + gg,), f"v_cos_f32 v{TT + gg}, v{TT + gg}")
         for q in range(8):
-            g = 2 * q
-            V("pkmul", (a + g, TT + g), f"v_pk_mul_f32 v[{a + g}:{a + g + 1}], v[{a + g}:{a + g + 1}], v[{TT + g}:{TT + g + 1}]")
-        for q in range(8):
-            g = 2 * q
-            V("pk", (out + q, a + g, a + g + 1), f"v_cvt_pk_bf16_f32 v{out + q}, v{a + g}, v{a + g + 1}")
+            gg = 2 * q
+            V("pkmul", (a + gg, TT + gg), f"v_pk_mul_f32 v[{a + gg}:{a + gg + 1}], v[{a + gg}:{a + gg + 1}], v[{TT + gg}:{TT + gg + 1}]")
+        if out < A0:
+            for q in range(8):
+                gg = 2 * q
+                V("pk", (out + q, a + gg, a + gg + 1), f"v_cvt_pk_bf16_f32 v{out + q}, v{a + gg}, v{a + gg + 1}")
+        else:   # the output vector lives in AGPRs: pack into the (now dead) cosine temporaries, then eight v_accvgpr_write
+            for q in range(8):
+                gg = 2 * q
+                V("pk", (TT + q, a + gg, a + gg + 1), f"v_cvt_pk_bf16_f32 v{TT + q}, v{a + gg}, v{a + gg + 1}")
+            for q in range(8):
+                V("accw", (out + q, TT + q), f"v_accvgpr_write_b32 {rn(out + q)}, v{TT + q}")
         # maximum of the 16 magnitudes (exact whatever the order): 8 instructions
         m, t1, t2 = M, T1, T1 + 1
-        ab = lambda g: f"|v{a + g}|"  # noqa: E731
+        ab = lambda k: f"|v{a + k}|"  # noqa: E731
         V("max3", (m, a + 0, a + 1, a + 2), f"v_max3_f32 v{m}, {ab(0)}, {ab(1)}, {ab(2)}")
         V("max3", (t1, a + 3, a + 4, a + 5), f"v_max3_f32 v{t1}, {ab(3)}, {ab(4)}, {ab(5)}")
         V("max3", (t2, a + 6, a + 7, a + 8), f"v_max3_f32 v{t2}, {ab(6)}, {ab(7)}, {ab(8)}")
@@ -179,17 +229,18 @@ class Trunk:
         # u = low mantissa byte of v * 2^(133 - E) + (1.5 * 2^23 + 128): two values per v_pk_fma_f32, three v_perm per four bytes; again
         # producers first (eight fmas into the sixteen temporaries), then the byte gathers
         for q in range(8):
-            g = 2 * q
-            V("pkfma", (TT + g, a + g), f"v_pk_fma_f32 v[{TT + g}:{TT + g + 1}], v[{a + g}:{a + g + 1}], v[{INV}:{INV + 1}], v[{MAGIC}:{MAGIC + 1}] op_sel_hi:[1,0,0]")
+            gg = 2 * q
+            V("pkfma", (TT + gg, a + gg), f"v_pk_fma_f32 v[{TT + gg}:{TT + gg + 1}], v[{a + gg}:{a + gg + 1}], v[{INV}:{INV + 1}], v[{MAGIC}:{MAGIC + 1}] op_sel_hi:[1,0,0]")
         for q4 in range(4):
-            g = 4 * q4
-            V("b4a", (TT + g, TT + g + 1, TT + g), f"v_perm_b32 v{TT + g}, v{TT + g + 1}, v{TT + g}, {S_B4A}")
-            V("b4a", (TT + g + 2, TT + g + 3, TT + g + 2), f"v_perm_b32 v{TT + g + 2}, v{TT + g + 3}, v{TT + g + 2}, {S_B4A}")
+            gg = 4 * q4
+            V("b4a", (TT + gg, TT + gg + 1, TT + gg), f"v_perm_b32 v{TT + gg}, v{TT + gg + 1}, v{TT + gg}, {S_B4A}")
+            V("b4a", (TT + gg + 2, TT + gg + 3, TT + gg + 2), f"v_perm_b32 v{TT + gg + 2}, v{TT + gg + 3}, v{TT + gg + 2}, {S_B4A}")
         for q4 in range(4):
-            g = 4 * q4
-            V("b4b", (sv + q4, TT + g + 2, TT + g), f"v_perm_b32 v{sv + q4}, v{TT + g + 2}, v{TT + g}, {S_B4B}")
+            gg = 4 * q4
+            V("b4b", (sv + q4, TT + gg + 2, TT + gg), f"v_perm_b32 v{sv + q4}, v{TT + gg + 2}, v{TT + gg}, {S_B4B}")
+
         def store():
-            unit = 8 * (l - 1) + t
+            unit = MT * (l - 1) + t
             delta = (unit - self.s_unit) * 1024
             self.s_unit = unit
             if delta:
@@ -197,24 +248,29 @@ class Trunk:
             self.e("store", (sv, unit), f"global_store_dwordx4 v{SOFF}, v[{sv}:{sv + 3}], %[db] nt")
         it.append(store)
         if t == MT - 1:
-            g = l - 1   # the layer's eight scale bytes: group l - 1 -> unit kD8Scale + (l - 1) / 2, bytes 8 ((l - 1) % 2) ..
+            grp = l - 1   # the layer's MT scale bytes: group l - 1 -> unit kD8Scale + (l - 1) / groups per unit, its slot of the lane's 16 bytes
 
             def store_scale():
-                unit = D8_SCALE + g // GROUPS_PER_UNIT
+                unit = g.D8_SCALE + grp // g.GROUPS_PER_UNIT
                 delta = (unit - self.s_unit) * 1024
                 self.s_unit = unit
+                off = MT * (grp % g.GROUPS_PER_UNIT)
                 self.e("soff", (delta,), f"v_add_u32 v{SOFF}, 0x{delta & 0xffffffff:x}, v{SOFF}")
-                self.e("store2", (EB, unit, 8 * (g % GROUPS_PER_UNIT)), f"global_store_dwordx2 v{SOFF}, v[{EB}:{EB + 1}], %[db] offset:{8 * (g % GROUPS_PER_UNIT)}")
+                self.e("store2", (EB, unit, off), f"global_store_dwordx{g.NEB} v{SOFF}, v[{EB}:{EB + g.NEB - 1}], %[db]" + (f" offset:{off}" if g.GROUPS_PER_UNIT > 1 else ""))
             it.append(store_scale)
-            # largest of the lane's eight bytes, then of the wave (lane 63 after the row broadcasts), -> cell g of the wave's maxima
+            # largest of the lane's MT bytes, then of the wave (lane 63 after the row broadcasts), -> cell `grp` of the wave's maxima
             c = T1
-            for j, (reg, b0, b1) in enumerate(((EB, 0, 1), (EB, 2, 3), (EB + 1, 0, 1), (EB + 1, 2, 3))):
-                V("bmax", (c + j, reg, b0, b1), f"v_max_u32_sdwa v{c + j}, v{reg}, v{reg} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_{b0} src1_sel:BYTE_{b1}")
+            n = 0
+            for r in range(g.NEB):
+                for b0 in (0, 2):
+                    dst = c + (n & 3) if n < 4 else TT + (n - 4)          # (the 512-wide layer has eight pair maxima)
+                    V("bmax", (dst, EB + r, b0, b0 + 1), f"v_max_u32_sdwa v{dst}, v{EB + r}, v{EB + r} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_{b0} src1_sel:BYTE_{b0 + 1}")
+                    n += 1
             V("umax3", (c, c, c + 1, c + 2), f"v_max3_u32 v{c}, v{c}, v{c + 1}, v{c + 2}")
             V("umax", (c, c, c + 3), f"v_max_u32 v{c}, v{c}, v{c + 3}")
-            def group(*parts):   # several instructions that must stay together (one epilogue item)
-                it.append(lambda: [self.e(op, args, text) for op, args, text in parts])
-
+            if g.NEB > 2:
+                V("umax3", (c + 1, TT, TT + 1, TT + 2), f"v_max3_u32 v{c + 1}, v{TT}, v{TT + 1}, v{TT + 2}")
+                V("umax3", (c, c, c + 1, TT + 3), f"v_max3_u32 v{c}, v{c}, v{c + 1}, v{TT + 3}")
             for ctrl in ("row_shr:1", "row_shr:2", "row_shr:4", "row_shr:8", "row_bcast:15 row_mask:0xa", "row_bcast:31 row_mask:0xc"):
                 group(("nop", (1,), "s_nop 1"),   # VALU write -> DPP read of the same register: two wait states
                       ("dppmax", (c, ctrl), f"v_max_u32_dpp v{c}, v{c}, v{c} {ctrl}" + ("" if "row_mask" in ctrl else " row_mask:0xf") + " bank_mask:0xf"))
@@ -222,22 +278,18 @@ class Trunk:
                   ("readlane", (c,), f"v_readlane_b32 {S_MAX}, v{c}, 63"))
             V("smov", (c + 1,), f"v_mov_b32 v{c + 1}, {S_MAX}")
             # one lane writes the cell; nothing else may issue while EXEC is narrowed (an A-fragment read would load one lane)
-            group(("exec1", (), "s_mov_b64 exec, 1"), ("cell", (c + 1, g), f"ds_write_b32 v{VCELL}, v{c + 1} offset:{4 * g}"), ("execall", (), "s_mov_b64 exec, -1"))
+            group(("exec1", (), "s_mov_b64 exec, 1"), ("cell", (c + 1, grp), f"ds_write_b32 v{g.VCELL}, v{c + 1} offset:{4 * grp}"), ("execall", (), "s_mov_b64 exec, -1"))
         return it
 
     def emit_item(self, f):
-        """one epilogue instruction, with the wait states the assembler does not insert in inline asm"""
         n0 = len(self.ins)
         f()
-        for k in range(n0, len(self.ins)):
-            x = self.ins[k]
-            if x.op == "cos":
-                self.last_trans[x.a[0]] = k
         return len(self.ins) - n0
 
     def _build(self):
-        R, PF, G = self.R, self.PF, self.GROUP
-        NT = LAYERS * MT                      # 56 tiles = chunks of 16 pieces
+        g = self.g
+        R, PF, G, KS, MT, NW = self.R, self.PF, self.GROUP, g.KS, g.MT, g.NW
+        NT = g.LAYERS * MT                    # tiles = chunks of KS pieces
         N = NT * KS
         n_rows = N // NW
         self.e("savem0", (), "s_mov_b32 %[m0save], m0")
@@ -270,9 +322,9 @@ class Trunk:
 
         def dsread(i):
             slot = i % R
-            base, off = (VL0, slot * 1024) if slot < 64 else (VL1, (slot - 64) * 1024)
-            d = AR0 + 4 * (i % NA)
-            self.e("dsread", (d, slot), f"ds_read_b128 v[{d}:{d + 3}], v{base} offset:{off}")
+            base, off = (g.VL0, slot * 1024) if slot < 64 else (g.VL1, (slot - 64) * 1024)
+            d = g.AR0 + 4 * (i % g.NA)
+            self.e("dsread", (d, slot), f"ds_read_b128 {rn(d, 4)}, v{base} offset:{off}")
 
         # the workspace offsets start at the tile's base (unit 0)
         self.p_unit, self.s_unit = 0, 0
@@ -297,22 +349,22 @@ class Trunk:
         for i in range(N):
             ti, k = divmod(i, KS)
             l = 7 - ti // MT
-            inp = X if (7 - l) % 2 == 0 else Y
-            acc = ACC[ti & 1]
+            inp = g.X if (7 - l) % 2 == 0 else g.Y
+            acc = g.ACC[ti & 1]
             if k == 0:
                 # the tile before last's epilogue still reads this accumulator: it must be out (and every B fragment of a new layer
-                # is produced by the previous layer's epilogues: tile 7's runs during this tile, k-steps 14, 15 come last)
+                # is produced by the previous layer's epilogues: the last tile's runs during this tile, its two k-steps come last)
                 while epi and epi[0][2] <= ti - 2:
                     self.emit_item(epi.pop(0)[1])
-            if ti % MT == 0 and k >= 14:
+            if ti % MT == 0 and k >= KS - 2:
                 while epi and epi[0][2] < ti:
                     self.emit_item(epi.pop(0)[1])
-                if k == 14:
+                if k == KS - 2:
                     self.e("nop", (1,), "s_nop 1")  # VALU write -> MFMA operand: two wait states
             self.e("waitl", (min(PF - 1, N - 1 - i),), f"s_waitcnt lgkmcnt({min(PF - 1, N - 1 - i)})")
             c = "0" if k == 0 else f"v[{acc}:{acc + 15}]"
-            areg = AR0 + 4 * (i % NA)
-            self.e("mfma", (acc, areg, inp + 4 * k, k == 0), f"v_mfma_f32_32x32x16_bf16 v[{acc}:{acc + 15}], v[{areg}:{areg + 3}], v[{inp + 4 * k}:{inp + 4 * k + 3}], {c}")
+            areg = g.AR0 + 4 * (i % g.NA)
+            self.e("mfma", (acc, areg, inp + 4 * k, k == 0), f"v_mfma_f32_32x32x16_bf16 v[{acc}:{acc + 15}], {rn(areg, 4)}, {rn(inp + 4 * k, 4)}, {c}")
             if k == KS - 1:
                 for f in self.epilogue_items(ti):
                     epi.append([i + 2, f, ti])
@@ -344,20 +396,20 @@ class Trunk:
 
     # ---- static checks of what the assembler would have padded in compiler-scheduled code -------------------------------------------
     def _check_hazards(self):
-        VALU_W = {"perm_ph": 0, "cos": 0, "pkmul": None, "pk": 0, "max3": 0, "max3r": 0, "max3m": 0, "max2": 0, "mx_e1": 0, "mx_e2": 0, "mx_e3a": 0,
-                  "mx_e3": 0, "mx_e4": 0, "mx_e5": 0, "mx_e6": 0, "pkfma": None, "b4a": 0, "b4b": 0, "bmax": 0, "umax3": 0, "umax": 0, "dppmax": 0,
-                  "smov": 0}
+        g = self.g
+        VALU_W = {"perm_ph", "cos", "pkmul", "pk", "accw", "max3", "max3r", "max3m", "max2", "mx_e1", "mx_e2", "mx_e3a", "mx_e3", "mx_e4", "mx_e5",
+                  "mx_e6", "pkfma", "b4a", "b4b", "bmax", "umax3", "umax", "dppmax", "smov"}
         last_cos, last_w, last_mfma_d = {}, {}, {}
         for idx, x in enumerate(self.ins):
             reads, writes = set(), set()
             if x.op in VALU_W:
-                if x.op in ("pkmul",):
+                if x.op == "pkmul":
                     a, tp = x.a
                     reads |= {a, a + 1, tp, tp + 1}
                     writes |= {a, a + 1}
                 elif x.op == "pkfma":
                     d, a = x.a
-                    reads |= {a, a + 1, INV, MAGIC}
+                    reads |= {a, a + 1, g.INV, g.MAGIC}
                     writes |= {d, d + 1}
                 elif x.op == "perm_ph":
                     writes.add(x.a[0]), reads.add(x.a[1])
@@ -369,11 +421,9 @@ class Trunk:
                     reads |= set(regs[1:]) if x.op not in ("mx_e6", "bmax") else {x.a[1]}
                     if x.op in ("mx_e1", "mx_e3a", "mx_e3", "mx_e5", "dppmax", "umax3", "umax", "max3r", "max3m", "max2"):
                         reads.add(regs[0])
-                # trans -> VALU use: at least one instruction in between
-                for r in reads:
+                for r in reads:   # trans -> VALU use: at least one instruction in between
                     assert idx - last_cos.get(r, -10) >= 2, ("trans -> VALU use", idx, x.text)
-                # MFMA D -> VALU read: the tile's last MFMA at least two MFMAs back
-                for r in reads:
+                for r in reads:   # MFMA D -> VALU read: the tile's last MFMA at least two MFMAs back (or 18 wait states)
                     if r in last_mfma_d:
                         n_mf = sum(1 for y in self.ins[last_mfma_d[r] + 1:idx] if y.op == "mfma")
                         states = sum(y.a[0] + 1 for y in self.ins[last_mfma_d[r] + 1:idx] if y.op == "nop")
@@ -415,17 +465,27 @@ class Trunk:
         return [x.text for x in self.ins if x.op not in drop]
 
     def inc_file(self):
+        g = self.g
         head = ["// GENERATED by csrc/gen/bwd_core.py -- do not edit (tests/test_bwd_core.py checks it is current).",
-                f"// dX trunk, AUXS = {self.auxs}: {self.stats.get('mfma', 0)} MFMAs, {len(self.ins)} instructions ({len(self.ins) / max(self.stats.get('mfma', 1), 1):.2f} per MFMA), "
+                f"// dX trunk, width {g.feat}, AUXS = {self.auxs}: {self.stats.get('mfma', 0)} MFMAs, {len(self.ins)} instructions ({len(self.ins) / max(self.stats.get('mfma', 1), 1):.2f} per MFMA), "
                 f"{self.stats.get('barrier', 0)} rendezvous, ring of {self.R} pieces, A fragments {self.PF} ahead, {self.FILL} epilogue instructions per gap."]
         return "\n".join(head + ['"' + t + '\\n"' for t in self.text()]) + "\n"
 
 
-def clobber_file():
-    regs = [r for r in range(64, N_VGPR) if r not in IN_REGS]
+def clobber_file(feat=256):
+    g = Geo(feat)
+    regs = [r for r in range(g.XREGS if g.Y >= A0 else g.Y, g.N_VGPR) if r not in g.IN_REGS]
+    if feat == 256:
+        regs = [r for r in range(64, g.N_VGPR) if r not in g.IN_REGS]
     sregs = list(S_SEL) + [S_B4A, S_B4B, S_MAX]
-    return ("// GENERATED by csrc/gen/bwd_core.py: clobber list of the dX trunk statement (X = v[0:63] is in/out, v218 v220..v225 v230 are inputs)\n"
-            + ", ".join(f'"v{r}"' for r in regs) + ", " + ", ".join(f'"{s}"' for s in sregs) + ', "memory", "scc"\n')
+    return (f"// GENERATED by csrc/gen/bwd_core.py: clobber list of the dX trunk statement, width {feat} (the X vector is in/out, the constants and offsets are inputs)\n"
+            + ", ".join(f'"v{r}"' for r in regs) + ("".join(f', "a{r}"' for r in range(g.N_AGPR))) + ", " + ", ".join(f'"{s_}"' for s_ in sregs)
+            + ', "memory", "scc"\n')
+
+
+def file_names(feat, auxs, suffix=""):
+    stem = "mlp_bwd_trunk" if feat == 256 else "mlp_bwd512_trunk"
+    return f"{stem}_a{auxs}{suffix}.inc", f"{stem}_clobbers.inc"
 
 
 def main():
@@ -435,13 +495,15 @@ def main():
         out_dir = sys.argv[1]
     suffix = sys.argv[2] if len(sys.argv) > 2 else ""
     ablate = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ()
-    for auxs in (1, 2):
-        t = Trunk(auxs, ablate=ablate)
-        with open(os.path.join(out_dir, f"mlp_bwd_trunk_a{auxs}{suffix}.inc"), "w") as f:
-            f.write(t.inc_file())
-        print(auxs, len(t.ins), "instructions,", t.stats.get("mfma"), "MFMAs;", {k: v for k, v in sorted(t.stats.items())})
-    with open(os.path.join(out_dir, "mlp_bwd_trunk_clobbers.inc"), "w") as f:
-        f.write(clobber_file())
+    for feat in (256, 512):
+        for auxs in (1, 2):
+            t = Trunk(auxs, feat=feat, ablate=ablate)
+            name, cname = file_names(feat, auxs, suffix)
+            with open(os.path.join(out_dir, name), "w") as f:
+                f.write(t.inc_file())
+            print(feat, auxs, len(t.ins), "instructions,", t.stats.get("mfma"), "MFMAs,", round(len(t.ins) / t.stats.get("mfma"), 2), "per MFMA")
+        with open(os.path.join(out_dir, cname), "w") as f:
+            f.write(clobber_file(feat))
 
 
 if __name__ == "__main__":

@@ -25,13 +25,15 @@ def _gen():
     return m
 
 
+@pytest.mark.parametrize("feat", [256, 512])
 @pytest.mark.parametrize("auxs", [1, 2])
-def test_generated_files_are_current(auxs):
+def test_generated_files_are_current(auxs, feat):
     g = _gen()
-    with open(os.path.join(ROOT, "satnerf_amd", "csrc", f"mlp_bwd_trunk_a{auxs}.inc")) as f:
-        assert f.read() == g.Trunk(auxs).inc_file(), "re-run satnerf_amd/csrc/gen/bwd_core.py"
-    with open(os.path.join(ROOT, "satnerf_amd", "csrc", "mlp_bwd_trunk_clobbers.inc")) as f:
-        assert f.read() == g.clobber_file()
+    name, cname = g.file_names(feat, auxs)
+    with open(os.path.join(ROOT, "satnerf_amd", "csrc", name)) as f:
+        assert f.read() == g.Trunk(auxs, feat=feat).inc_file(), "re-run satnerf_amd/csrc/gen/bwd_core.py"
+    with open(os.path.join(ROOT, "satnerf_amd", "csrc", cname)) as f:
+        assert f.read() == g.clobber_file(feat)
 
 
 def _bf16_bits(x):
@@ -63,9 +65,10 @@ def _frag_f32(quad):
 class Machine:
     """one wave of the workgroup, the other seven in lock step (every LDS-DMA row brings all eight waves' pieces)"""
 
-    def __init__(self, g, trunk, stream_bits, acts, x0):
-        self.g, self.t = g, trunk
-        self.v = np.zeros((256, 64), np.uint32)
+    def __init__(self, gen, trunk, stream_bits, acts, x0):
+        self.gen, self.t = gen, trunk
+        self.g = g = trunk.g                                   # register map / sizes of this width (gen/bwd_core.py Geo)
+        self.v = np.zeros((512, 64), np.uint32)                # unified numbering: 0..255 VGPRs, 256..511 AGPRs
         self.s = {}
         self.ring = np.zeros((trunk.R, 64, 4), np.uint32)
         self.ring_piece = [-1] * trunk.R
@@ -76,7 +79,7 @@ class Machine:
         self.exec1 = False
         self.visible_rows = -1                               # rows made visible by the last rendezvous
         self.landed_rows = -1
-        for k in range(16):
+        for k in range(g.KS):
             self.v[g.X + 4 * k:g.X + 4 * k + 4] = x0[k]
         self.v[g.MAGIC] = _u32(np.full(64, 12583040.0, np.float32))
         self.v[g.K43] = 0x43000000
@@ -93,8 +96,8 @@ class Machine:
             op = self.vmq.pop(0)
             if op[0] == "row":
                 j = op[1]
-                for w in range(8):
-                    p = 8 * j + w
+                for w in range(self.g.NW):
+                    p = self.g.NW * j + w
                     self.ring[p % self.t.R] = self.stream[p]
                     self.ring_piece[p % self.t.R] = p
                 self.landed_rows = j
@@ -131,17 +134,17 @@ class Machine:
             if op == "sconst":
                 self.s[a[0]] = int(x.text.split(",")[1].strip(), 16)
             elif op == "m0":
-                self.s["m0"] = ((8 * a[0]) % self.t.R) * 1024   # + wave * 1024 (wave 0)
+                self.s["m0"] = ((g.NW * a[0]) % self.t.R) * 1024   # + wave * 1024 (wave 0)
             elif op == "dma":
                 j = a[0]
-                assert self.s["m0"] == ((8 * j) % self.t.R) * 1024
-                assert int(self.v[g.VOFF][0]) == j * 8192, ("stream offset", j, int(self.v[g.VOFF][0]))
-                for w in range(8):                               # the slots this row overwrites must have been consumed by this wave's reads
-                    old = self.ring_piece[(8 * j + w) % self.t.R]
+                assert self.s["m0"] == ((g.NW * j) % self.t.R) * 1024
+                assert int(self.v[g.VOFF][0]) == j * g.NW * 1024, ("stream offset", j, int(self.v[g.VOFF][0]))
+                for w in range(g.NW):                            # the slots this row overwrites must have been consumed by this wave's reads
+                    old = self.ring_piece[(g.NW * j + w) % self.t.R]
                     assert old < 0 or old < self.next_read, ("LDS-DMA row over a piece not read yet", j, old, self.next_read)
                 self.vmq.append(("row", j))
             elif op == "voff":
-                self.v[g.VOFF] += 0x2000
+                self.v[g.VOFF] += g.NW * 1024
             elif op == "poff":
                 self.v[g.POFF] = (self.v[g.POFF].astype(np.int64) + a[0]).astype(np.uint32)
             elif op == "soff":
@@ -162,7 +165,7 @@ class Machine:
                 piece = self.next_read
                 self.next_read += 1
                 assert piece % self.t.R == slot
-                assert piece // 8 <= self.visible_rows, ("piece read before the rendezvous that makes it visible", piece, self.visible_rows)
+                assert piece // g.NW <= self.visible_rows, ("piece read before the rendezvous that makes it visible", piece, self.visible_rows)
                 self._ready(dst, dst + 1, dst + 2, dst + 3)
                 self.lgkm.append(("rd", dst, slot, piece))
             elif op == "mfma":
@@ -194,6 +197,8 @@ class Machine:
             elif op == "pk":
                 dst, r0, r1 = a
                 self.v[dst] = _bf16_bits(_f32(self.v[r0])) | (_bf16_bits(_f32(self.v[r1])) << 16)
+            elif op == "accw":
+                self.v[a[0]] = self.v[a[1]]
             elif op in ("max3", "max3r", "max3m", "max2"):
                 dst = a[0]
                 vals = [_f32(self.v[r]) for r in a[1:]]
@@ -236,7 +241,7 @@ class Machine:
             elif op == "store2":
                 eb, unit, off = a
                 assert int(self.v[g.SOFF][0]) == unit * 1024
-                self.scale_stores[(unit, off)] = self.v[eb:eb + 2].T.copy()
+                self.scale_stores[(unit, off)] = self.v[eb:eb + g.NEB].T.copy()
             elif op == "bmax":
                 dst, reg, b0, b1 = a
                 self.v[dst] = np.maximum((self.v[reg] >> (8 * b0)) & 0xFF, (self.v[reg] >> (8 * b1)) & 0xFF)
@@ -262,9 +267,9 @@ class Machine:
                         out[lane] = max(src[lane], src[31])
                 self.v[r] = out
             elif op == "readlane":
-                self.s[g.S_MAX] = int(self.v[a[0]][63])
+                self.s[self.gen.S_MAX] = int(self.v[a[0]][63])
             elif op == "smov":
-                self.v[a[0]] = self.s[g.S_MAX]
+                self.v[a[0]] = self.s[self.gen.S_MAX]
             elif op == "exec1":
                 self.exec1 = True
             elif op == "cell":
@@ -284,56 +289,56 @@ class Machine:
         assert self.mfma_pending.get(base, 99) >= 2 or True  # (the generator's own hazard check covers the wait states)
 
 
-@pytest.mark.parametrize("tau", [4, 16])
-def test_instruction_stream_computes_the_trunk(tau):
-    g = _gen()
+@pytest.mark.parametrize("feat,tau", [(256, 4), (256, 16), (512, 4)])
+def test_instruction_stream_computes_the_trunk(feat, tau):
+    gen = _gen()
     auxs = packing.aux_steps(tau)
-    trunk = g.Trunk(auxs)
-    bm = packing.backward_maps(256, tau)
+    trunk = gen.Trunk(auxs, feat=feat)
+    G = trunk.g
+    KS, MT = G.KS, G.MT
+    bm = packing.backward_maps(feat, tau)
     rng = np.random.default_rng(11)
     n_params = bm["n_params"]
     flat = rng.uniform(-0.06, 0.06, n_params).astype(np.float32)
     vals = np.where(bm["idx"] >= 0, flat[np.maximum(bm["idx"], 0)] * bm["scale"], np.float32(0)).astype(np.float32)
     bits = _bf16_bits(vals).reshape(-1, 64, 8)
-    # the trunk's part of the transposed stream: everything behind bG1 (mlp_layout.h BwdStream: bH 12 | bS3, bS2 2 x 32 | bG2 8 x 24 | bDT 8 | bG1 8 x 17)
-    first = 12 + 32 + 32 + 8 * 24 + 8 + 8 * 17
+    # the trunk's part of the transposed stream: everything behind bG1 (mlp_layout.h BwdStream: bH | bS3 | bS2 | bG2 | bDT | bG1)
+    hs, mth = KS // 2, MT // 2
+    first = 3 * mth + 2 * (mth * hs) + MT * 3 * hs + hs + MT * (KS + 1)
     bits = bits[first:]
-    assert bits.shape[0] == 7 * 8 * 16
+    assert bits.shape[0] == 7 * MT * KS
     stream_bits = (bits[:, :, 0::2] | (bits[:, :, 1::2] << 16)).astype(np.uint32)          # [piece, lane, 4]
-    acts = {u: rng.integers(0, 2 ** 32, (64, 4), dtype=np.uint64).astype(np.uint32) for u in range(auxs, auxs + 56)}   # PHASE8 units of a0..a6
-    d7 = (rng.normal(size=(256, 32)) * 1e-3).astype(np.float32)                           # d pre_7 [feature slot][point]
+    acts = {u: rng.integers(0, 2 ** 32, (64, 4), dtype=np.uint64).astype(np.uint32) for u in range(auxs, auxs + 7 * MT)}   # PHASE8 units of a0..a6
+    d7 = (rng.normal(size=(feat, 32)) * 1e-3).astype(np.float32)                          # d pre_7 [feature slot][point]
     x0 = []
-    for k in range(16):                                                                     # B fragment k: lane (p, h) holds slots 16 k + 8 h + j
+    for k in range(KS):                                                                     # B fragment k: lane (p, h) holds slots 16 k + 8 h + j
         fr = np.zeros((64, 8), np.float32)
         for lane in range(64):
             fr[lane] = d7[16 * k + 8 * (lane >> 5): 16 * k + 8 * (lane >> 5) + 8, lane & 31]
         b = _bf16_bits(fr)
         x0.append(np.stack([b[:, 2 * q] | (b[:, 2 * q + 1] << 16) for q in range(4)]))
-    m = Machine(g, trunk, stream_bits, acts, x0)
-    assert m.run() == 896 and not m.vmq and not m.lgkm
+    m = Machine(gen, trunk, stream_bits, acts, x0)
+    assert m.run() == 7 * MT * KS and not m.vmq and not m.lgkm
 
     # ---- reference: the seven layers straight from the pieces, float64 contraction, float32 element-wise as the kernel ------------------
     cur = _bf16_f32(_bf16_bits(d7)).astype(np.float64)                                      # [slot, point]
     piece = 0
     for l in range(7, 0, -1):
-        nxt = np.zeros((256, 32), np.float32)
-        ebytes = np.zeros((8, 64), np.uint32)
-        for t in range(8):
+        nxt = np.zeros((feat, 32), np.float32)
+        ebytes = np.zeros((MT, 64), np.uint32)
+        for t in range(MT):
             D = np.zeros((32, 32))
-            for k in range(16):
+            for k in range(KS):
                 A = _bf16_f32(bits[piece]).astype(np.float64).reshape(2, 32, 8)            # [h, row, j] = W^T rows of this tile, k-slots 16 k + 8 h + j
                 piece += 1
                 for h in range(2):
                     D += A[h] @ cur[16 * k + 8 * h: 16 * k + 8 * h + 8]
-            unit = auxs + 8 * (l - 1) + t
+            unit = auxs + MT * (l - 1) + t
             ph = acts[unit]                                                                  # [lane, 4 dwords]: value g = byte g & 3 of dword g >> 2
-            v = np.zeros((64, 16), np.float32)
-            for lane in range(64):
-                p, h = lane & 31, lane >> 5
-                for gg in range(16):
-                    u = (int(ph[lane, gg >> 2]) >> (8 * (gg & 3))) & 0xFF
-                    c = np.float32(np.cos(2 * np.pi * (u / 256.0)))
-                    v[lane, gg] = np.float32(D[(gg & 3) + 8 * (gg >> 2) + 4 * h, p]) * c
+            u = np.stack([(ph[:, gg >> 2] >> (8 * (gg & 3))) & 0xFF for gg in range(16)], 1).astype(np.float64)   # [lane, g]
+            c = np.cos(2 * np.pi * (u / 256.0)).astype(np.float32)
+            rows = (np.arange(16)[None, :] & 3) + 8 * (np.arange(16)[None, :] >> 2) + 4 * (LANE[:, None] >> 5)
+            v = D[rows, (LANE & 31)[:, None]].astype(np.float32) * c                        # [lane, g]
             # next layer's B fragments 2 t, 2 t + 1: slot 32 t + 16 s + 8 h + j holds value g = 8 s + j of lane (p, h)
             for lane in range(64):
                 p, h = lane & 31, lane >> 5
@@ -343,18 +348,19 @@ def test_instruction_stream_computes_the_trunk(tau):
             e = np.clip((_u32((mx * 0.0078125 + mx).astype(np.float32)) >> 23).astype(np.int64), 6, 254)
             ebytes[t] = e
             want = np.rint(v.astype(np.float64) * (2.0 ** (133 - e))[:, None]).astype(np.int64) + 128
-            got_q = m.stores[8 * (l - 1) + t]                                                # [lane, 4 dwords]
+            got_q = m.stores[MT * (l - 1) + t]                                               # [lane, 4 dwords]
             got = np.stack([(got_q[:, gg >> 2] >> (8 * (gg & 3))) & 0xFF for gg in range(16)], 1).astype(np.int64)
             assert np.abs(got - want).max() <= 1, (l, t, np.abs(got - want).max())          # (+-1: fp32 accumulation order of the contraction)
-        sc = m.scale_stores[(94 + (l - 1) // 2, 8 * ((l - 1) % 2))]                        # two dwords per lane: bytes = E of tiles 0..7
-        got_e = np.stack([(sc[:, t >> 2] >> (8 * (t & 3))) & 0xFF for t in range(8)])
+        grp = l - 1
+        sc = m.scale_stores[(G.D8_SCALE + grp // G.GROUPS_PER_UNIT, MT * (grp % G.GROUPS_PER_UNIT))]   # NEB dwords per lane: bytes = E of the layer's tiles
+        got_e = np.stack([(sc[:, t >> 2] >> (8 * (t & 3))) & 0xFF for t in range(MT)])
         assert np.abs(got_e.astype(np.int64) - ebytes.astype(np.int64)).max() <= 1
-        assert m.cells[l - 1] == int(got_e.max()), (l, m.cells[l - 1], int(got_e.max()))   # the wave maximum of exactly the bytes it stored
+        assert m.cells[grp] == int(got_e.max()), (l, m.cells[grp], int(got_e.max()))      # the wave maximum of exactly the bytes it stored
         cur = _bf16_f32(_bf16_bits(nxt)).astype(np.float64)
     # the last layer's output vector (d pre_0, bf16 B fragments) sits in Y
-    out = np.zeros((256, 32), np.float32)
-    for k in range(16):
-        fr = _frag_f32(m.v[g.Y + 4 * k:g.Y + 4 * k + 4])
+    out = np.zeros((feat, 32), np.float32)
+    for k in range(KS):
+        fr = _frag_f32(m.v[G.Y + 4 * k:G.Y + 4 * k + 4])
         for lane in range(64):
             out[16 * k + 8 * (lane >> 5): 16 * k + 8 * (lane >> 5) + 8, lane & 31] = fr[lane]
     assert np.abs(out - cur).max() <= 2.0 ** -7 * np.abs(cur).max()

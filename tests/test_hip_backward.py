@@ -631,8 +631,8 @@ def test_direct_step_with_solar_correction_matches_autograd_path():
     assert trg._graph is not None and all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
 
 
-@pytest.mark.parametrize("tau,n_rays", [(4, 300), (16, 41)])
-def test_generated_dx_trunk_writes_the_same_bytes_as_the_compiler_scheduled_one(monkeypatch, tau, n_rays):
+@pytest.mark.parametrize("feat,tau,n_rays", [(256, 4, 300), (256, 16, 41), (512, 4, 70), (512, 16, 9)])
+def test_generated_dx_trunk_writes_the_same_bytes_as_the_compiler_scheduled_one(monkeypatch, feat, tau, n_rays):
     """csrc/gen/bwd_core.py's instruction stream (the seven trunk layers of the dX kernel, default) against the compiler-scheduled loop of
     csrc/mlp_bwd.inc (SATNERF_BWD_V1=1): the same arithmetic per value in the same order, so the dpre workspace -- MX8 bytes, scale bytes,
     the table of exponent maxima behind the last tile -- and d_t must be identical bit for bit.  tau 16 = two aux fragments (other phase units)."""
@@ -640,8 +640,8 @@ def test_generated_dx_trunk_writes_the_same_bytes_as_the_compiler_scheduled_one(
     from satnerf_amd.models import load_model
 
     torch.manual_seed(0)
-    s, feat, mode = 64, 256, "bf16"
-    args = O.default_args(mlp_mode=mode, t_embbeding_tau=tau)
+    s, mode = 64, "bf16"
+    args = O.default_args(mlp_mode=mode, t_embbeding_tau=tau, fc_units=feat)
     model = load_model(args).to(DEV)
     emb = torch.nn.Embedding(30, tau).to(DEV)
     rays, ts = O.synthetic_rays(n_rays, seed=9)
