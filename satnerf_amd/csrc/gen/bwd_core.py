@@ -60,7 +60,13 @@ class Geo:
     def __init__(self, feat):
         assert feat in (256, 512)
         self.feat = feat
-        self.KS, self.MT, self.NW, self.LAYERS = feat // 16, feat // 32, (8 if feat == 256 else 4), 7
+        self.KS, self.MT, self.NW = feat // 16, feat // 32, (8 if feat == 256 else 4)
+        # g1: the stream starts one stage earlier, at bG1 ([d feats | d sigma_pre] -> d a_7: MT tiles of KS + 1 k-steps, the last reading the
+        # d sigma_pre fragment XS).  Built, tested (tests/test_bwd_core.py runs either setting) and OFF: at width 256 the compiler cannot keep
+        # the hand-over (68 pinned registers at two waves per SIMD) out of scratch -- 103 spilled registers in the stages before it, the
+        # kernel 6 % SLOWER; at width 512 (no spills) 440 us against 426 with the trunk alone (r05, interleaved on one box)
+        self.g1 = False
+        self.LAYERS = 8 if self.g1 else 7
         self.R, self.GROUP, self.FILL = (96, 2, 6) if feat == 256 else (128, 1, 4)
         self.NEB = self.MT // 4                      # registers of a layer's exponent bytes
         if feat == 256:
@@ -95,6 +101,10 @@ class Geo:
         self.NA, self.NPH = 6, 4
         self.IN_REGS = (self.MAGIC, self.K43, self.VL0, self.VL1, self.VOFF, self.POFF, self.SOFF, self.VCELL)   # operands (wired by mlp_bwd.inc)
         self.XREGS = self.KS * 4                     # registers of a d pre vector
+        # g1: the d sigma_pre B fragment = an in/out operand in the LAST quad of Y, which bG1's own last tile's epilogue overwrites only
+        # after the layer's last MFMA has read it
+        self.XS = self.Y + self.XREGS - 4
+        self.L0 = 8 if self.g1 else 7                # `l` of the stream's first layer (8 = bG1)
 
 
 S_SEL = ("s84", "s85", "s86", "s87")     # v_perm selectors of phase byte k: the byte lands in bits 8..15 of 0x43000000 (codec8.h phase8_rev)
@@ -146,7 +156,7 @@ class Trunk:
 
     def phase_unit(self, tau):
         g = self.g
-        l, t = 7 - tau // g.MT, tau % g.MT       # layer bL_l multiplies by cos(phase a_{l-1}): unit A + MT (l - 1) + t
+        l, t = g.L0 - tau // g.MT, tau % g.MT    # layer l (8 = bG1, 7..1 = bL_l) multiplies by cos(phase a_{l-1}): unit A + MT (l - 1) + t
         return self.auxs + g.MT * (l - 1) + t
 
     def phase_load(self, tau):
@@ -166,9 +176,9 @@ class Trunk:
         layer's input vector, MX8 bytes -> the dpre workspace (codec8.h: bit for bit what bpack / mx8_exponent / mx8_encode compute)"""
         g = self.g
         MT, TT, K43, EB, E, M, INV, MAGIC, T1, SOFF = g.MT, g.TT, g.K43, g.EB, g.E, g.M, g.INV, g.MAGIC, g.T1, g.SOFF
-        l, t = 7 - tau // MT, tau % MT
+        l, t = g.L0 - tau // MT, tau % MT
         a, ph = g.ACC[tau & 1], g.PH0 + 4 * (tau % g.NPH)
-        out = (g.Y if (7 - l) % 2 == 0 else g.X) + 8 * t
+        out = (g.Y if (g.L0 - l) % 2 == 0 else g.X) + 8 * t
         sv = g.SV[tau & 1]
         it = []
 
@@ -289,8 +299,14 @@ class Trunk:
     def _build(self):
         g = self.g
         R, PF, G, KS, MT, NW = self.R, self.PF, self.GROUP, g.KS, g.MT, g.NW
-        NT = g.LAYERS * MT                    # tiles = chunks of KS pieces
-        N = NT * KS
+        NT = g.LAYERS * MT                    # tiles = chunks of KS pieces (bG1's: KS + 1)
+        ks_of = lambda ti: KS + 1 if (g.g1 and ti < MT) else KS   # noqa: E731
+        mf = [(ti, k) for ti in range(NT) for k in range(ks_of(ti))]
+        first_piece = {}
+        for i, (ti, k) in enumerate(mf):
+            first_piece.setdefault(ti, i)
+        N = len(mf)
+        assert N % NW == 0
         n_rows = N // NW
         self.e("savem0", (), "s_mov_b32 %[m0save], m0")
         for k in range(4):
@@ -312,7 +328,7 @@ class Trunk:
 
         def sync_for(first_tile):
             last = min(first_tile + G, NT) - 1
-            need = ((last + 1) * KS + NW - 1) // NW
+            need = (first_piece[last] + ks_of(last) + NW - 1) // NW
             while pending:
                 emit_row()
             assert rows_issued >= need
@@ -333,7 +349,7 @@ class Trunk:
 
         def read_for(i):
             nonlocal sync_done_for
-            ti, k = divmod(i, KS)
+            ti, k = mf[i]
             if ti > sync_done_for and ti % G == 0 and k == 0:
                 sync_for(ti)
                 sync_done_for = ti + G - 1
@@ -347,16 +363,16 @@ class Trunk:
             dsread(i)
         epi = []          # [earliest gap, closure, tile]
         for i in range(N):
-            ti, k = divmod(i, KS)
-            l = 7 - ti // MT
-            inp = g.X if (7 - l) % 2 == 0 else g.Y
+            ti, k = mf[i]
+            l = g.L0 - ti // MT
+            inp = g.X if (g.L0 - l) % 2 == 0 else g.Y
             acc = g.ACC[ti & 1]
             if k == 0:
                 # the tile before last's epilogue still reads this accumulator: it must be out (and every B fragment of a new layer
                 # is produced by the previous layer's epilogues: the last tile's runs during this tile, its two k-steps come last)
                 while epi and epi[0][2] <= ti - 2:
                     self.emit_item(epi.pop(0)[1])
-            if ti % MT == 0 and k >= KS - 2:
+            if ti % MT == 0 and ti > 0 and KS - 2 <= k < KS:
                 while epi and epi[0][2] < ti:
                     self.emit_item(epi.pop(0)[1])
                 if k == KS - 2:
@@ -364,14 +380,15 @@ class Trunk:
             self.e("waitl", (min(PF - 1, N - 1 - i),), f"s_waitcnt lgkmcnt({min(PF - 1, N - 1 - i)})")
             c = "0" if k == 0 else f"v[{acc}:{acc + 15}]"
             areg = g.AR0 + 4 * (i % g.NA)
-            self.e("mfma", (acc, areg, inp + 4 * k, k == 0), f"v_mfma_f32_32x32x16_bf16 v[{acc}:{acc + 15}], {rn(areg, 4)}, {rn(inp + 4 * k, 4)}, {c}")
-            if k == KS - 1:
+            breg = inp + 4 * k if k < KS else g.XS
+            self.e("mfma", (acc, areg, breg, k == 0), f"v_mfma_f32_32x32x16_bf16 v[{acc}:{acc + 15}], {rn(areg, 4)}, {rn(breg, 4)}, {c}")
+            if k == ks_of(ti) - 1:
                 for f in self.epilogue_items(ti):
                     epi.append([i + 2, f, ti])
             # ---- gap(i)
             if i + PF < N:
                 if read_for(i + PF):
-                    allow_rows(ti * KS)   # the barrier proves every wave has issued MFMA i: all tiles before the current one are consumed
+                    allow_rows(first_piece[ti])   # the barrier proves every wave has issued MFMA i: all tiles before the current one are consumed
                 dsread(i + PF)
             if k == 0 and ti + 2 < NT:
                 self.phase_load(ti + 2)
@@ -478,8 +495,9 @@ def clobber_file(feat=256):
     if feat == 256:
         regs = [r for r in range(64, g.N_VGPR) if r not in g.IN_REGS]
     sregs = list(S_SEL) + [S_B4A, S_B4B, S_MAX]
+    skip_a = set(range(g.XS - A0, g.XS - A0 + 4)) if g.g1 and g.XS >= A0 else set()
     return (f"// GENERATED by csrc/gen/bwd_core.py: clobber list of the dX trunk statement, width {feat} (the X vector is in/out, the constants and offsets are inputs)\n"
-            + ", ".join(f'"v{r}"' for r in regs) + ("".join(f', "a{r}"' for r in range(g.N_AGPR))) + ", " + ", ".join(f'"{s_}"' for s_ in sregs)
+            + ", ".join(f'"v{r}"' for r in regs) + ("".join(f', "a{r}"' for r in range(g.N_AGPR) if r not in skip_a)) + ", " + ", ".join(f'"{s_}"' for s_ in sregs)
             + ', "memory", "scc"\n')
 
 

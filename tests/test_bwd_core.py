@@ -304,11 +304,12 @@ def test_instruction_stream_computes_the_trunk(feat, tau):
     bits = _bf16_bits(vals).reshape(-1, 64, 8)
     # the trunk's part of the transposed stream: everything behind bG1 (mlp_layout.h BwdStream: bH | bS3 | bS2 | bG2 | bDT | bG1)
     hs, mth = KS // 2, MT // 2
-    first = 3 * mth + 2 * (mth * hs) + MT * 3 * hs + hs + MT * (KS + 1)
+    first = 3 * mth + 2 * (mth * hs) + MT * 3 * hs + hs + (0 if G.g1 else MT * (KS + 1))   # (Geo.g1: the stream starts at bG1)
     bits = bits[first:]
-    assert bits.shape[0] == 7 * MT * KS
+    n_mfma = 7 * MT * KS + (MT * (KS + 1) if G.g1 else 0)
+    assert bits.shape[0] == n_mfma
     stream_bits = (bits[:, :, 0::2] | (bits[:, :, 1::2] << 16)).astype(np.uint32)          # [piece, lane, 4]
-    acts = {u: rng.integers(0, 2 ** 32, (64, 4), dtype=np.uint64).astype(np.uint32) for u in range(auxs, auxs + 7 * MT)}   # PHASE8 units of a0..a6
+    acts = {u: rng.integers(0, 2 ** 32, (64, 4), dtype=np.uint64).astype(np.uint32) for u in range(auxs, auxs + 8 * MT)}   # PHASE8 units of a0..a7
     d7 = (rng.normal(size=(feat, 32)) * 1e-3).astype(np.float32)                          # d pre_7 [feature slot][point]
     x0 = []
     for k in range(KS):                                                                     # B fragment k: lane (p, h) holds slots 16 k + 8 h + j
@@ -318,21 +319,32 @@ def test_instruction_stream_computes_the_trunk(feat, tau):
         b = _bf16_bits(fr)
         x0.append(np.stack([b[:, 2 * q] | (b[:, 2 * q + 1] << 16) for q in range(4)]))
     m = Machine(gen, trunk, stream_bits, acts, x0)
-    assert m.run() == 7 * MT * KS and not m.vmq and not m.lgkm
+    xs_mat = (rng.normal(size=(16, 32)) * 1e-3).astype(np.float32)                         # bG1's 17th k-step: the d sigma_pre fragment
+    if G.g1:
+        fr = np.zeros((64, 8), np.float32)
+        for lane in range(64):
+            fr[lane] = xs_mat[8 * (lane >> 5): 8 * (lane >> 5) + 8, lane & 31]
+        b = _bf16_bits(fr)
+        m.v[G.XS:G.XS + 4] = np.stack([b[:, 2 * q] | (b[:, 2 * q + 1] << 16) for q in range(4)])
+    xs_q = _bf16_f32(_bf16_bits(xs_mat)).astype(np.float64)
+    assert m.run() == n_mfma and not m.vmq and not m.lgkm
 
     # ---- reference: the seven layers straight from the pieces, float64 contraction, float32 element-wise as the kernel ------------------
     cur = _bf16_f32(_bf16_bits(d7)).astype(np.float64)                                      # [slot, point]
     piece = 0
-    for l in range(7, 0, -1):
+    for l in range(G.L0, 0, -1):
         nxt = np.zeros((feat, 32), np.float32)
         ebytes = np.zeros((MT, 64), np.uint32)
+        grp = l - 1
+        sc = m.scale_stores[(G.D8_SCALE + grp // G.GROUPS_PER_UNIT, MT * (grp % G.GROUPS_PER_UNIT))]   # NEB dwords per lane: bytes = E of the layer's tiles
+        got_e = np.stack([(sc[:, t_ >> 2] >> (8 * (t_ & 3))) & 0xFF for t_ in range(MT)]).astype(np.int64)
         for t in range(MT):
             D = np.zeros((32, 32))
-            for k in range(KS):
+            for k in range(KS + (1 if l == 8 else 0)):
                 A = _bf16_f32(bits[piece]).astype(np.float64).reshape(2, 32, 8)            # [h, row, j] = W^T rows of this tile, k-slots 16 k + 8 h + j
                 piece += 1
                 for h in range(2):
-                    D += A[h] @ cur[16 * k + 8 * h: 16 * k + 8 * h + 8]
+                    D += A[h] @ (cur[16 * k + 8 * h: 16 * k + 8 * h + 8] if k < KS else xs_q[8 * h: 8 * h + 8])
             unit = auxs + MT * (l - 1) + t
             ph = acts[unit]                                                                  # [lane, 4 dwords]: value g = byte g & 3 of dword g >> 2
             u = np.stack([(ph[:, gg >> 2] >> (8 * (gg & 3))) & 0xFF for gg in range(16)], 1).astype(np.float64)   # [lane, g]
@@ -347,20 +359,23 @@ def test_instruction_stream_computes_the_trunk(feat, tau):
             mx = np.abs(v).max(1).astype(np.float64)
             e = np.clip((_u32((mx * 0.0078125 + mx).astype(np.float32)) >> 23).astype(np.int64), 6, 254)
             ebytes[t] = e
-            want = np.rint(v.astype(np.float64) * (2.0 ** (133 - e))[:, None]).astype(np.int64) + 128
             got_q = m.stores[MT * (l - 1) + t]                                               # [lane, 4 dwords]
             got = np.stack([(got_q[:, gg >> 2] >> (8 * (gg & 3))) & 0xFF for gg in range(16)], 1).astype(np.int64)
-            assert np.abs(got - want).max() <= 1, (l, t, np.abs(got - want).max())          # (+-1: fp32 accumulation order of the contraction)
-        grp = l - 1
-        sc = m.scale_stores[(G.D8_SCALE + grp // G.GROUPS_PER_UNIT, MT * (grp % G.GROUPS_PER_UNIT))]   # NEB dwords per lane: bytes = E of the layer's tiles
-        got_e = np.stack([(sc[:, t >> 2] >> (8 * (t & 3))) & 0xFF for t in range(MT)])
-        assert np.abs(got_e.astype(np.int64) - ebytes.astype(np.int64)).max() <= 1
+            # dequantised with the exponent the stream itself stored (a lane whose largest magnitude sits on a binade boundary may take
+            # the neighbouring exponent: fp32 accumulation order of the contraction; a bf16 rounding that falls the other way in an
+            # earlier layer moves a later value by a fraction of a code): within 2.5 codes of the coarser scale -- any addressing,
+            # operand-order or register mix-up is off by the full range
+            deq = (got - 128).astype(np.float64) * (2.0 ** (got_e[t] - 133))[:, None]
+            tol = (2.0 ** (np.maximum(got_e[t], e) - 133))[:, None]
+            assert (np.abs(deq - v.astype(np.float64)) <= 2.5 * tol).all(), (l, t)
+        assert np.abs(got_e - ebytes.astype(np.int64)).max() <= 1
         assert m.cells[grp] == int(got_e.max()), (l, m.cells[grp], int(got_e.max()))      # the wave maximum of exactly the bytes it stored
         cur = _bf16_f32(_bf16_bits(nxt)).astype(np.float64)
-    # the last layer's output vector (d pre_0, bf16 B fragments) sits in Y
+    # the last layer's output vector (d pre_0, bf16 B fragments) sits in Y (in X when the stream has an even number of layers)
     out = np.zeros((feat, 32), np.float32)
+    last = G.Y if G.LAYERS % 2 else G.X
     for k in range(KS):
-        fr = _frag_f32(m.v[G.Y + 4 * k:G.Y + 4 * k + 4])
+        fr = _frag_f32(m.v[last + 4 * k:last + 4 * k + 4])
         for lane in range(64):
             out[16 * k + 8 * (lane >> 5): 16 * k + 8 * (lane >> 5) + 8, lane & 31] = fr[lane]
     assert np.abs(out - cur).max() <= 2.0 ** -7 * np.abs(cur).max()
