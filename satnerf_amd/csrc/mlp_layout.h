@@ -181,11 +181,12 @@ struct BwdStream {
 
 // ---- weight-gradient partial blocks (wgrad.hip) -------------------------------------------------------------------
 // One split-K slice of one job block: 256 x 256 main block + 256 x 32 aux columns, fp32.  Job table row (kWgTableInts int32):
-//   rf0 nr0 rf1 nr1 | cf0 nc0 cf1 nc1 | col_kind n_slices first_slice -
+//   rf0 nr0 rf1 nr1 | cf0 nc0 cf1 nc1 | col_kind n_slices first_slice span
 // = up to two ranges of dpre row fragments (nr0 + nr1 <= 16), up to two ranges of activation column fragments (nc0 + nc1 <= 16);
 // slices of all blocks are numbered consecutively (sr_wgrad_plan) and slice s lives at partial + s * kWgBlockFloats.
 constexpr int kWgBlockFloats = 256 * 256 + 256 * 32;
 constexpr int kWgTableInts = 12, kWgSlices = 9, kWgFirstSlice = 10;
+constexpr int kWgSpan = 11;  // (first row only) stream-K plans: tile units per workgroup of the 4-wave kernel; 0 = one slice per workgroup
 
 #ifdef __HIPCC__
 // sum over the slices of element k = block * kWgBlockFloats + offset

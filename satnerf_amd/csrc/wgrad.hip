@@ -269,6 +269,7 @@ extern "C" int sr_wgrad_plan(int32_t* blocks, int n_blocks, int64_t n_points, in
   int first = 0;
   static thread_local int sl[4096];
   const bool weighted = fmt == SR_FMT8 && n_blocks <= n_wg;
+  blocks[kWgSpan] = 0;
   if (weighted && !old_kernel) {
     // equal split, the remainder to the first blocks: what wgrad9.hip's workgroup numbering (slice-major, blocks 8 positions apart on one
     // XCD) assumes; a block never gets more slices than it has tiles
@@ -276,6 +277,18 @@ extern "C" int sr_wgrad_plan(int32_t* blocks, int n_blocks, int64_t n_points, in
     for (int b = 0; b < n_blocks; ++b) {
       long v = q + (b < r ? 1 : 0);
       sl[b] = (int)(v > n_tiles ? n_tiles : v);
+    }
+    // ... unless that leaves the workgroups unevenly loaded (width 512: 47 blocks over 256 workgroups = 5 or 6 slices, 410 against 342
+    // tiles): then stream-K -- the job list as one line of n_blocks x n_tiles tile units, `span` consecutive units per workgroup, a
+    // workgroup that crosses a block boundary writes two partial blocks (wgrad9.hip).  Block b's slices = the workgroups whose span
+    // touches it, numbered in tile order.  SATNERF_WGRAD_STREAMK = 0 / 1 forces the choice (A/B).
+    const long total = (long)n_blocks * n_tiles, span = (total + n_wg - 1) / n_wg;
+    const long worst = q > 0 ? (n_tiles + q - 1) / q : n_tiles;
+    bool streamk = q > 0 && span >= 8 && worst * 100 > span * 103;
+    if (const char* e = getenv("SATNERF_WGRAD_STREAMK")) streamk = e[0] == '1' && span >= 1;
+    if (streamk) {
+      for (int b = 0; b < n_blocks; ++b) sl[b] = (int)((((long)(b + 1) * n_tiles - 1) / span) - (((long)b * n_tiles) / span) + 1);
+      blocks[kWgSpan] = (int32_t)span;
     }
   } else if (weighted) {
     double cost[4096];

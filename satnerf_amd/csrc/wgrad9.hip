@@ -97,8 +97,28 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
     if (last > prm.n_tiles - 1) last = prm.n_tiles - 1;
     return first <= last;
   };
+  // stream-K plans (sr_wgrad_plan writes the span into int 11 of the table's first row; 0 = one slice per workgroup): the job list is ONE
+  // line of n_blocks x n_tiles tile units and workgroup i takes units [i span, (i + 1) span) -- a workgroup whose span crosses a block
+  // boundary finishes its slice of block b, writes the partial block, and starts over on block b + 1 (`seg`).  At width 512 the 47 blocks
+  // do not divide the 256 workgroups (5 or 6 slices each: 342 / 410 tiles, a sixth of the chip idle at the end); this gives every
+  // workgroup 376.
+  const long span = __builtin_amdgcn_readfirstlane(prm.blocks[kWgSpan]);
+  const long u_all = (long)prm.n_blocks * prm.n_tiles;
+  long u0 = (long)blockIdx.x * span;
+  const long u_end = u0 + span < u_all ? u0 + span : u_all;
+  if (span > 0 && u0 >= u_all) return;  // (the launch has one workgroup per partial slice: a few more than spans)
+  for (int seg = 0;; ++seg) {
+  if (seg > 0) __syncthreads();  // every wave has left the previous segment's slice loop: the LDS slots and counters are free again
   int slice;  // this workgroup's slice of the block: partial block d[kWgFirstSlice] + slice
-  {
+  long sk_begin = 0, sk_end = 0;  // (stream-K) this segment's tiles of block blk
+  if (span > 0) {
+    blk = (int)(u0 / prm.n_tiles);
+    sk_begin = u0 - (long)blk * prm.n_tiles;
+    sk_end = sk_begin + (u_end - u0) < prm.n_tiles ? sk_begin + (u_end - u0) : prm.n_tiles;
+    slice = (int)((long)blockIdx.x - ((long)blk * prm.n_tiles) / span);  // the block's first workgroup writes its slice 0
+    fetch_tables(blk);
+    fetch_emax(sk_begin, sk_end - 1);
+  } else {
     // workgroup i = slice i / n_blocks of block i % n_blocks (the r blocks with one slice more take the last r workgroups): workgroup i
     // runs on XCD i % 8, so blocks 8 table positions apart -- packing.backward_maps puts blocks that share an operand there -- stream the
     // same tiles through the same L2 at the same time.  Valid for sr_wgrad_plan's equal split (q or q + 1 slices, the larger first)
@@ -140,8 +160,8 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   const int nr = d[1] + d[3], nc = d[5] + d[7];
   const bool col_mx = d[8] == 0;  // packing.KIND_BF16: the identity stage (feats) -> MX8 columns
   const long tiles_per_split = (prm.n_tiles + d[kWgSlices] - 1) / d[kWgSlices];
-  const long t_begin = (long)slice * tiles_per_split;
-  long t_end = t_begin + tiles_per_split;
+  const long t_begin = span > 0 ? sk_begin : (long)slice * tiles_per_split;
+  long t_end = span > 0 ? sk_end : t_begin + tiles_per_split;
   if (t_end > prm.n_tiles) t_end = prm.n_tiles;
   // (every value the slice loop takes as a scalar operand is forced into an SGPR: the table reads above are scalar loads only as long as
   // the compiler can prove them uniform, and an "s" operand held in a VGPR is passed in that VGPR without a diagnostic)
@@ -346,6 +366,10 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   __builtin_amdgcn_s_waitcnt(0);
   if (prm.dbg && tid == 0) prm.dbg[3 * 1024 + 4 * blockIdx.x + 3] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
+  if (span <= 0) break;
+  u0 += t_end - t_begin;
+  if (u0 >= u_end) break;
+  }  // next segment of a stream-K span
 }
 
 // the 4-wave kernel reads both workspaces through 32-bit per-lane offsets

@@ -59,3 +59,31 @@ def test_new_kernel_matches_the_r02_kernel_over_batch_shapes(tmp_path):
             if float(cb.abs().max()) > 0:
                 assert float((ca - cb).abs().max() / cb.abs().max()) < 2e-2, case
         print(case, f"{err:.1e}")
+
+
+CHILD512 = CHILD.replace('args = O.default_args(mlp_mode="bf16", n_samples=s, t_embbeding_tau=tau)', 'args = O.default_args(mlp_mode="bf16", n_samples=s, t_embbeding_tau=tau, fc_units=int(sys.argv[4]))')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("feat", [256, 512])
+def test_stream_k_plan_matches_the_equal_split(tmp_path, feat):
+    """sr_wgrad_plan's stream-K plan (the job list as one line of tile units, a workgroup whose span crosses a block boundary writes two
+    partial blocks: the default at width 512, where 47 blocks do not divide 256 workgroups) against the equal split
+    (SATNERF_WGRAD_STREAMK=0): the same kernels on the same batch, the split-K sums cut at other tiles -- equal to fp32 summation order.
+    Batch sizes: one workgroup span inside a block, spans crossing boundaries, more slices than tiles."""
+    cases = [(1024, 64, 4), (333, 64, 16), (40, 64, 4), (3, 64, 4)]
+    paths = {}
+    for name, env in (("sk", {"SATNERF_WGRAD_STREAMK": "1"}), ("eq", {"SATNERF_WGRAD_STREAMK": "0"})):
+        paths[name] = str(tmp_path / f"{name}.pt")
+        r = subprocess.run([sys.executable, "-c", CHILD512, ROOT, paths[name], repr(cases), str(feat)], env=dict(os.environ, **env), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    a, b = torch.load(paths["sk"]), torch.load(paths["eq"])
+    for case in cases:
+        ga, gb = a[case], b[case]
+        assert torch.isfinite(ga).all() and float(gb.abs().max()) > 0, case
+        err = float((ga - gb).abs().max() / gb.abs().max())
+        assert err < 2e-4, (case, feat, err)   # (the range fit is per slice: other slices, other flush thresholds, other summation order)
+        for ca, cb in zip(ga.chunk(64), gb.chunk(64)):
+            if float(cb.abs().max()) > 0:
+                assert float((ca - cb).abs().max() / cb.abs().max()) < 5e-3, (case, feat)
