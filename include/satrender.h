@@ -225,9 +225,11 @@ int sr_satnerf_wgrad(int feat, int tau, int64_t n_points, const uint16_t* dpre, 
  * it goes -- ints 0..19 for the r02 kernel, 20..108 the duty table, the exponent groups of the row pairs and the quadrant mask of the default one
  * (which reads the exponent maxima behind the dpre workspace: dpre must be the buffer sr_satnerf_mlp_bwd wrote, sr_dpre_workspace_elems long); `blocks` is
  * the same planned table.  sr_wgrad_plan hands the default kernel equal slices (it runs one instruction stream for every block) and the
- * r02 kernel cost-weighted ones. */
+ * r02 kernel cost-weighted ones.
+ * plan_span = int 11 of the planned table's first row (sr_wgrad_plan): 0 = one slice per workgroup; > 0 = a stream-K plan (the 4-wave kernel
+ * walks `plan_span` tile units of the block-major job list per workgroup, writing one partial block per block it touches). */
 int sr_satnerf_wgrad8(int feat, int tau, int64_t n_points, const uint16_t* dpre, const uint16_t* acts, const int32_t* blocks,
-                      const int32_t* loads, int n_blocks, int n_slices, float* partial, void* stream);
+                      const int32_t* loads, int n_blocks, int n_slices, int plan_span, float* partial, void* stream);
 int sr_wgrad8_load_ints(void);
 
 /* parameter gradients of the sky head (atomicAdd into g_*; zero them first) and of the embedding table

@@ -268,16 +268,17 @@ namespace sr {
 int launch_wgrad8f(const uint4* dpre, const uint4* acts, const int* blocks, const int* loads, float* partial, long n_tiles, int n_blocks,
                    int ak, int auxs, int dk, int n_slices, hipStream_t st);  // wgrad8f.hip
 int launch_wgrad9(const uint4* dpre, const uint4* acts, const uint4* emax, const int* blocks, const int* loads, float* partial, long n_tiles,
-                  int n_blocks, int ak, int dk, int load_ints, int n_slices, hipStream_t st);  // wgrad9.hip
+                  int n_blocks, int ak, int dk, int load_ints, int n_slices, int span, hipStream_t st);  // wgrad9.hip
 bool wgrad9_fits(long n_tiles, int ak, int dk);
 }
 using namespace sr;
 
 extern "C" int sr_satnerf_wgrad8(int feat, int tau, int64_t n_points, const uint16_t* dpre, const uint16_t* acts, const int32_t* blocks,
-                                 const int32_t* loads, int n_blocks, int n_slices, float* partial, void* stream) {
+                                 const int32_t* loads, int n_blocks, int n_slices, int plan_span, float* partial, void* stream) {
   SR_REQUIRE(feat == 256 || feat == 512, "sr_satnerf_wgrad8: feat=%d unsupported (256, 512)", feat);
   SR_REQUIRE(dpre && acts && blocks && loads && partial, "sr_satnerf_wgrad8: null pointer argument");
-  SR_REQUIRE(n_blocks >= 1 && n_slices >= n_blocks, "sr_satnerf_wgrad8: bad plan (%d blocks, %d slices): run sr_wgrad_plan first", n_blocks, n_slices);
+  SR_REQUIRE(n_blocks >= 1 && n_slices >= n_blocks && plan_span >= 0, "sr_satnerf_wgrad8: bad plan (%d blocks, %d slices, span %d): run sr_wgrad_plan first",
+             n_blocks, n_slices, plan_span);
   Wgrad8Params p;
   p.dpre = (const uint4*)dpre, p.acts = (const uint4*)acts, p.blocks = blocks, p.loads = loads, p.partial = partial;
   p.n_tiles = (n_points + 31) / 32;
@@ -292,7 +293,8 @@ extern "C" int sr_satnerf_wgrad8(int feat, int tau, int64_t n_points, const uint
   static const bool v2 = [] { const char* e = getenv("SATNERF_WGRAD_V2"); return e && e[0] == '1'; }();
   if (!v1 && !v2 && wgrad9_fits(p.n_tiles, p.ak, p.dk))
     return launch_wgrad9(p.dpre, p.acts, p.dpre + sr::ws_tiles(n_points) * p.dk * 64 /* the exponent maxima behind the last tile */, blocks, loads,
-                         partial, p.n_tiles, n_blocks, p.ak, p.dk, kWg8LoadInts, n_slices, (hipStream_t)stream);
+                         partial, p.n_tiles, n_blocks, p.ak, p.dk, kWg8LoadInts, n_slices, plan_span, (hipStream_t)stream);
+  SR_REQUIRE(plan_span == 0, "sr_satnerf_wgrad8: a stream-K plan (span %d) needs the 4-wave kernel: plan with SATNERF_WGRAD_STREAMK=0 for the r02 / r03 kernels", plan_span);
   if (feat == 256 && v2)
     return launch_wgrad8f(p.dpre, p.acts, blocks, loads, partial, p.n_tiles, n_blocks, p.ak, p.auxs, p.dk, n_slices, (hipStream_t)stream);
   const size_t lds = (size_t)kSlots8 * kSlot8Bytes;

@@ -46,10 +46,15 @@ struct Wgrad9Params {
   int n_blocks;
   int ak, dk;  // 1-KiB units per tile of the activation / dpre workspace
   int load_ints;
+  int span;            // stream-K plans: tile units per workgroup (= int kWgSpan of the table's first row); 0 = one slice per workgroup
   long long* dbg;  // SR_W9_TIMING builds: per workgroup (shader cycles, 100-MHz ticks, tiles) of wave 0's slice loop
 };
 }  // namespace
 
+// SK: the stream-K build -- the body below runs once per segment of the workgroup's span.  The one-slice build (SK = false) is the same
+// source with the loop known to run once: kept separate because the loop-carried state around the slice-loop statement (which clobbers
+// nearly every register) cost the one-slice kernel 6 us in its partial-block write (spills), r05.
+template <bool SK>
 __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
 #ifdef SR_W9_TIMING
@@ -102,7 +107,7 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   // boundary finishes its slice of block b, writes the partial block, and starts over on block b + 1 (`seg`).  At width 512 the 47 blocks
   // do not divide the 256 workgroups (5 or 6 slices each: 342 / 410 tiles, a sixth of the chip idle at the end); this gives every
   // workgroup 376.
-  const long span = __builtin_amdgcn_readfirstlane(prm.blocks[kWgSpan]);
+  const long span = SK ? (long)prm.span : 0l;
   const long u_all = (long)prm.n_blocks * prm.n_tiles;
   long u0 = (long)blockIdx.x * span;
   const long u_end = u0 + span < u_all ? u0 + span : u_all;
@@ -366,7 +371,7 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   __builtin_amdgcn_s_waitcnt(0);
   if (prm.dbg && tid == 0) prm.dbg[3 * 1024 + 4 * blockIdx.x + 3] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-  if (span <= 0) break;
+  if constexpr (!SK) break;
   u0 += t_end - t_begin;
   if (u0 >= u_end) break;
   }  // next segment of a stream-K span
@@ -379,17 +384,22 @@ bool wgrad9_fits(long n_tiles, int ak, int dk) {
 }
 
 int launch_wgrad9(const uint4* dpre, const uint4* acts, const uint4* emax, const int* blocks, const int* loads, float* partial, long n_tiles,
-                  int n_blocks, int ak, int dk, int load_ints, int n_slices, hipStream_t st) {
+                  int n_blocks, int ak, int dk, int load_ints, int n_slices, int span, hipStream_t st) {
   Wgrad9Params p;
   p.dpre = (const char*)dpre, p.acts = (const char*)acts, p.emax = emax, p.blocks = blocks, p.loads = loads, p.partial = partial;
-  p.n_tiles = n_tiles, p.n_blocks = n_blocks, p.ak = ak, p.dk = dk, p.load_ints = load_ints;
+  p.n_tiles = n_tiles, p.n_blocks = n_blocks, p.ak = ak, p.dk = dk, p.load_ints = load_ints, p.span = span;
   p.dbg = nullptr;
 #ifdef SR_W9_TIMING  // timing builds only (tools/ab_wgrad8.py passes the address of its stamp buffer): a product build never takes a pointer from the environment
   if (const char* dbg = getenv("SR_W9_DBG")) p.dbg = (long long*)strtoull(dbg, nullptr, 10);
 #endif
   const size_t lds = (size_t)kSlots9 * kSlot9 + 16;  // four operand slots + their publish counters
-  if (!ensure_dynamic_lds((const void*)wgrad9_kernel, lds)) return 1;
-  hipLaunchKernelGGL(wgrad9_kernel, dim3(n_slices), dim3(256), lds, st, p);
+  if (span > 0) {
+    if (!ensure_dynamic_lds((const void*)wgrad9_kernel<true>, lds)) return 1;
+    hipLaunchKernelGGL(wgrad9_kernel<true>, dim3(n_slices), dim3(256), lds, st, p);
+    return check_launch("wgrad9_kernel");
+  }
+  if (!ensure_dynamic_lds((const void*)wgrad9_kernel<false>, lds)) return 1;
+  hipLaunchKernelGGL(wgrad9_kernel<false>, dim3(n_slices), dim3(256), lds, st, p);
   return check_launch("wgrad9_kernel");
 }
 

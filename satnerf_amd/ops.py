@@ -459,7 +459,7 @@ _plan_cache = {}
 
 def wgrad_plan(blocks, n_points, n_wg=0, fmt=16):
     """Split-K plan of the weight-gradient job table for ``n_points`` points (sr_wgrad_plan; ``fmt`` = workspace format of the kernel
-    that will run it): returns (planned device table, total slices).  Cached per (table, n_points, fmt): the copy to the device
+    that will run it): returns (planned device table, total slices, span of a stream-K plan or 0).  Cached per (table, n_points, fmt): the copy to the device
     must not happen inside a graph capture."""
     key = (blocks.data_ptr(), int(n_points), int(n_wg), str(blocks.device), int(fmt))
     ent = _plan_cache.get(key)
@@ -472,14 +472,15 @@ def wgrad_plan(blocks, n_points, n_wg=0, fmt=16):
             _lib.call("sr_wgrad_plan", host.data_ptr(), host.shape[0], n_points, n_wg, int(fmt), ctypes.addressof(n_slices))
         if len(_plan_cache) > 64:
             _plan_cache.clear()
-        ent = _plan_cache[key] = (host.to(blocks.device), int(n_slices.value), blocks)  # keeps `blocks` alive: data_ptr stays unique
-    return ent[0], ent[1]
+        # (int 11 of the first row: the span of a stream-K plan, 0 otherwise -- the launch has to know which build of the kernel to run)
+        ent = _plan_cache[key] = (host.to(blocks.device), int(n_slices.value), blocks, int(host[0, 11]))  # keeps `blocks` alive: data_ptr stays unique
+    return ent[0], ent[1], ent[3]
 
 
 def wgrad_partials(feat, tau, n_points, dpre, acts, blocks, fmt=16, loads=None):
     """Weight-gradient GEMMs only: returns (fp32 split-K slices, planned job table); reduce with grad_tail / unpack_grads.
     ``fmt`` = format of both workspaces; the 8-bit kernel also needs the per-block load table ``loads`` (packing.wgrad8_loads)."""
-    plan, n_slices = wgrad_plan(blocks, n_points, fmt=fmt)
+    plan, n_slices, span = wgrad_plan(blocks, n_points, fmt=fmt)
     block_floats = 256 * 256 + 256 * 32  # csrc/mlp_layout.h kWgBlockFloats
     partial = _ws_empty(n_slices * block_floats, torch.float32, dpre.device, 3)
     ev = kernel_timer.span("wgrad") if kernel_timer is not None else None
@@ -487,7 +488,7 @@ def wgrad_partials(feat, tau, n_points, dpre, acts, blocks, fmt=16, loads=None):
         ev[0].record()
     if int(fmt) == 8:
         _lib.call("sr_satnerf_wgrad8", feat, tau, n_points, _p(dpre), _p(acts), _p(plan), _p(_chk(loads, "loads", torch.int32)), plan.shape[0], n_slices,
-                  _p(partial), _stream())
+                  span, _p(partial), _stream())
     else:
         _lib.call("sr_satnerf_wgrad", feat, tau, n_points, _p(dpre), _p(acts), _p(plan), plan.shape[0], n_slices, _p(partial), _stream())
     if ev:

@@ -82,7 +82,14 @@ def test_wgrad_plan_host_only(handle):
         tiles = (n_points + 31) // 32
         assert (ns >= 1).all() and (ns <= tiles).all()
         assert (first == np.concatenate([[0], np.cumsum(ns)[:-1]])).all() and n.value == ns.sum()
-        assert n.value <= max(n_wg, blocks.shape[0])
+        span = int(blocks[0, 11])
+        if span > 0:   # stream-K (fmt 8, uneven equal split): spans of `span` tile units over <= n_wg workgroups; slices = the (block,
+            assert fmt == 8 and -(-blocks.shape[0] * tiles // span) <= n_wg   # workgroup) pairs that meet
+            assert n.value <= n_wg + blocks.shape[0] - 1
+            w_first, w_last = (np.arange(blocks.shape[0]) * tiles) // span, ((np.arange(blocks.shape[0]) + 1) * tiles - 1) // span
+            assert (ns == w_last - w_first + 1).all()
+        else:
+            assert n.value <= max(n_wg, blocks.shape[0])
         if tiles >= 1024 and n_wg >= 2 * blocks.shape[0]:
             assert n.value > n_wg - blocks.shape[0]  # the launch fills the chip
         assert (blocks[:, :9] == blocks0[:, :9]).all()

@@ -15,7 +15,7 @@ acts = torch.randint(0, 30000, (tiles * act_e,), dtype=torch.int16, device=dev)
 dpre = torch.randint(0, 30000, (tiles * dp_e,), dtype=torch.int16, device=dev)
 n_wgs = [int(a) for a in sys.argv[2:]] or [0]
 def make(n_wg):
-    plan, n_slices = ops.wgrad_plan(blocks, n_points, n_wg)
+    plan, n_slices, span = ops.wgrad_plan(blocks, n_points, n_wg)
     if os.environ.get("AB_SPLITS"):  # override: equal slices per block
         k = int(os.environ["AB_SPLITS"]); plan = plan.clone(); plan[:, 9] = k; plan[:, 10] = torch.arange(plan.shape[0], device=plan.device, dtype=plan.dtype) * k; n_slices = k * plan.shape[0]
     partial = torch.empty(n_slices * (256 * 256 + 256 * 32), dtype=torch.float32, device=dev)

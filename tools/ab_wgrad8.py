@@ -24,13 +24,13 @@ if os.environ.get("AB_TIMING9"):  # wgrad9.hip built with -DSR_W9_TIMING: per wo
     dbg9 = torch.zeros(8 * 1024, dtype=torch.int64, device=dev)
     os.environ["SR_W9_DBG"] = str(dbg9.data_ptr())
 def make(n_wg):
-    plan, n_slices = ops.wgrad_plan(blocks, n_points, n_wg)
+    plan, n_slices, span = ops.wgrad_plan(blocks, n_points, n_wg)
     if os.environ.get("AB_SPLITS"):  # override: equal slices per block
         k = int(os.environ["AB_SPLITS"]); plan = plan.clone(); plan[:, 9] = k; plan[:, 10] = torch.arange(plan.shape[0], device=plan.device, dtype=plan.dtype) * k; n_slices = k * plan.shape[0]
     partial = torch.empty(n_slices * (256 * 256 + 256 * 32), dtype=torch.float32, device=dev)
     ld = loads[sel].contiguous() if os.environ.get("AB_BLOCKS") else loads
     return n_slices, lambda: _lib.call("sr_satnerf_wgrad8", 256, 4, n_points, dpre.data_ptr(), acts.data_ptr(), plan.data_ptr(), ld.data_ptr(), plan.shape[0],
-                                       n_slices, partial.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                                       n_slices, span, partial.data_ptr(), torch.cuda.current_stream().cuda_stream)
 for n_wg in n_wgs:
     n_slices, run = make(n_wg)
     for _ in range(5): run()
