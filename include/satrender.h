@@ -179,9 +179,17 @@ int sr_render_points_per_block(int feat, int mode);
  * SR_MODE_BF16 / SR_MODE_F16, widths 256 and 512.  `out`: albedo / sigma / sun_v / beta (N,S[,3]) and sky (N,3) are required (the dX
  * pass and the sky head's backward read them), z_vals optional, weights / transparency / depth / rgb unused.  `train` outputs: loss_parts
  * (one per workgroup = ceil(N * S / sr_render_points_per_block) floats: the loss is their sum), rgb (N,3) or NULL, d_sigma (N,S),
- * d_albedo (N,S,3), d_sun_v (N,S), g_beta (N,S), d_sky (N,3).  acts: the SR_FMT8 workspace of sr_satnerf_mlp_fwd. */
+ * d_albedo (N,S,3), d_sun_v (N,S), g_beta (N,S), d_sky (N,3).  acts: the SR_FMT8 workspace of sr_satnerf_mlp_fwd.
+ * r05, the batch sampler inside the launch (replaces the DataLoader of main.py:96-110 as sr_gather_batch does, without its launch):
+ * gather_idx != NULL: `in->rays` (stride 11), `in->ts` and `target` are the RESIDENT RAY BANK, gather_idx holds the shuffled row indices
+ * of a whole epoch = `batches` x N entries, and the launch trains on batch cursor[0] of it -- ray r of the launch is bank row
+ * gather_idx[cursor[0] * N + r] -- then moves the cursor on modulo `batches` (cursor = a 4-float block as sr_gather_batch's).  The wave
+ * that composites a ray also copies its row to out_rays (N,11) / out_rgbs (N,3) / out_ts (N): the batch as the later launches of the
+ * step (sky-head and embedding gradients, solar-correction pass) read it.
+ * in->tick == 2 ("tick first", training launches only): the launch advances the step counter as tick == 1 does AND draws its jitter for
+ * the advanced value -- it is the first launch of a step that has no sr_pack_all in front of it to tick. */
 typedef struct sr_train_args {
-  const float* target;   /* (N,3) */
+  const float* target;   /* (N,3), or the bank's colours (rows, 3) with gather_idx */
   const float* sched;    /* 4-float schedule block or NULL */
   float beta_min;
   float* loss_parts;
@@ -191,6 +199,12 @@ typedef struct sr_train_args {
   float* d_sun_v;
   float* g_beta;
   float* d_sky;
+  const int64_t* gather_idx;
+  float* cursor;
+  int64_t batches;
+  float* out_rays;
+  float* out_rgbs;
+  int64_t* out_ts;
 } sr_train_args;
 int sr_satnerf_render_train(const sr_render_args* in, int feat, int tau, int mode, const uint16_t* stream_hi, const uint16_t* stream_lo,
                             const float* l0, const sr_render_outputs* out, const sr_train_args* train, uint16_t* acts, int act_fmt, void* stream);
@@ -283,13 +297,26 @@ int sr_grad_tail(const float* partial, const int32_t* gidx, const float* gscale,
  * torch.optim.Adam to it (params / exp_avg / exp_avg_sq are aligned with grad: element i of all four is parameter i) and zeroes its
  * gradient slot; `late_idx` (n_late flat indices relative to grad) lists the parameters whose gradients arrive by atomics -- the sky head
  * and the embedding rows: the last atomics block to finish updates them.  `state` = the 4-float schedule block ([0] 1-based step, [1]
- * rate used when lr < 0, [3] arrival counter, zero between launches). */
+ * rate used when lr < 0, [3] arrival counter, zero between launches).
+ * `pack` (NULL or pack->map == NULL: none), r05: the launch ALSO keeps the weight streams current -- the thread that updated parameter i
+ * writes it to its (at most two) places in the packed streams, so the next step needs no sr_pack_all launch.  map = 2 int32 per
+ * parameter (packing.pack_scatter_map): position | scale index << 26 | (1 << 28: the fp32 fc_net.0 table `l0`), -1 = none; positions
+ * address `hi` (bf16; fp16 below n_f16 as sr_pack_all's n_f16) and, if not NULL, `lo` (the bf16x3 remainder plane); the value written
+ * is param * scales[index], the element-wise arithmetic of sr_pack_all: the streams hold the same bits as a fresh sr_pack_all. */
+typedef struct sr_pack_scatter {
+  const int32_t* map;
+  uint16_t* hi;
+  uint16_t* lo;
+  float* l0;
+  int64_t n_f16;
+  float scales[4];
+} sr_pack_scatter;
 int sr_grad_tail_adam(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, const int32_t* blocks, float* grad,
                       int accumulate, const float* sun, int sun_stride, int64_t n_rays, int hidden, const float* w1, const float* b1,
                       const float* w2, const float* sky, const float* d_sky, float* g_w1, float* g_b1, float* g_w2, float* g_b2,
                       const float* d_t, const int64_t* ts, int n_samples, int tau, float* g_emb, float* params, float* exp_avg,
                       float* exp_avg_sq, const int32_t* late_idx, int n_late, float* state, float lr, float beta1, float beta2, float eps,
-                      float grad_scale, void* stream);
+                      float grad_scale, const sr_pack_scatter* pack, void* stream);
 int sr_adam_step_graph(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                        float beta2, float eps, float grad_scale, float* state, int zero_grad, void* stream);
 

@@ -36,7 +36,12 @@ class RenderOutputs(C.Structure):
 
 class TrainArgs(C.Structure):
     _fields_ = [("target", _vp), ("sched", _vp), ("beta_min", _f), ("loss_parts", _vp), ("rgb", _vp), ("d_sigma", _vp), ("d_albedo", _vp),
-                ("d_sun_v", _vp), ("g_beta", _vp), ("d_sky", _vp)]
+                ("d_sun_v", _vp), ("g_beta", _vp), ("d_sky", _vp), ("gather_idx", _vp), ("cursor", _vp), ("batches", _i64), ("out_rays", _vp),
+                ("out_rgbs", _vp), ("out_ts", _vp)]
+
+
+class PackScatter(C.Structure):
+    _fields_ = [("map", _vp), ("hi", _vp), ("lo", _vp), ("l0", _vp), ("n_f16", _i64), ("scales", _f * 4)]
 
 
 class LinearSrc(C.Structure):
@@ -87,7 +92,7 @@ SIGNATURES = {
     "sr_grad_tail": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
                           _vp, _vp]),
     "sr_grad_tail_adam": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
-                               _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _f, _f, _vp]),
+                               _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _f, _f, _vp, _vp]),
     "sr_adam_step_graph": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp, _i, _vp]),
     "sr_pack_all": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     "sr_gather_scale_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),

@@ -218,7 +218,8 @@ class Stream:
         for q in range(4):
             V(f"v_lshlrev_b32 v{T0}, 16, v{r + q}")
             V(f"v_and_b32 v{T0 + 1}, 0xffff0000, v{r + q}")
-            V(f"v_pk_mul_f32 v[{T0}:{T0 + 1}], v[{T0}:{T0 + 1}], v[{SX}:{SX + 1}]")
+            V(f"v_mul_f32 v{T0}, v{T0}, v{SX}")       # (two plain multiplies: a v_pk_mul_f32 holds the matrix pipe for 7-10 cycles,
+            V(f"v_mul_f32 v{T0 + 1}, v{T0 + 1}, v{SX}")   #  tools/probe_power.hip)
             V(f"v_cvt_pk_f16_f32 v{OUT + q}, v{T0}, v{T0 + 1}")
         it.append(lambda: self.lds(("w", "x", 0), f"ds_write_b128 v{WADDR}, v[{OUT}:{OUT + 3}]"))
         return it

@@ -86,7 +86,15 @@ static int render_launch(const char* who, const sr_render_args* in, int feat, in
     SR_REQUIRE(in->n_samples <= 64, "%s: n_samples=%d unsupported (one wave per ray: <= 64); use the separate launches", who, in->n_samples);
     SR_REQUIRE(tr->target && tr->loss_parts && tr->d_sigma && tr->d_albedo && tr->d_sun_v && tr->g_beta && tr->d_sky && out->sky, "%s: null training output", who);
     SR_REQUIRE(out->albedo && out->sigma && out->sun_v && out->beta, "%s: the four per-point outputs are required (the dX pass reads them)", who);
+    if (tr->gather_idx != nullptr) {
+      SR_REQUIRE(tr->cursor && tr->batches >= 1 && tr->batches < (1 << 24), "%s: the in-launch sampler needs a cursor block and 1 <= batches < 2^24", who);
+      SR_REQUIRE(tr->out_rays && tr->out_rgbs && tr->out_ts, "%s: the in-launch sampler needs out_rays / out_rgbs / out_ts", who);
+      SR_REQUIRE(in->ray_stride == 11 && in->bank_chunks == 0 && in->z_in == nullptr && in->u == nullptr && in->noise == nullptr,
+                 "%s: the in-launch sampler takes a bank of 11-float rows and draws its own jitter (no z_in / u / noise / bank_chunks)", who);
+    }
   }
+  SR_REQUIRE(in->tick != 2 || (tr != nullptr && in->bank_chunks == 0), "%s: tick == 2 (tick first) is a training-launch option", who);
+  SR_REQUIRE(in->tick >= 0 && in->tick <= 2, "%s: tick must be 0, 1 or 2", who);
   if (in->n_rays <= 0) return 0;
   FwdParams p;
   p.in.org = in->rays, p.in.org_stride = in->ray_stride;
@@ -105,6 +113,8 @@ static int render_launch(const char* who, const sr_render_args* in, int feat, in
     TrainParams& t = p.train;
     t.target = tr->target, t.sched = tr->sched, t.beta_min = tr->beta_min, t.loss_parts = tr->loss_parts, t.rgb = tr->rgb;
     t.d_sigma = tr->d_sigma, t.d_albedo = tr->d_albedo, t.d_sun = tr->d_sun_v, t.g_beta = tr->g_beta, t.d_sky = tr->d_sky;
+    t.gather_idx = (const long long*)tr->gather_idx, t.cursor = tr->cursor, t.batches = (unsigned)tr->batches;
+    t.out_rays = tr->out_rays, t.out_rgbs = tr->out_rgbs, t.out_ts = (long long*)tr->out_ts;
   }
   p.stream_hi = (const char*)stream_hi, p.stream_lo = (const char*)stream_lo, p.l0 = (const float4*)l0;
   p.albedo = out->albedo, p.sigma = out->sigma, p.sun_v = out->sun_v, p.beta = out->beta;

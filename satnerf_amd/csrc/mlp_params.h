@@ -43,6 +43,14 @@ struct TrainParams {
   float* d_sun;            // (N,S)
   float* g_beta;           // (N,S)
   float* d_sky;            // (N,3)
+  // the batch sampler inside the launch (include/satrender.h sr_train_args): rays / ts / target are the resident bank, ray r reads row
+  // gather_idx[cursor[0] * n_rays + r]; the compositing wave copies the row out for the later launches of the step
+  const long long* gather_idx;
+  float* cursor;
+  unsigned batches;
+  float* out_rays;         // (N,11)
+  float* out_rgbs;         // (N,3)
+  long long* out_ts;       // (N)
 };
 
 struct FwdParams {

@@ -569,7 +569,33 @@ struct TailAdamParams {
   const int* late; int n_late;    // flat indices (relative to q.grad) updated by the last atomics block
   const float* state; unsigned* arrive;
   float lr, b1, b2, eps, grad_scale;
+  sr_pack_scatter pack;           // pack.map != NULL: the updated parameter is also written into the weight streams (r05: no sr_pack_all launch)
 };
+
+// The weight streams' copy of ONE freshly updated parameter (what sr_pack_all gathers for the whole stream at the start of the next step):
+// `map` lists the parameter's (at most two) places -- the forward stream, the transposed stream of the dX kernel, or the fp32 fc_net.0
+// table -- as  position | scale index << 26 | (1 << 28 for the fp32 table),  -1 = none.  The arithmetic per element is sr_pack_all's
+// (src * scale, unfused; bf16 hi = RNE(v), lo = RNE(v - hi); the fp16 part of the stream saturates), so the streams hold the same bits.
+__device__ __forceinline__ void pack_scatter_one(const sr_pack_scatter& k, long i, float p) {
+#pragma clang fp contract(off)
+  const int2 w = reinterpret_cast<const int2*>(k.map)[i];
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    const int c = o == 0 ? w.x : w.y;
+    if (c < 0) continue;
+    const int pos = c & 0x3ffffff, si = (c >> 26) & 3;
+    const float v = p * (si == 0 ? k.scales[0] : si == 1 ? k.scales[1] : si == 2 ? k.scales[2] : k.scales[3]);
+    if (c & (1 << 28)) {
+      k.l0[pos] = v;
+      continue;
+    }
+    uint32_t h, l;
+    split_bf16x2(v, 0.f, h, l);
+    if (pos < k.n_f16) h = pack_f16x2_sat(v, 0.f);
+    k.hi[pos] = (uint16_t)h;
+    if (k.lo) k.lo[pos] = (uint16_t)l;
+  }
+}
 __global__ void __launch_bounds__(256) grad_tail_adam_kernel(const TailAdamParams a) {
   const GradTailParams& q = a.q;
   __shared__ float bc[2];
@@ -611,8 +637,11 @@ __global__ void __launch_bounds__(256) grad_tail_adam_kernel(const TailAdamParam
   if (k < 0) return;  // (no weight-gradient GEMM produces it: on the `late` list)
   float g = wg_sum_slices(q.partial, q.blocks, k) * q.gscale[i];
   if (q.accumulate) g += q.grad[i];  // what the solar-correction / depth-supervision passes of this step left
-  adam_one(a.p[i], g, a.m[i], a.v[i], step_size, a.b1, a.b2, a.eps, a.grad_scale, sqrt_bc2, 1);
+  float p = a.p[i];
+  adam_one(p, g, a.m[i], a.v[i], step_size, a.b1, a.b2, a.eps, a.grad_scale, sqrt_bc2, 1);
+  a.p[i] = p;
   q.grad[i] = 0.f;
+  if (a.pack.map != nullptr) pack_scatter_one(a.pack, i, p);
 }
 
 }  // namespace sr
@@ -803,7 +832,7 @@ extern "C" int sr_grad_tail_adam(const float* partial, const int32_t* gidx, cons
                                  const float* b1, const float* w2, const float* sky, const float* d_sky, float* g_w1, float* g_b1, float* g_w2,
                                  float* g_b2, const float* d_t, const int64_t* ts, int n_samples, int tau, float* g_emb, float* params,
                                  float* exp_avg, float* exp_avg_sq, const int32_t* late_idx, int n_late, float* state, float lr, float beta1,
-                                 float beta2, float eps, float grad_scale, void* stream) {
+                                 float beta2, float eps, float grad_scale, const sr_pack_scatter* pack, void* stream) {
   SR_REQUIRE(partial && gidx && gscale && blocks && grad && sun && w1 && b1 && w2 && sky && d_sky && g_w1 && g_b1 && g_w2 && g_b2 && d_t && ts && g_emb,
              "sr_grad_tail_adam: null pointer");
   SR_REQUIRE(params && exp_avg && exp_avg_sq && state && (late_idx || n_late == 0) && n_late >= 0, "sr_grad_tail_adam: null optimizer pointer");
@@ -820,6 +849,11 @@ extern "C" int sr_grad_tail_adam(const float* partial, const int32_t* gidx, cons
   a.p = params, a.m = exp_avg, a.v = exp_avg_sq, a.late = late_idx, a.n_late = n_late, a.state = state;
   a.arrive = reinterpret_cast<unsigned*>(state + 3);  // the schedule block's arrival counter (ray_device.h tick_when_all_read: unused by training steps)
   a.lr = lr, a.b1 = beta1, a.b2 = beta2, a.eps = eps, a.grad_scale = grad_scale;
+  a.pack = sr_pack_scatter{};
+  if (pack != nullptr && pack->map != nullptr) {
+    SR_REQUIRE(pack->hi && pack->l0 && pack->n_f16 >= 0, "sr_grad_tail_adam: pack needs the stream and the fc_net.0 table");
+    a.pack = *pack;
+  }
   hipLaunchKernelGGL(grad_tail_adam_kernel, dim3(q.blocks_unpack + q.blocks_sky + q.blocks_emb), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("grad_tail_adam_kernel");
 }

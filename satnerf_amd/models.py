@@ -206,6 +206,45 @@ class SatNeRF(_FlatParamModule):
         if backward:
             self._pack_cache["bstream"] = (version, flat.data_ptr(), bufs["hi"][n_f:])
 
+    def pack_scatter(self, mode):
+        """What ``ops.grad_tail_adam(pack=...)`` needs so that the launch that updates the parameters ALSO refreshes the buffers
+        ``repack(mode, backward=True)`` fills (forward stream | transposed stream, fc_net.0 table): the inverse scatter map of
+        ``packing.pack_scatter_map`` on the device plus those buffers.  A captured single-GPU step then has no sr_pack_all launch;
+        ``note_packed`` tells the caches afterwards."""
+        key = _stream_kind(mode)
+        bufs = self._pack_cache.get(("buf", key, True))
+        if bufs is None:
+            raise RuntimeError("pack_scatter needs the buffers of an earlier repack(mode, backward=True)")
+        dev = bufs["hi"].device
+        ent = self._pack_cache.get("scatter")
+        if ent is None or ent[0].device != dev:
+            m, scales = packing.pack_scatter_map(self.feat, self.t_embedding_dims)
+            ent = (torch.from_numpy(m).to(dev), [float(x) for x in scales])
+            self._pack_cache["scatter"] = ent
+        n_f = self._device_maps()["idx"].numel()
+        return {"map": ent[0], "scales": ent[1], "hi": bufs["hi"], "lo": bufs["lo"], "l0": bufs["l0"], "n_f16": n_f if key == "f16" else 0}
+
+    def packed_static(self, mode):
+        """(hi, lo | None, l0, transposed stream, backward maps) = views of the STATIC buffers ``repack(mode, backward=True)`` fills, without
+        a version check: for steps whose own optimizer launch keeps those buffers current (``pack_scatter``)."""
+        key = _stream_kind(mode)
+        bufs = self._pack_cache.get(("buf", key, True))
+        if bufs is None:
+            raise RuntimeError("packed_static needs the buffers of an earlier repack(mode, backward=True)")
+        n_f = self._device_maps()["idx"].numel()
+        return bufs["hi"][:n_f], (bufs["lo"][:n_f] if key == "x3" else None), bufs["l0"], bufs["hi"][n_f:], self._pack_cache["bmaps"]
+
+    def note_packed(self, mode):
+        """The buffers of ``repack(mode, backward=True)`` hold the CURRENT weights (the optimizer launch scattered them): stamp the caches
+        ``packed`` / ``packed_backward`` consult with the current version, as ``repack`` does after its launch."""
+        key = _stream_kind(mode)
+        bufs = self._pack_cache[("buf", key, True)]
+        flat = self.flat_params()
+        n_f = self._device_maps()["idx"].numel()
+        version = self.weights_version()
+        self._pack_cache[key] = (version, flat.data_ptr(), (bufs["hi"][:n_f], bufs["lo"][:n_f] if key == "x3" else None, bufs["l0"]))
+        self._pack_cache["bstream"] = (version, flat.data_ptr(), bufs["hi"][n_f:])
+
     def _device_maps(self):
         dev = self._flat.device
         ent = self._pack_cache.get("maps")

@@ -191,14 +191,23 @@ def render_fwd(rays, ts, temb, n_samples, feat, tau, mode, stream_hi, stream_lo,
 
 
 def render_train(rays, ts, temb, n_samples, feat, tau, mode, stream_hi, stream_lo, l0, sky_w1, sky_b1, sky_w2, sky_b2, target, acts, u=None,
-                 noise=None, noise_std=0.0, seed=0, step_counter=None, sched=None, beta_min=0.05, want_z=False):
+                 noise=None, noise_std=0.0, seed=0, step_counter=None, sched=None, beta_min=0.05, want_z=False, tick=0, gather=None):
     """The training forward in ONE launch (sr_satnerf_render_train): stratified depths (``u`` (N,S) given, else drawn in the kernel from
     ``seed`` / ``step_counter``) -> fused MLP saving the 8-bit activations into ``acts`` -> sky head, compositing, colour loss and the
     compositing backward per ray.  Returns dict(albedo (N,S,3), sigma, sun_v, beta (N,S), sky (N,3), z (N,S) or None, loss (partial sums),
     rgb (N,3), d_sigma, d_sun, g_beta (N,S), d_albedo (N,S,3), d_sky (N,3)) -- what ``ray_setup`` + ``satnerf_mlp`` + ``render_loss``
-    return, bit for bit."""
+    return, bit for bit.  ``tick`` = 2: the launch opens the step (advances ``step_counter`` and draws for the advanced value).
+    ``gather`` = dict(idx, cursor, batches, out=(rays (N,11), rgbs (N,3), ts (N))): ``rays`` / ``ts`` / ``target`` are the resident bank and
+    the launch samples batch cursor[0] of the epoch's shuffled ``idx`` itself, writing the batch rows to ``out``."""
     rays, stride = _rows(rays, "rays", 11)
     n, s, dev = rays.shape[0], int(n_samples), rays.device
+    if gather is not None:
+        o_rays, o_rgbs, o_ts = gather["out"]
+        n = o_rays.shape[0]
+        if (stride != 11 or tuple(_chk(o_rays, "out rays").shape) != (n, 11) or tuple(_chk(o_rgbs, "out rgbs").shape) != (n, 3)
+                or tuple(_chk(o_ts, "out ts", torch.int64).shape) != (n,) or _chk(gather["idx"], "idx", torch.int64).numel() < int(gather["batches"]) * n
+                or target.shape[0] != rays.shape[0] or ts.shape[0] != rays.shape[0] or u is not None or noise is not None):
+            raise ValueError("gather: the bank (rays (R,11), ts (R), target (R,3)), idx (>= batches x N) and out = ((N,11), (N,3), (N,)) do not fit")
     _chk(ts, "ts", torch.int64), _chk(temb, "temb")
     for t, nm in ((u, "u"), (noise, "noise")):
         if t is not None and tuple(_chk(t, nm).shape) != (n, s):
@@ -211,11 +220,14 @@ def render_train(rays, ts, temb, n_samples, feat, tau, mode, stream_hi, stream_l
            "loss": e((n * s + per_block - 1) // per_block), "rgb": e(n, 3), "d_sigma": e(n, s), "d_albedo": e(n, s, 3), "d_sun": e(n, s),
            "g_beta": e(n, s), "d_sky": e(n, 3)}
     args = _lib.RenderArgs(_p(rays), stride, _p(ts), _p(temb), n, s, None, _p(u), int(seed) & 0xFFFFFFFFFFFFFFFF,
-                           _p(_chk(step_counter, "step_counter", allow_none=True)), 0, _p(noise), float(noise_std), sky_w1.shape[0],
+                           _p(_chk(step_counter, "step_counter", allow_none=True)), int(tick), _p(noise), float(noise_std), sky_w1.shape[0],
                            _p(_chk(sky_w1, "w1")), _p(_chk(sky_b1, "b1")), _p(_chk(sky_w2, "w2")), _p(_chk(sky_b2, "b2")), 0)
     outs = _lib.RenderOutputs(_p(out["z"]), _p(out["albedo"]), _p(out["sigma"]), _p(out["sun_v"]), _p(out["beta"]), _p(out["sky"]), None, None, None, None)
+    g = gather or {}
     tr = _lib.TrainArgs(_p(_chk(target, "target")), _p(_chk(sched, "sched", allow_none=True)), float(beta_min), _p(out["loss"]), _p(out["rgb"]),
-                        _p(out["d_sigma"]), _p(out["d_albedo"]), _p(out["d_sun"]), _p(out["g_beta"]), _p(out["d_sky"]))
+                        _p(out["d_sigma"]), _p(out["d_albedo"]), _p(out["d_sun"]), _p(out["g_beta"]), _p(out["d_sky"]),
+                        _p(g.get("idx")), _p(_chk(g.get("cursor"), "cursor", allow_none=True)), int(g.get("batches", 0)),
+                        *([_p(t) for t in g["out"]] if gather is not None else [None, None, None]))
     ev = kernel_timer.span("mlp_fwd") if kernel_timer is not None else None
     if ev:
         ev[0].record()
@@ -639,16 +651,23 @@ def grad_tail(partial, plan, gidx, gscale, grad_flat, sun, w1, b1, w2, sky_rgb, 
 
 
 def grad_tail_adam(partial, plan, gidx, gscale, grad_flat, sun, w1, b1, w2, sky_rgb, d_sky, g_w1, g_b1, g_w2, g_b2, d_t, ts, n_rays, n_samples, tau,
-                   g_emb, params, exp_avg, exp_avg_sq, late_idx, state, lr=-1.0, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+                   g_emb, params, exp_avg, exp_avg_sq, late_idx, state, lr=-1.0, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, pack=None):
     """``grad_tail`` + ``adam_step_graph`` in one launch (sr_grad_tail_adam): ``params`` / ``exp_avg`` / ``exp_avg_sq`` are the flat buffers
-    aligned with ``grad_flat`` (they may extend past it: ``late_idx`` addresses the embedding rows behind the model's parameters)."""
+    aligned with ``grad_flat`` (they may extend past it: ``late_idx`` addresses the embedding rows behind the model's parameters).
+    ``pack`` (``SatNeRF.pack_scatter``): the launch also writes every updated parameter into the weight streams (no sr_pack_all next step)."""
     sun, stride = _rows(sun, "sun", 3)
+    ps = None
+    if pack is not None:
+        if pack["map"].shape != (gidx.numel(), 2):
+            raise ValueError("pack map does not match the parameter count")
+        ps = _lib.PackScatter(_p(_chk(pack["map"], "pack map", torch.int32)), _p(pack["hi"]), _p(pack["lo"]), _p(_chk(pack["l0"], "pack l0")),
+                              int(pack["n_f16"]), (C.c_float * 4)(*[float(x) for x in pack["scales"]]))
     _lib.call("sr_grad_tail_adam", _p(partial), _p(_chk(gidx, "gidx", torch.int32)), _p(_chk(gscale, "gscale")), gidx.numel(), _p(plan),
               _p(_chk(grad_flat, "grad_flat")), 1, _p(sun), stride, n_rays, w1.shape[0], _p(w1), _p(b1), _p(w2), _p(_chk(sky_rgb, "sky")),
               _p(_chk(d_sky, "d_sky")), _p(g_w1), _p(g_b1), _p(g_w2), _p(g_b2), _p(_chk(d_t, "d_t")), _p(_chk(ts, "ts", torch.int64)), n_samples, tau,
               _p(_chk(g_emb, "g_emb")), _p(_chk(params, "params")), _p(_chk(exp_avg, "exp_avg")), _p(_chk(exp_avg_sq, "exp_avg_sq")),
               _p(_chk(late_idx, "late_idx", torch.int32)), late_idx.numel(), _p(_chk(state, "state")), float(lr), float(betas[0]), float(betas[1]),
-              float(eps), float(grad_scale), _stream())
+              float(eps), float(grad_scale), C.byref(ps) if ps is not None else None, _stream())
 
 
 def adam_step_graph(params, grads, exp_avg, exp_avg_sq, state, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, zero_grad=True):

@@ -615,3 +615,41 @@ def wgrad9_duties(feat=256, tau=4):
                 n_df += 1
                 pos += 2
     return out.reshape(len(bm["block_rows"]), WG9_DUTY_INTS)
+
+
+PACK_POS_BITS, PACK_L0_FLAG = 26, 1 << 28
+
+
+@functools.lru_cache(maxsize=8)
+def pack_scatter_map(feat=256, tau=4):
+    """The inverse of the gather maps ``sr_pack_all`` runs (forward stream | transposed stream | fp32 fc_net.0 table), for the launch
+    that updates the parameters (sr_grad_tail_adam's ``pack``): int32 [n_params, 2] = the (at most two) places parameter i is copied
+    to, each  position | scale index << 26 | (1 << 28: the fc_net.0 table),  -1 = none; positions count through ``forward_maps`` idx
+    followed by ``backward_maps`` idx, exactly the buffer ``SatNeRF.repack(backward=True)`` packs.  Returns (map, scales[4]): the distinct
+    non-zero scale factors of the three maps (1, 1 / 2 pi, 30 / 2 pi).  A stream element whose gather index is negative is a constant
+    zero: the first sr_pack_all wrote it and nothing changes it."""
+    fm, bm = forward_maps(feat, tau), backward_maps(feat, tau)
+    n = int(bm["n_params"])
+    idx = np.concatenate([fm["idx"], bm["idx"]]).astype(np.int64)
+    scale = np.concatenate([fm["scale"], bm["scale"]]).astype(np.float32)
+    l0_idx, l0_scale = fm["l0_idx"].astype(np.int64), fm["l0_scale"].astype(np.float32)
+    assert idx.size < (1 << PACK_POS_BITS) and l0_idx.size < (1 << PACK_POS_BITS)
+    live = (idx >= 0) & (scale != 0)
+    live0 = (l0_idx >= 0) & (l0_scale != 0)
+    values = sorted(set(np.unique(scale[live]).tolist()) | set(np.unique(l0_scale[live0]).tolist()))
+    assert 1 <= len(values) <= 4, values
+    scales = np.zeros(4, np.float32)
+    scales[:len(values)] = values
+    values_arr = np.array(values, np.float32)
+    pos, pos0 = np.nonzero(live)[0], np.nonzero(live0)[0]
+    params = np.concatenate([idx[pos], l0_idx[pos0]])
+    words = np.concatenate([pos | (np.searchsorted(values_arr, scale[pos]).astype(np.int64) << PACK_POS_BITS),
+                            pos0 | (np.searchsorted(values_arr, l0_scale[pos0]).astype(np.int64) << PACK_POS_BITS) | PACK_L0_FLAG])
+    order = np.argsort(params, kind="stable")
+    params, words = params[order], words[order]
+    first = np.r_[True, params[1:] != params[:-1]]
+    rank = np.arange(params.size) - np.maximum.accumulate(np.where(first, np.arange(params.size), 0))  # 0, 1, .. within a parameter's run
+    assert rank.max() < 2, "a parameter is copied to more than two places"
+    out = np.full((n, 2), -1, np.int32)
+    out[params, rank] = words
+    return out, scales

@@ -234,6 +234,7 @@ class Trainer:
             self._late_idx = torch.from_numpy(late.astype(np.int32)).to(p.device)
         self._graph, self._static, self._graph_banks = None, None, None
         self._pre_setup, self._pre_bufs = None, None
+        self._pack_in_tail, self._gather_in_fwd, self._packed_version = False, None, None
         self.max_inflight = int(os.environ.get("SATNERF_MAX_INFLIGHT", "0"))
         self.pace_every = max(1, int(os.environ.get("SATNERF_PACE_EVERY", "1")))
         self.last_rgb = None
@@ -258,9 +259,15 @@ class Trainer:
         mode = _mode_of(args)
         feat, tau = model.feat, model.t_embedding_dims
         ticking = self._kernel_rng or self._adam_in_graph
-        model.repack(mode, backward=True, tick=self.adam_state if ticking else None)
-        hi, lo, l0 = model.packed(mode)
-        bstream, maps = model.packed_backward()
+        # r05, single-GPU captured step: no sr_pack_all launch -- the launch that updates the parameters (sr_grad_tail_adam) also writes
+        # them into the weight streams, and the forward, now the step's first launch, ticks the step counter itself ("tick first")
+        pit = self._pack_in_tail and ticking
+        if pit:
+            hi, lo, l0, bstream, maps = model.packed_static(mode)
+        else:
+            model.repack(mode, backward=True, tick=self.adam_state if ticking else None)
+            hi, lo, l0 = model.packed(mode)
+            bstream, maps = model.packed_backward()
         sk = model.sky_color
         # stratified jitter (rendering.py:77): torch's generator when run eagerly; inside a captured step the kernel draws it
         # itself (Philox keyed by the seed, stepping with the device counter) -- one launch and the graph's RNG bookkeeping less
@@ -275,10 +282,18 @@ class Trainer:
         # state, compositing + colour loss + compositing backward in the epilogue -- r04 ran sr_ray_setup, the MLP and sr_render_loss
         # as three launches; the per-ray functions are the same, the results bit-identical.  SATNERF_TRAIN_FUSED=0: the three launches (A/B)
         fused = self._pre_setup is None and self._fused_forward()
+        gather, self._gather_in_fwd = self._gather_in_fwd, None
+        if pit and not fused:
+            raise RuntimeError("pack-in-tail steps need the one-launch training forward (it ticks the step counter)")
         if fused:
-            r = ops.render_train(rays, ts, emb.weight.data, s, feat, tau, mode, hi, lo, l0, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data,
-                                 sk[2].bias.data, rgbs, acts, u=u, noise=nz, noise_std=noise_std, seed=self._seed, step_counter=self.adam_state,
-                                 sched=self.sched, want_z=sc_on)
+            # gather: the captured step samples its batch INSIDE this launch (the bank's cursor over the epoch's shuffled rows): rays / ts /
+            # rgbs -- the graph's static batch tensors -- are then OUTPUTS of the launch, read by the step's later launches
+            src = (gather["bank"].rays, gather["bank"].ts, gather["bank"].rgbs) if gather is not None else (rays, ts, rgbs)
+            r = ops.render_train(src[0], src[1], emb.weight.data, s, feat, tau, mode, hi, lo, l0, sk[0].weight.data, sk[0].bias.data, sk[2].weight.data,
+                                 sk[2].bias.data, src[2], acts, u=u, noise=nz, noise_std=noise_std, seed=self._seed, step_counter=self.adam_state,
+                                 sched=self.sched, want_z=sc_on, tick=2 if pit else 0,
+                                 gather=None if gather is None else dict(idx=gather["idx"], cursor=gather["cursor"], batches=gather["batches"],
+                                                                         out=(rays, rgbs, ts)))
             z, sky, loss, self.last_rgb = r["z"], r["sky"], r["loss"], r["rgb"]
             albedo, sigma, sun_v, beta = r["albedo"].view(-1, 3), r["sigma"].view(-1), r["sun_v"].view(-1), r["beta"].view(-1)
             d_sigma, d_albedo, d_sun, g_beta, d_sky = r["d_sigma"], r["d_albedo"], r["d_sun"], r["g_beta"], r["d_sky"]
@@ -316,8 +331,10 @@ class Trainer:
         if self._adam_in_graph and not self._collective and self._late_idx is not None and os.environ.get("SATNERF_TAIL_ADAM", "1") != "0":
             # lr < 0: the kernel reads the current rate from sched[1], so a scheduler can change it under graph replay
             ops.grad_tail_adam(*tail, self.state.params, self.exp_avg, self.exp_avg_sq, self._late_idx, self.adam_state, lr=-1.0,
-                               grad_scale=1.0 / self.world)
+                               grad_scale=1.0 / self.world, pack=model.pack_scatter(mode) if pit else None)
             return loss
+        if pit:
+            raise RuntimeError("pack-in-tail steps end in sr_grad_tail_adam")
         ops.grad_tail(*tail)
         if self._adam_in_graph:  # the update rides in the same graph (the RCCL all-reduce captured with it, or the A/B switch above)
             if self._collective:
@@ -459,7 +476,11 @@ class Trainer:
         for k, b in enumerate(self._graph_banks):
             idx, cursor, batches = b.graph_source()
             out = self._static[3 * k:3 * k + 3]
-            if k == 0 and self._kernel_rng and not self._fused_forward():
+            if (k == 0 and self._kernel_rng and self._fused_forward() and not self._snerf and type(b).__name__ == "RayBank"
+                    and os.environ.get("SATNERF_GATHER_IN_FWD", "1") != "0"):
+                # the colour batch is sampled by the forward launch itself (sr_satnerf_render_train's gather): no launch here
+                self._gather_in_fwd = dict(bank=b, idx=idx, cursor=cursor, batches=batches)
+            elif k == 0 and self._kernel_rng and not self._fused_forward():
                 # the colour batch: gather + stratified depths + sky colour in ONE launch (sr_gather_setup); _forward_backward then
                 # skips its ray set-up launch (when the forward is not the one-launch training render, which sets the rays up itself).
                 # step_offset 1: this runs before sr_pack_all ticks the step counter
@@ -487,6 +508,12 @@ class Trainer:
                               and dist.get_backend() == "nccl" and not getattr(self, "_collective_capture_failed", False))
         self._adam_in_graph = (not self._collective) or capture_collective
         self._kernel_rng = float(self.args.noise_std) == 0.0  # (a noisy step still draws randn from torch's generator)
+        # single GPU: the tail applies Adam and re-packs the weight streams, the forward opens the step (no sr_pack_all launch)
+        self._pack_in_tail = (self._adam_in_graph and not self._collective and self._late_idx is not None and self._kernel_rng
+                              and self._fused_forward() and os.environ.get("SATNERF_TAIL_ADAM", "1") != "0"
+                              and os.environ.get("SATNERF_TAIL_PACK", "1") != "0")
+        if self._pack_in_tail:
+            self._repack_static()
         snapshot = (self.state.params.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.adam_state.clone())
         def run():
             if self._graph_banks:
@@ -506,6 +533,8 @@ class Trainer:
         self.adam_state.copy_(snapshot[3])  # ... and ticked the step counter (the jitter RNG's step) in every configuration
         for b in self._graph_banks or ():    # ... and moved the banks' cursors
             b.graph_reset()
+        if self._pack_in_tail:               # ... and left the warm-up's weights in the streams
+            self._repack_static()
         from . import ops
 
         self._graph = torch.cuda.CUDAGraph()
@@ -528,6 +557,15 @@ class Trainer:
             self.state.zero_grad()
             return self._capture(inputs, banks=banks)
         self.state.zero_grad()  # capture does not execute
+
+    def _repack_static(self):
+        """(pack-in-tail steps) one eager sr_pack_all into the static stream buffers: at capture time, and whenever somebody other than the
+        step's own optimizer launch changed the weights (load_state_dict, a manual edit) -- the step itself keeps them current."""
+        from .rendering import _mode_of
+
+        model = self.models["coarse"]
+        model.repack(_mode_of(self.args), backward=True, tick=None)
+        self._packed_version = model.weights_version()
 
     def _any_rank(self, flag):
         """Logical OR of ``flag`` over the ranks, host-side and without a collective: every rank adds its flag and a tick to two counters
@@ -557,6 +595,11 @@ class Trainer:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._vote_group)
             return bool(t.item())
 
+    def _sampler_in_forward(self, banks):
+        """True when a captured step can sample its colour batch inside the forward launch (sr_satnerf_render_train's gather)."""
+        return (self._fused_forward() and not self._snerf and type(banks[0]).__name__ == "RayBank"
+                and os.environ.get("SATNERF_GATHER_IN_FWD", "1") != "0")
+
     def step_from_bank(self, bank, depth_bank=None):
         """One step on the banks' next batches; with a captured graph the batches are gathered straight into its static inputs."""
         shapes = (bank.batch_size,) + ((depth_bank.batch_size,) if depth_bank is not None else ())
@@ -568,7 +611,7 @@ class Trainer:
                 b._ts_validated = True
         banks = (bank,) + ((depth_bank,) if depth_bank is not None else ())
         if (self.direct and self.use_graph and float(self.args.noise_std) == 0.0 and all(b.drop_last for b in banks)
-                and os.environ.get("SATNERF_GRAPH_SAMPLER", "0") == "1"):
+                and os.environ.get("SATNERF_GRAPH_SAMPLER", "1" if self._sampler_in_forward(banks) else "0") == "1"):
             # opt-in: the captured step samples for itself -- its first launches gather the banks' next batches (device cursors over
             # the epoch's shuffled indices), so a step is ONE graph replay with no eager launch and no host-side index arithmetic.
             # Off by default: on MI355X it is exactly as fast as the eager gather in front of the replay (0.420-0.425 ms per step
@@ -622,11 +665,15 @@ class Trainer:
                 if not _inputs_in_place:
                     for dst, src in zip(self._static, inputs):
                         dst.copy_(src)
+                if self._pack_in_tail and self.models["coarse"].weights_version() != self._packed_version:
+                    self._repack_static()  # the weights changed behind the step's back
                 self._pace()
                 self._graph.replay()
                 loss = self._static_loss
             else:
                 inputs = tuple(t.contiguous() for t in inputs)
+                if self._pack_in_tail and self._adam_in_graph and self.models["coarse"].weights_version() != self._packed_version:
+                    self._repack_static()
                 loss = self._forward_backward(*inputs[:3], depth=inputs[3:] or None)
             in_graph = self._adam_in_graph and self._graph is not None and self.use_graph and float(self.args.noise_std) == 0.0
             if self._collective and not self._adam_in_graph:
@@ -671,6 +718,11 @@ class Trainer:
         for m in self.state.modules:
             if hasattr(m, "mark_weights_changed"):
                 m.mark_weights_changed()
+        if self.direct and self._pack_in_tail and self._adam_in_graph:  # ... and the step's last launch re-packed the streams
+            from .rendering import _mode_of
+
+            self.models["coarse"].note_packed(_mode_of(self.args))
+            self._packed_version = self.models["coarse"].weights_version()
         self.args.noise_std *= 0.9  # main.py:132
         if self._caller_args is not self.args:
             self._caller_args.noise_std = self.args.noise_std

@@ -259,10 +259,8 @@ class _Wave:
                 x = _f16((self.v[int(args[1][1:])] >> (16 * half)) & 0xffff)
                 r = _to_f16_bits(np.sin(2 * np.pi * x))
                 self.v[d] = (self.v[d] & (0xffff0000 if half == 0 else 0x0000ffff)) | (r << (16 * half))
-            elif op == "v_pk_mul_f32":
-                d, x, y = (int(re.match(r"v\[(\d+):", a_).group(1)) for a_ in args[:3])
-                for k in range(2):
-                    self.v[d + k] = (self.v[x + k].view(np.float32) * self.v[y + k].view(np.float32)).astype(np.float32).view(np.uint32)
+            elif op == "v_mul_f32":
+                self.v[int(args[0][1:])] = (self.src(args[1]).view(np.float32) * self.src(args[2]).view(np.float32)).astype(np.float32).view(np.uint32)
             elif op == "v_cvt_pk_f16_f32":
                 lo, hi = self.src(args[1]).view(np.float32), self.src(args[2]).view(np.float32)
                 self.v[int(args[0][1:])] = _to_f16_bits(lo) | (_to_f16_bits(hi) << 16)

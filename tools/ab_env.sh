@@ -1,11 +1,12 @@
 #!/bin/bash
-# tools/ab_env.sh <rounds> <ENV=a> <ENV=b> ...: interleaved bench.py runs (200 graph-replayed training steps) of ONE tree under different
-# environment settings (A/B switches such as SATNERF_TRAIN_FUSED=0): step time and the eager per-kernel timings, one line per run.
+# Interleaved A/B of bench.py's training step under environment toggles, on ONE box (step times differ by up to 12 % between boxes of the
+# pool): tools/ab_env.sh ROUNDS "A_ENV=.. B_ENV=.." "C_ENV=.." ...  -- every variant is an env string ("" = defaults); prints ms_per_step
+# per run.  Example (r05: the four-launch step against the r04 launch sequence):
+#   tools/ab_env.sh 3 "" "SATNERF_TAIL_PACK=0 SATNERF_GATHER_IN_FWD=0"
 rounds=$1; shift
-root=$(cd "$(dirname "$0")/.." && pwd)
 for r in $(seq $rounds); do
-  for e in "$@"; do
-    ( cd $root && echo "[$e]" $(env $e python bench.py --steps 200 --warmup 20 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; b=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('step_ms', round(b['ms_per_step'],4), {k: round(v['ms']*1e3,1) for k,v in b['roofline']['all_kernels'].items()})") )
+  for v in "$@"; do
+    ms=$(env $v python bench.py --no-cpu-baseline --no-extras ${AB_ARGS:-} 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1)
+    echo "[$r] {${v:-defaults}} $ms"
   done
 done
