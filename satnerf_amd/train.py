@@ -18,6 +18,9 @@ import torch
 import torch.distributed as dist
 
 
+_VOTES = 0  # capture votes taken by this process (Trainer._any_rank): the rendezvous store's keys are job-global
+
+
 def _fmt_of(args):
     """Format of the saved training state (include/satrender.h SR_FMT*): ``args.bwd_fmt`` (32 | 16 | 8) when given, else the
     numeric mode's default -- 8-bit for the throughput mode ``bf16``, 16-bit for the parity mode ``bf16x3``.
@@ -574,12 +577,17 @@ class Trainer:
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return bool(flag)
         world = dist.get_world_size()
-        self._vote_no = getattr(self, "_vote_no", 0) + 1  # (captures happen in the same order on every rank)
+        # one key per vote of the JOB, not of this Trainer: the store and its counters outlive a trainer, and a second trainer re-using
+        # vote #1 would find the first one's ticks already at `world` and read `failed` before the other ranks have added theirs
+        # (ADVICE r04).  Captures -- of every trainer a process creates -- happen in the same order on every rank: a process-wide
+        # counter names the same vote everywhere.
+        global _VOTES
+        _VOTES += 1
         try:
             import time
 
             store = dist.distributed_c10d._get_default_store()
-            key = f"satnerf_amd/capture_vote/{self._vote_no}"
+            key = f"satnerf_amd/capture_vote/{_VOTES}"
             store.add(key + "/failed", 1 if flag else 0)
             store.add(key + "/ticks", 1)
             deadline = time.time() + 300.0

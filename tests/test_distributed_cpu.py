@@ -104,6 +104,15 @@ def _vote_worker(rank, world, port, out):
 
     tr = Trainer.__new__(Trainer)  # the vote needs no trainer state: only the process group's rendezvous store
     votes = [tr._any_rank(False), tr._any_rank(rank == 1), tr._any_rank(True), tr._any_rank(False)]
+    # a SECOND trainer of the same job (re-created, or another test sharing the process group): its votes must not meet the first
+    # trainer's counters in the store (keys are numbered per process, not per trainer).  Rank 0 arrives late on purpose: a
+    # re-used key would already hold `world` ticks and rank 1 would read `failed` before rank 0 has added its flag
+    tr2 = Trainer.__new__(Trainer)
+    if rank == 0:
+        import time
+
+        time.sleep(0.3)
+    votes += [tr2._any_rank(rank == 0), tr2._any_rank(False)]
     out[rank] = votes
     dist.destroy_process_group()
 
@@ -115,4 +124,4 @@ def test_capture_failure_vote_is_the_same_on_every_rank():
     with mp.Manager() as mgr:
         out = mgr.dict()
         mp.spawn(_vote_worker, args=(world, port, out), nprocs=world, join=True)
-        assert dict(out) == {0: [False, True, True, False], 1: [False, True, True, False]}
+        assert dict(out) == {0: [False, True, True, False, True, False], 1: [False, True, True, False, True, False]}
