@@ -106,6 +106,17 @@ __device__ __forceinline__ void tick_when_all_read(float* counter, uint32_t step
     }
   }
 }
+// The same at the END of a launch (training launches, r05): ONE thread per workgroup calls it after every wave of the workgroup has long used
+// the value read at the start -- no workgroup barrier and no fence (nothing but the counter is published, and it is read by the NEXT
+// launch).  At the start of the launch the returning atomic held wave 0 -- and with it the workgroup's next barrier -- for a memory round
+// trip per counter (the forward launch that also samples its batch ticks two: +3 us on a 92-us kernel).
+__device__ __forceinline__ void tick_at_exit(float* counter, uint32_t step_read, uint32_t modulo = 0u, uint32_t keep_mod = 1u) {
+  unsigned* arrive = reinterpret_cast<unsigned*>(counter + 3);
+  if (atomicAdd(arrive, 1u) == gridDim.x - 1) {
+    counter[0] = (float)(modulo != 0u ? (step_read + 1u >= modulo ? 0u : step_read + 1u) : next_step(step_read, keep_mod));
+    atomicExch(arrive, 0u);
+  }
+}
 
 // ---- sky colour head of one ray, computed by one wave: models/satnerf.py:138-143,201; every lane returns the colour -------
 __device__ __forceinline__ void sky_ray(float sx, float sy, float sz, int hidden, const float* __restrict__ w1, const float* __restrict__ b1,
