@@ -219,8 +219,17 @@ def test_gradients_vs_oracle_autograd_variants(tau, n_samples, mode, n_rays):
     errs["embedding"] = maxnorm_rel(models["t"].weight.grad.cpu(), eo.grad)
     worst = max(errs, key=errs.get)
     print(tau, n_samples, mode, n_rays, "worst", worst, f"{errs[worst]:.1e}")
-    tol = GRAD_TOL if mode == "bf16x3" else {48: 8e-2, 37: 6.5e-2, 1: 1.8e-1}[n_rays]
-    assert errs[worst] < tol, errs
+    if mode == "bf16x3":
+        assert errs[worst] < GRAD_TOL, errs
+    else:
+        # per tensor: every tensor within 3.5e-2 (1.5 x the worst of them, rgb_from_xyzdir.2.weight at 2.4e-2) EXCEPT the small
+        # sun-visibility gradients named here, which the 8-bit state moves on batches this small (measured 5.4e-2 / 4.4e-2 on the 48- / 37-ray
+        # cases; 1.2e-1, 5.3e-2, 3.9e-2 on the one-ray case: tools/grad_errs_tiny.py); at the benched shape they are inside the common gate
+        # (tests/test_hip_benched_shape.py)
+        loose = {48: {"sun_v_net.2.weight": 8e-2}, 37: {"sun_v_net.2.weight": 6.5e-2},
+                 1: {"sun_v_net.2.weight": 1.8e-1, "sun_v_net.4.weight": 8e-2, "sun_v_net.6.weight": 6e-2}}[n_rays]
+        bad = {k: v for k, v in errs.items() if v >= loose.get(k, 3.5e-2)}
+        assert not bad, (bad, errs)
     assert all(torch.isfinite(sd[k].grad).all() for k in po)
 
 
