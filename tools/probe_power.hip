@@ -31,15 +31,15 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-enum { V_BF16 = 0, V_F16, V_LDS1, V_LDS2, V_SIN, V_PERM4, V_PK4, V_DMA, V_COUNT };
+enum { V_BF16 = 0, V_F16, V_LDS1, V_LDS2, V_SIN, V_PERM4, V_PK4, V_DMA, V_HBM16, V_HBM8, V_COUNT };
 static const char* kNames[V_COUNT] = {"mfma bf16 (regs)", "mfma f16 (regs)", "bf16 + A from LDS per MFMA", "bf16 + A from LDS per 2 MFMAs",
                                       "bf16 + 1 v_sin per MFMA", "bf16 + 4 v_perm per MFMA", "bf16 + 4 v_pk_mul_f32 per MFMA",
-                                      "bf16 + A from LDS + LDS-DMA refill"};
+                                      "bf16 + A from LDS + LDS-DMA refill", "bf16 + 1 KiB from HBM per wave and 16 MFMAs", "bf16 + 1 KiB from HBM per wave and 8 MFMAs"};
 constexpr int kSlots = 64;  // MFMAs per loop iteration
 
 // operands: `ops` holds 8 KiB per wave-lane set: fragment f (0..7) of lane l at ops[(f * 64 + l)] (uint4); LDS ring of 64 KiB filled from `ring`
 template <int V>
-__global__ void __launch_bounds__(512) k(const uint4* __restrict__ ops, const uint4* __restrict__ ring, float* out, int iters) {
+__global__ void __launch_bounds__(512) k(const uint4* __restrict__ ops, const uint4* __restrict__ ring, float* out, int iters, const char* big) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63;
   for (int i = threadIdx.x; i < 4096; i += blockDim.x) reinterpret_cast<uint4*>(lds)[i] = ring[i];
@@ -81,6 +81,19 @@ __global__ void __launch_bounds__(512) k(const uint4* __restrict__ ops, const ui
         asm volatile(RG16(FK) RG16(FK) RG16(FK) RG16(FK) : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [c3] "+v"(c3), [p0] "+v"(p0), [p1] "+v"(p1) : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [b0] "v"(b[0]), [b1] "v"(b[1]));
         s1 += p0[0];
       }
+    } else if constexpr (V == V_HBM16 || V == V_HBM8) {
+      // workspace-like traffic: every wave streams its own region of a 1-GiB buffer (beyond the 256-MB Infinity Cache) with 1-KiB loads
+      constexpr int EVERY = V == V_HBM16 ? 16 : 8;
+      const uint64_t gb = (uint64_t)(uintptr_t)big;
+      uint32_t ho = (uint32_t)(((((unsigned long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (unsigned long)iters + it) * (64 / EVERY) * 1024ul) & ((1ul << 30) - 16384ul)) + lane * 16;
+      asm volatile(".set n, 0\n.rept 64\n"
+                   "v_mfma_f32_32x32x16_bf16 v[32+16*(n%%4):47+16*(n%%4)], %[a0], %[b0], v[32+16*(n%%4):47+16*(n%%4)]\n"
+                   ".if (n %% %c[ev]) == 0\n global_load_dwordx4 v[100+4*((n/%c[ev])%%8):103+4*((n/%c[ev])%%8)], %[ho], %[gb] offset:0\n v_add_u32 %[ho], 1024, %[ho]\n.endif\n"
+                   ".set n, n+1\n.endr\n s_waitcnt vmcnt(0)\n"
+                   : "+{v[32:47]}"(c0), "+{v[48:63]}"(c1), "+{v[64:79]}"(c2), "+{v[80:95]}"(c3), [ho] "+v"(ho)
+                   : [a0] "v"(a[0]), [b0] "v"(b[0]), [gb] "s"(gb), [ev] "n"(EVERY)
+                   : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",
+                     "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "memory");
     } else {
       // A fragments through an 8-deep register ring v[100:131]; piece p of the LDS ring at lds + 1024 p (64 pieces).  lds1: the read of slot
       // n + 6 is issued in front of MFMA n (six ahead, in-order returns: lgkmcnt(6) = read n has landed); lds2 (64 points per wave): one read
@@ -225,6 +238,7 @@ static uint16_t to_f16(float f) {
   return u;
 }
 
+static const char* g_big = nullptr;
 template <int V>
 static double time_one(int waves, const uint4* ops, const uint4* ring, float* out, int slots_per_iter) {
   const int iters = 100;
@@ -232,7 +246,7 @@ static double time_one(int waves, const uint4* ops, const uint4* ring, float* ou
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
   CHECK(hipFuncSetAttribute((const void*)k<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-  auto launch = [&] { hipLaunchKernelGGL(k<V>, dim3(256), dim3(64 * 4 * waves), 65536, 0, ops, ring, out, iters); };
+  auto launch = [&] { hipLaunchKernelGGL(k<V>, dim3(256), dim3(64 * 4 * waves), 65536, 0, ops, ring, out, iters, g_big); };
   for (int i = 0; i < 250; ++i) launch();  // >= 25 ms: the chip settles at its power limit
   CHECK(hipDeviceSynchronize());
   const int reps = 300;
@@ -273,6 +287,12 @@ int main() {
   CHECK(hipMemset(d_zero, 0, h.size() * 2));
   CHECK(hipMemset(d_zring, 0, big.size() * 2));
   CHECK(hipMemcpy(d_ring, big.data(), big.size() * 2, hipMemcpyHostToDevice));
+  {
+    char* big;
+    CHECK(hipMalloc(&big, 1ul << 30));
+    CHECK(hipMemset(big, 0x3c, 1ul << 30));
+    g_big = big;
+  }
   for (int waves = 1; waves <= 2; ++waves) {
     run<V_BF16>(kNames[V_BF16], waves, d_bf, d_ring, d_zero, d_zring, d_out);
     run<V_F16>(kNames[V_F16], waves, d_f16, d_ring, d_zero, d_zring, d_out);
@@ -282,6 +302,8 @@ int main() {
     run<V_SIN>(kNames[V_SIN], waves, d_bf, d_ring, d_zero, d_zring, d_out);
     run<V_PERM4>(kNames[V_PERM4], waves, d_bf, d_ring, d_zero, d_zring, d_out);
     run<V_PK4>(kNames[V_PK4], waves, d_bf, d_ring, d_zero, d_zring, d_out);
+    run<V_HBM16>(kNames[V_HBM16], waves, d_bf, d_ring, d_zero, d_zring, d_out);
+    run<V_HBM8>(kNames[V_HBM8], waves, d_bf, d_ring, d_zero, d_zring, d_out);
   }
   printf("---- fillers beside the MFMA (bf16, operands in registers) ----\n");
 #define X(i, name, text) run_filler<i>(name, d_bf, d_zero, d_out);
