@@ -80,3 +80,37 @@ def test_emulated_backward_dataflow_matches_autograd(tau):
         want = pd[k].grad.reshape(-1).numpy()
         assert np.abs(grad[o:o + n] - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-30), k
     assert np.abs(d_t - t.grad.numpy()).max() <= 1e-5 * np.abs(t.grad.numpy()).max()
+
+
+@pytest.mark.parametrize("feat,tau", [(256, 4), (256, 16), (512, 4)])
+def test_pack_scatter_map_is_the_inverse_of_the_gather_maps(feat, tau):
+    """packing.pack_scatter_map (what sr_grad_tail_adam's `pack` walks: parameter -> its places in the packed streams) against the gather
+    maps sr_pack_all runs: scattering every parameter reproduces the gathered forward stream | transposed stream and the fc_net.0 table
+    exactly (the same fp32 products), every live stream element is written exactly once, constant-zero elements never."""
+    import numpy as np
+
+    fm, bm = packing.forward_maps(feat, tau), packing.backward_maps(feat, tau)
+    m, scales = packing.pack_scatter_map(feat, tau)
+    n = int(bm["n_params"])
+    assert m.shape == (n, 2) and m.dtype == np.int32 and scales.shape == (4,)
+    src = np.random.default_rng(5).standard_normal(n).astype(np.float32)
+    idx = np.concatenate([fm["idx"], bm["idx"]])
+    scale = np.concatenate([fm["scale"], bm["scale"]]).astype(np.float32)
+    want = np.where(idx >= 0, src[np.maximum(idx, 0)] * scale, np.float32(0)).astype(np.float32)
+    want_l0 = np.where(fm["l0_idx"] >= 0, src[np.maximum(fm["l0_idx"], 0)] * fm["l0_scale"].astype(np.float32), np.float32(0)).astype(np.float32)
+    got, got_l0 = np.zeros_like(want), np.zeros_like(want_l0)
+    hits, hits_l0 = np.zeros(want.size, np.int32), np.zeros(want_l0.size, np.int32)
+    for o in range(2):
+        c = m[:, o]
+        ok = c >= 0
+        pos, si, is_l0 = c & ((1 << packing.PACK_POS_BITS) - 1), (c >> packing.PACK_POS_BITS) & 3, (c & packing.PACK_L0_FLAG) != 0
+        v = (src * scales[si]).astype(np.float32)
+        s_ = ok & ~is_l0
+        got[pos[s_]] = v[s_]
+        np.add.at(hits, pos[s_], 1)
+        t_ = ok & is_l0
+        got_l0[pos[t_]] = v[t_]
+        np.add.at(hits_l0, pos[t_], 1)
+    assert np.array_equal(got, want) and np.array_equal(got_l0, want_l0)
+    live = (idx >= 0) & (scale != 0)
+    assert np.array_equal(hits, live.astype(np.int32)) and np.array_equal(hits_l0, ((fm["l0_idx"] >= 0) & (fm["l0_scale"] != 0)).astype(np.int32))
