@@ -157,8 +157,11 @@ __global__ void __launch_bounds__(512) k(const uint4* __restrict__ ops, const ui
   X(18, "v_cvt_pk_f16_f32", "v_cvt_pk_f16_f32 v[16+d], v[24+d], v[28]\n")                 \
   X(19, "v_exp_f32", "v_exp_f32 v[16+d], v[24+d]\n")                                      \
   X(20, "ds_read_b64_tr_b16", "ds_read_b64_tr_b16 v[16+2*(d%%4):17+2*(d%%4)], v30 offset:64*d\n") \
-  X(21, "ds_write_b128", "ds_write_b128 v30, v[24:27] offset:1024*d\n")
-constexpr int kFillers = 22;
+  X(21, "ds_write_b128", "ds_write_b128 v30, v[24:27] offset:1024*d\n")                   \
+  X(22, "v_perm_b32 under EXEC = 0", "s_mov_b64 exec, 0\n v_perm_b32 v[16+d], v[24+d], v[28], v[29]\n s_mov_b64 exec, -1\n") \
+  X(23, "ds_write_b128 under EXEC = 0", "s_mov_b64 exec, 0\n ds_write_b128 v30, v[24:27] offset:1024*d\n s_mov_b64 exec, -1\n") \
+  X(24, "2 x s_mov_b64 exec only", "s_mov_b64 exec, 0\n s_mov_b64 exec, -1\n")
+constexpr int kFillers = 25;
 
 template <int F, int K>
 __global__ void __launch_bounds__(512) kf(const uint4* __restrict__ ops, float* out, int iters) {
@@ -309,6 +312,9 @@ int main() {
 #define X(i, name, text) run_filler<i>(name, d_bf, d_zero, d_out);
   FILLERS(X)
 #undef X
+  printf("---- dead work under EXEC = 0 (8 / 10 per MFMA, zero operands) ----\n");
+  run_fetch<22>("v_perm_b32 under EXEC = 0", 8, d_zero, d_out);
+  run_fetch<24>("2 x s_mov_b64 exec only", 0, d_zero, d_out);
   printf("---- instruction fetch ----\n");
   run_fetch<16>("v_mov_b32", 4, d_zero, d_out);
   run_fetch<0>("v_mul_f32", 4, d_zero, d_out);
