@@ -470,7 +470,48 @@ class Trainer:
             if key in self.models and not (self._snerf and key == "t"):
                 sd.update({prefix + k: v.detach().cpu().clone() for k, v in self.models[key].state_dict().items()})
         torch.save({"state_dict": sd, "global_step": self.n_steps, "epoch": self.current_epoch(),
-                    "optimizer": {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "lr": self.lr, "step": self.n_steps}}, path)
+                    "optimizer": {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "lr": self.lr, "step": self.n_steps,
+                                  "lr0": self.lr0, "device_step": float(self.adam_state[0].item()), "noise_std": float(self.args.noise_std),
+                                  "jitter_seed": int(self._seed)}}, path)
+
+    def load_ckpt(self, path):
+        """Resume (main.py:251 ``resume_from_checkpoint``): restore what ``save_ckpt`` wrote -- weights by Lightning's key prefixes, the
+        Adam moments, the step count (host side: schedule; device side: bias corrections and the jitter stream of captured steps) -- so that
+        the next step is the one the saved run would have taken.  A checkpoint without an ``optimizer`` entry (a reference ``epoch=N.ckpt``:
+        Lightning keeps its optimizer state under other keys) restores the weights and the step count only; the moments restart at zero."""
+        ck = torch.load(path, map_location="cpu")
+        sd = ck["state_dict"]
+        for prefix, key in (("nerf_coarse.", "coarse"), ("nerf_fine.", "fine"), ("embedding_t.", "t")):
+            if key in self.models and not (self._snerf and key == "t"):
+                part = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+                if not part:
+                    raise KeyError(f"checkpoint holds no '{prefix}*' entries")
+                self.models[key].load_state_dict(part)
+        self.state.zero_grad()
+        self.n_steps = int(ck.get("global_step", 0))
+        opt = ck.get("optimizer")
+        if opt is not None and "exp_avg" in opt:
+            if opt["exp_avg"].numel() != self.exp_avg.numel():
+                raise ValueError("the checkpoint's optimizer state does not fit this model set")
+            self.exp_avg.copy_(opt["exp_avg"]), self.exp_avg_sq.copy_(opt["exp_avg_sq"])
+            self.lr0 = float(opt.get("lr0", self.lr0))
+            self.adam_state[0] = float(opt.get("device_step", opt.get("step", self.n_steps)))
+            if "jitter_seed" in opt and int(opt["jitter_seed"]) != self._seed:
+                self._seed = int(opt["jitter_seed"])  # the in-kernel jitter is keyed by (seed, step): the graph holds the seed as a constant
+                self._graph = None
+            if "noise_std" in opt:
+                self.args.noise_std = float(opt["noise_std"])
+                if self._caller_args is not self.args:
+                    self._caller_args.noise_std = self.args.noise_std
+        else:
+            self.exp_avg.zero_(), self.exp_avg_sq.zero_()
+            self.adam_state[0] = float(self.n_steps)
+        self.adam_state.view(torch.int32)[3] = 0  # (the arrival counter of the tick / tail launches)
+        self._sched_host = None
+        self._apply_schedule()
+        for m in self.state.modules:  # the packed weight streams follow at the next step (version check / repack)
+            if hasattr(m, "mark_weights_changed"):
+                m.mark_weights_changed()
 
     def _gather_from_banks(self):
         """(inside the captured step) every bank gathers its next batch into the static inputs and moves its device cursor on"""

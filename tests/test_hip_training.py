@@ -556,3 +556,49 @@ def test_fused_tail_adam_matches_tail_then_adam(monkeypatch):
         assert torch.equal(a[mlp], b[mlp])
         assert maxnorm_rel(a[late].cpu(), b[late].cpu()) < 1e-5
     assert maxnorm_rel(out[0][2][0].cpu(), out[1][2][0].cpu()) < 2e-3
+
+
+def test_resume_from_checkpoint_continues_the_saved_run(tmp_path):
+    """Trainer.save_ckpt / load_ckpt (main.py:241-251 ModelCheckpoint + resume_from_checkpoint): a fresh trainer that loads the checkpoint takes
+    the steps the saved run goes on to take -- same weights, moments, schedule position, device-side step (Adam's bias corrections, the key
+    of the in-kernel jitter) -- so after three more steps on the same batches the weight-gradient parameters agree bit for bit; and
+    checkpoint.load_ckpt reads the same file into an evaluation model by Lightning's key prefixes."""
+    from satnerf_amd.checkpoint import load_ckpt
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    batches = []
+    for k in range(6):
+        rays, ts = O.synthetic_rays(128, seed=300 + k)
+        batches.append((rays.to(DEV), ts.to(DEV), torch.rand(128, 3, generator=torch.Generator().manual_seed(400 + k)).to(DEV)))
+    args = O.default_args(mlp_mode="bf16")
+
+    def make(seed):
+        torch.manual_seed(seed)
+        return Trainer({"coarse": load_model(args).to(DEV), "t": torch.nn.Embedding(30, 4).to(DEV)}, args, steps_per_epoch=2)
+
+    tr = make(0)
+    for b in batches[:3]:
+        tr.step(*b, validate=False)
+    path = str(tmp_path / "epoch=1.ckpt")
+    tr.save_ckpt(path)
+    epoch3 = tr.current_epoch()
+    for b in batches[3:]:
+        la = tr.step(*b, validate=False).item()
+    torch.cuda.synchronize()
+
+    tr2 = make(123)  # other initial weights, other jitter seed: everything must come from the file
+    tr2.load_ckpt(path)
+    assert tr2.n_steps == 3 and tr2.current_epoch() == epoch3 and abs(tr2.lr - tr.lr0 * 0.9) < 1e-12 and tr2.adam_state[0].item() == 3.0
+    for b in batches[3:]:
+        lb = tr2.step(*b, validate=False).item()
+    torch.cuda.synchronize()
+    late = tr._late_idx.long()
+    mlp = torch.ones(tr.state.params.numel(), dtype=torch.bool, device=DEV)
+    mlp[late] = False
+    # (the sky head and the embedding rows take their gradients by float atomics: equal to rounding, and they feed the later steps)
+    assert maxnorm_rel(tr2.state.params[mlp].cpu(), tr.state.params[mlp].cpu()) < 2e-3
+    assert abs(la - lb) < 1e-4 * abs(la) and tr2.n_steps == tr.n_steps == 6
+    ev = load_model(args).to(DEV)
+    load_ckpt(ev, path, model_name="nerf_coarse")
+    assert all(torch.isfinite(p_).all() for p_ in ev.parameters())
