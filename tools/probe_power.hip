@@ -1,16 +1,18 @@
 // Probe: what does each ingredient of the fused kernels cost IN ENERGY on a power-capped MI355X?  (r05)
 //
-// The training step runs at the 1400 W package limit (profiles/r04_power.txt): a kernel's time follows its energy, not its cycles, and
-// removing two small launches from the step moved nothing (profiles/r05_ab_fusion.txt).  This probe runs hand-placed streams of
-// v_mfma_f32_32x32x16 SUSTAINED (hundreds of back-to-back launches after a warm-up, random operands) and reports the wall time per MFMA
-// slot of a SIMD: every stream issues its MFMAs at the same ~32 cycles, so the wall-time ratio of two streams is their ratio of energy per
-// MFMA.  One wave per SIMD (256 threads) or two (512), one workgroup per CU.
+// The training step runs at the 1400 W package limit (profiles/r04_power.txt): a kernel that keeps the matrix pipe busy is clocked down until
+// its power fits, so its time follows its energy.  This probe runs hand-placed streams of v_mfma_f32_32x32x16 SUSTAINED (hundreds of
+// back-to-back launches after a warm-up) on all-zero operands (what the stream's CYCLES cost at the un-throttled clock) and on random ones
+// (what its ENERGY costs) and reports the wall time per MFMA slot of a SIMD.  One wave per SIMD (256 threads) or two (512), one workgroup per CU.
 //   bf16 / f16        : MFMAs only, A / B fragments resident in registers (4 accumulators round robin)
-//   zero              : the same on all-zero operands (the un-throttled reference)
-//   lds1 / lds2       : the A fragment of every MFMA / of every second MFMA read from LDS (ds_read_b128, 4 reads ahead): 32 vs 64 points
-//                       per wave and weight fragment
-//   sin, perm4, pk4   : bf16 + 1 v_sin_f32 / 4 v_perm_b32 / 4 v_pk_mul_f32 per MFMA gap (epilogue-like fillers)
-//   dma               : lds1 + the forward's LDS-DMA refill (every wave re-loads 1 KiB of the ring per 8 MFMAs from a 1.4-MB L2-resident stream)
+//   lds1 / lds2       : the A fragment of every MFMA / of every second MFMA read from LDS (ds_read_b128, six / three reads ahead): 32 vs 64
+//                       points per wave and weight fragment
+//   dma               : lds1 + the forward's LDS-DMA refill (every wave re-loads 1 KiB of the ring per 8 MFMAs from an L2-resident stream)
+//   sin, perm4, pk4   : bf16 + 1 v_sin_f32 / 4 v_perm_b32 / 4 v_pk_mul_f32 per MFMA gap
+//   hbm16 / hbm8      : bf16 + 1 KiB streamed from a 1-GiB buffer per wave and 16 / 8 MFMAs (3.6 / 6 TB/s chip-wide)
+//   fillers           : every VALU / LDS instruction class the kernels use, 2 and 4 copies behind every MFMA (which co-issue, which hold the
+//                       matrix pipe); the same under EXEC = 0; 4- vs 8-byte encodings at 6 / 8 / 10 per MFMA (instruction fetch)
+// Results: profiles/r05_probe_power.txt, read in DESIGN.md section 4.
 // hipcc --offload-arch=gfx950 -O3 tools/probe_power.hip -o /tmp/probe_power && /tmp/probe_power
 #include <hip/hip_runtime.h>
 #include <stdint.h>
