@@ -45,13 +45,23 @@ enum { kFwd = 0, kDx = 1, kDw = 2 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float w0) {
 #pragma clang fp contract(off)
+  // the hardware sine of the exact fraction, as the fused parity kernels (mlp_fwd.inc: 1.6e-6 of the reference end to end); SR_LINEAR_POLY_SIN:
+  // the degree-11 polynomial it replaces (r05: ~22 VALU instructions per staged element made the staging, not the MFMAs, this kernel's bound)
+#ifdef SR_LINEAR_POLY_SIN
   if (act == SR_ACT_SIN) return sin_rev_precise((w0 * v) * 0.15915494309189533577f);
+#else
+  if (act == SR_ACT_SIN) return sin_rev_fast(__builtin_amdgcn_fractf((w0 * v) * 0.15915494309189533577f));
+#endif
   if (act == SR_ACT_RELU) return v > 0.f ? v : 0.f;
   return v;
 }
 __device__ __forceinline__ float act_grad(float v, int act, float w0) {
 #pragma clang fp contract(off)
+#ifdef SR_LINEAR_POLY_SIN
   if (act == SR_ACT_SIN) return w0 * sin_rev_precise((w0 * v) * 0.15915494309189533577f + 0.25f);
+#else
+  if (act == SR_ACT_SIN) return w0 * __builtin_amdgcn_cosf(__builtin_amdgcn_fractf((w0 * v) * 0.15915494309189533577f));
+#endif
   if (act == SR_ACT_RELU) return v > 0.f ? 1.f : 0.f;
   return 1.f;
 }
