@@ -286,10 +286,11 @@ int sr_render_loss(const float* z_vals, const float* sigma, const float* noise, 
  * replays: [0] 1-based optimizer step (ticked by sr_pack_all), [1] learning rate (sr_adam_step_graph with lr < 0 reads it:
  * StepLR(gamma 0.9) per epoch, main.py:86-94 / train_utils.py:41-57), [2] != 0 while the SNerfLoss warm-up lasts (the colour loss
  * is then the plain MSE of metrics.SNerfLoss, main.py:128-131 -- no beta term, no beta gradient), [3] reserved.
- * sr_grad_tail = sr_unpack_grads + sr_sky_bwd + sr_embedding_bwd as three block ranges of one launch (training fast path);
+ * sr_grad_tail = sr_unpack_grads + sr_sky_bwd + sr_embedding_bwd as three block ranges of one launch (training fast path;
+ * n_blocks = rows of the planned job table `blocks`);
  * sr_adam_step_graph = sr_adam_step with the 1-based step count read from the device (state[0], advanced by sr_pack_all's
  * `tick` earlier in the same step) so the launch can be replayed from a hipGraph. */
-int sr_grad_tail(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, const int32_t* blocks,
+int sr_grad_tail(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, const int32_t* blocks, int n_blocks,
                  float* grad, int accumulate, const float* sun, int sun_stride, int64_t n_rays, int hidden,
                  const float* w1, const float* b1, const float* w2, const float* sky, const float* d_sky, float* g_w1, float* g_b1,
                  float* g_w2, float* g_b2, const float* d_t, const int64_t* ts, int n_samples, int tau, float* g_emb, void* stream);
@@ -311,7 +312,8 @@ typedef struct sr_pack_scatter {
   int64_t n_f16;
   float scales[4];
 } sr_pack_scatter;
-int sr_grad_tail_adam(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, const int32_t* blocks, float* grad,
+int sr_grad_tail_adam(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, const int32_t* blocks, int n_blocks,
+                      float* grad,
                       int accumulate, const float* sun, int sun_stride, int64_t n_rays, int hidden, const float* w1, const float* b1,
                       const float* w2, const float* sky, const float* d_sky, float* g_w1, float* g_b1, float* g_w2, float* g_b2,
                       const float* d_t, const int64_t* ts, int n_samples, int tau, float* g_emb, float* params, float* exp_avg,
@@ -319,6 +321,13 @@ int sr_grad_tail_adam(const float* partial, const int32_t* gidx, const float* gs
                       float grad_scale, const sr_pack_scatter* pack, void* stream);
 int sr_adam_step_graph(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                        float beta2, float eps, float grad_scale, float* state, int zero_grad, void* stream);
+/* sr_adam_step_graph that also re-packs (r06: the data-parallel step = the single-GPU step + one collective): Adam on all n elements of
+ * the flat buffers, and each of the first n_packed parameters (the coarse model's; `pack->map` holds n_packed x 2 words) written into its
+ * places of the weight streams as sr_grad_tail_adam does.  Sequence at N > 1: ... sr_grad_tail | all-reduce of `grads` | sr_adam_step_pack
+ * -- no sr_pack_all, no separate update launch.  pack may be NULL (n_packed 0): plain sr_adam_step_graph arithmetic. */
+int sr_adam_step_pack(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float grad_scale, float* state, int zero_grad, int64_t n_packed, const sr_pack_scatter* pack,
+                      void* stream);
 
 /* ---- layer-by-layer path for widths the fused kernel does not cover (fc_units != 256; opt.py:50 defaults to 512) ----
  * One nn.Linear of models/satnerf.py:104-153 per call, its input being the concatenation of one or two sources with the

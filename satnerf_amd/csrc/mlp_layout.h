@@ -189,33 +189,33 @@ constexpr int kWgTableInts = 12, kWgSlices = 9, kWgFirstSlice = 10;
 constexpr int kWgSpan = 11;  // (first row only) stream-K plans: tile units per workgroup of the 4-wave kernel; 0 = one slice per workgroup
 
 #ifdef __HIPCC__
-// sum over the slices of element k = block * kWgBlockFloats + offset
-__device__ __forceinline__ float wg_sum_slices(const float* __restrict__ partial, const int* __restrict__ blocks, int k) {
-  const int b = k / kWgBlockFloats, w = k - b * kWgBlockFloats;
-  const int ns = blocks[kWgTableInts * b + kWgSlices];
-  const float* p = partial + (long)blocks[kWgTableInts * b + kWgFirstSlice] * kWgBlockFloats + w;
-  // SR_TAIL_INFLIGHT independent loads in flight per thread (slices beyond ns are clamped to the last one and masked): with a plain
-  // loop every 295-KiB-strided load waited for the previous add and the reduction ran at 2.6 TB/s (23.6 us, PMC r02a); six in flight:
-  // 20.5 us; ten: 20.0 us
+// sum over the slices of element k = block * kWgBlockFloats + offset of a block with `ns` slices, the first at slice `first`.
+// All of a chunk's loads are issued before the first add (slices beyond ns are clamped to the last one and masked): with a plain loop
+// every 295-KiB-strided load waited for the previous add and the reduction ran at 2.6 TB/s (23.6 us, PMC r02a); ten in flight: 20.0 us;
+// r06: a whole block's slices (18-19 at width 256) in flight at once, the callers fetch everything that does not depend on the sum
+// (optimizer state, the block table) BEFORE it -- the tail launch was a chain of five dependent memory round trips per thread.
 #ifndef SR_TAIL_INFLIGHT
-#define SR_TAIL_INFLIGHT 10
+#define SR_TAIL_INFLIGHT 20
 #endif
+__device__ __forceinline__ float wg_sum_slices(const float* __restrict__ partial, int ns, int first, int w) {
+  const float* p = partial + (long)first * kWgBlockFloats + w;
   constexpr int NF = SR_TAIL_INFLIGHT;
-  float acc[NF];
-#pragma unroll
-  for (int i = 0; i < NF; ++i) acc[i] = 0.f;
+  float sum = 0.f;
   for (int sp = 0; sp < ns; sp += NF) {
+    float v[NF];
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
       const int sl = sp + i;
-      const float v = p[(long)(sl < ns ? sl : ns - 1) * kWgBlockFloats];
-      acc[i] += sl < ns ? v : 0.f;
+      v[i] = p[(long)(sl < ns ? sl : ns - 1) * kWgBlockFloats];
     }
-  }
-  float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < NF; ++i) sum += acc[i];
+    for (int i = 0; i < NF; ++i) sum += sp + i < ns ? v[i] : 0.f;
+  }
   return sum;
+}
+__device__ __forceinline__ float wg_sum_slices(const float* __restrict__ partial, const int* __restrict__ blocks, int k) {
+  const int b = k / kWgBlockFloats;
+  return wg_sum_slices(partial, blocks[kWgTableInts * b + kWgSlices], blocks[kWgTableInts * b + kWgFirstSlice], k - b * kWgBlockFloats);
 }
 #endif
 

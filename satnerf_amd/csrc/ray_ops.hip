@@ -533,7 +533,20 @@ struct GradTailParams {
   const float* d_sky; float* g_w1; float* g_b1; float* g_w2; float* g_b2;
   const float* d_t; const long long* ts; int S; int tau; float* g_emb;
   int blocks_unpack, blocks_sky, blocks_emb;
+  int n_blocks;  // rows of the job table `blocks`
 };
+// (n_slices, first_slice) of the job blocks in LDS: the split-K sums then need ONE dependent memory round trip (gidx -> the slices)
+// instead of two (gidx -> table row -> slices).  Tables beyond kTailTab rows are read from memory.
+constexpr int kTailTab = 256;
+__device__ __forceinline__ void tail_table_to_lds(int2* tab, const int* __restrict__ blocks, int n_blocks) {
+  if ((int)threadIdx.x < n_blocks && threadIdx.x < kTailTab)
+    tab[threadIdx.x] = int2{blocks[kWgTableInts * threadIdx.x + kWgSlices], blocks[kWgTableInts * threadIdx.x + kWgFirstSlice]};
+}
+__device__ __forceinline__ float tail_sum(const float* __restrict__ partial, const int2* tab, const int* __restrict__ blocks, int k) {
+  const int b = k / kWgBlockFloats;
+  const int2 t = b < kTailTab ? tab[b] : int2{blocks[kWgTableInts * b + kWgSlices], blocks[kWgTableInts * b + kWgFirstSlice]};
+  return wg_sum_slices(partial, t.x, t.y, k - b * kWgBlockFloats);
+}
 __global__ void __launch_bounds__(256) grad_tail_kernel(const GradTailParams q) {
   // the two small latency-bound ranges (atomics, one wave per ray) come FIRST in dispatch order so that they run under the cover
   // of the bandwidth-bound reduction instead of forming the kernel's tail
@@ -548,12 +561,17 @@ __global__ void __launch_bounds__(256) grad_tail_kernel(const GradTailParams q) 
     return;
   }
   b -= q.blocks_emb;
+  __shared__ int2 tab[kTailTab];
+  tail_table_to_lds(tab, q.blocks, q.n_blocks);
   const long i = (long)b * 256 + threadIdx.x;
-  if (i >= q.n_params) return;
-  const int k = q.gidx[i];
+  const bool in = i < q.n_params;
+  // everything that does not depend on the sum is requested before it
+  const int k = in ? q.gidx[i] : -1;
+  const float gs = in ? q.gscale[i] : 0.f;
+  const float g0 = in && q.accumulate ? q.grad[i] : 0.f;
+  __syncthreads();
   if (k < 0) return;
-  const float s = wg_sum_slices(q.partial, q.blocks, k) * q.gscale[i];
-  q.grad[i] = q.accumulate ? q.grad[i] + s : s;
+  q.grad[i] = g0 + tail_sum(q.partial, tab, q.blocks, k) * gs;
 }
 
 // ---- gradient tail + Adam in ONE launch (single-GPU captured step) -------------------------------------------------------------------
@@ -576,9 +594,8 @@ struct TailAdamParams {
 // `map` lists the parameter's (at most two) places -- the forward stream, the transposed stream of the dX kernel, or the fp32 fc_net.0
 // table -- as  position | scale index << 26 | (1 << 28 for the fp32 table),  -1 = none.  The arithmetic per element is sr_pack_all's
 // (src * scale, unfused; bf16 hi = RNE(v), lo = RNE(v - hi); the fp16 part of the stream saturates), so the streams hold the same bits.
-__device__ __forceinline__ void pack_scatter_one(const sr_pack_scatter& k, long i, float p) {
+__device__ __forceinline__ void pack_scatter_words(const sr_pack_scatter& k, int2 w, float p) {  // w = the parameter's two map words
 #pragma clang fp contract(off)
-  const int2 w = reinterpret_cast<const int2*>(k.map)[i];
 #pragma unroll
   for (int o = 0; o < 2; ++o) {
     const int c = o == 0 ? w.x : w.y;
@@ -600,10 +617,12 @@ __global__ void __launch_bounds__(256) grad_tail_adam_kernel(const TailAdamParam
   const GradTailParams& q = a.q;
   __shared__ float bc[2];
   __shared__ int last;
+  __shared__ int2 tab[kTailTab];
   if (threadIdx.x == 0) {
     const float t = a.state[0];
     bc[0] = 1.0f - powf(a.b1, t), bc[1] = 1.0f - powf(a.b2, t);
   }
+  tail_table_to_lds(tab, q.blocks, q.n_blocks);
   __syncthreads();
   const float lr = a.lr < 0.f ? a.state[1] : a.lr;
   const float step_size = lr / bc[0], sqrt_bc2 = sqrtf(bc[1]);
@@ -612,14 +631,30 @@ __global__ void __launch_bounds__(256) grad_tail_adam_kernel(const TailAdamParam
   if (b < n_atomic) {
     if (b < q.blocks_sky) sky_bwd_body(b, q.sun, q.sun_stride, q.n_rays, q.hidden, q.w1, q.b1, q.w2, q.sky, q.d_sky, q.g_w1, q.g_b1, q.g_w2, q.g_b2);
     else embedding_bwd_body(b - q.blocks_sky, q.d_t, q.ts, q.n_rays, q.S, q.tau, q.g_emb);
-    // this block's atomics have been PERFORMED (acknowledged: vmcnt) before it checks in.  Deliberately not __threadfence(): an agent-scope
-    // release writes the XCD's whole L2 back (buffer_wbl2) -- 288 of them while the other blocks stream 18 MB of moments made this launch
-    // 64 us instead of 28.  Nothing but device-scope atomics (performed at the memory side, not in an XCD's L2) is published here, and
-    // the last block reads them back with device-scope atomic loads.
+    // Publishing this block's float atomics to the block that arrives last.  Two builds:
+    //  SR_TAIL_RELEASE = 1: what the HIP / LLVM memory model asks for -- after the workgroup barrier ONE thread arrives with an agent-scope
+    //    acq_rel fetch_add (release: the barrier makes the block's atomics happen-before it; acquire: the last arriver then reads everything
+    //    the earlier ones released), and the barrier behind it carries that to the block's other threads.
+    //  SR_TAIL_RELEASE = 0 (the r05 code): relaxed arrive behind `s_waitcnt vmcnt(0)`.  Rests on gfx950 behaviour, not on the model: agent-scope
+    //    float atomics are performed at the memory side (not in an XCD's L2) and vmcnt acknowledges them once performed, so a counter
+    //    increment issued afterwards cannot overtake them.  A per-THREAD agent-scope release (__threadfence) writes the XCD's whole L2
+    //    back (buffer_wbl2) 73 k times while the other blocks stream 18 MB of moments: 64 us instead of 28 (r05).
+#ifndef SR_TAIL_RELEASE
+#define SR_TAIL_RELEASE 1
+#endif
+#if SR_TAIL_RELEASE
+    __syncthreads();
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n_atomic - 1);
+    __syncthreads();
+#else
+#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "the relaxed arrive of grad_tail_adam_kernel relies on gfx950's memory-side atomics"
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) last = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n_atomic - 1);
     __syncthreads();
+#endif
     if (!last) return;
     for (int k = threadIdx.x; k < a.n_late; k += 256) {
       const int i = a.late[k];
@@ -632,16 +667,54 @@ __global__ void __launch_bounds__(256) grad_tail_adam_kernel(const TailAdamParam
   }
   b -= n_atomic;
   const long i = (long)b * 256 + threadIdx.x;
-  if (i >= q.n_params) return;
-  const int k = q.gidx[i];
-  if (k < 0) return;  // (no weight-gradient GEMM produces it: on the `late` list)
-  float g = wg_sum_slices(q.partial, q.blocks, k) * q.gscale[i];
-  if (q.accumulate) g += q.grad[i];  // what the solar-correction / depth-supervision passes of this step left
-  float p = a.p[i];
-  adam_one(p, g, a.m[i], a.v[i], step_size, a.b1, a.b2, a.eps, a.grad_scale, sqrt_bc2, 1);
-  a.p[i] = p;
+  const bool in = i < q.n_params;
+  // everything that does not depend on the split-K sum is requested before it: the launch used to be a chain of five dependent memory
+  // round trips per thread (gidx -> table row -> 10 slices -> 8 slices -> optimizer state), 74 % of its wave cycles parked (r05 PMC)
+  const int k = in ? q.gidx[i] : -1;  // (< 0: no weight-gradient GEMM produces it: on the `late` list)
+  const bool live = k >= 0;
+  const float gs = in ? q.gscale[i] : 0.f;
+  const float g0 = in && q.accumulate ? q.grad[i] : 0.f;  // what the solar-correction / depth-supervision passes of this step left
+  float p = in ? a.p[i] : 0.f, m = in ? a.m[i] : 0.f, v = in ? a.v[i] : 0.f;
+  int2 w = int2{-1, -1};
+  if (a.pack.map != nullptr && in) w = reinterpret_cast<const int2*>(a.pack.map)[i];
+  if (!live) return;
+  float g = g0 + tail_sum(q.partial, tab, q.blocks, k) * gs;
+  adam_one(p, g, m, v, step_size, a.b1, a.b2, a.eps, a.grad_scale, sqrt_bc2, 1);
+  a.p[i] = p, a.m[i] = m, a.v[i] = v;
   q.grad[i] = 0.f;
-  if (a.pack.map != nullptr) pack_scatter_one(a.pack, i, p);
+  if (a.pack.map != nullptr) pack_scatter_words(a.pack, w, p);
+}
+
+// ---- Adam + re-pack in ONE launch (data-parallel captured step, r06) ---------------------------------------------------------------------
+// With more than one rank the split-K reduction (sr_grad_tail) and the update are separated by the gradient all-reduce; the update launch
+// then does what the single-GPU tail does after its sums: torch.optim.Adam on every element of the flat buffers (adam_one), the gradient
+// slot zeroed, and each of the first n_packed parameters (the coarse model's) written into its places of the weight streams
+// (pack_scatter_words) -- the N > 1 step is the N = 1 step plus one collective, with no sr_pack_all and no separate Adam launch.
+struct AdamPackParams {
+  float* p; float* g; float* m; float* v; long n, n_packed;
+  const float* state;
+  float lr, b1, b2, eps, grad_scale;
+  int zero_grad;
+  sr_pack_scatter pack;
+};
+__global__ void __launch_bounds__(256) adam_pack_kernel(const AdamPackParams a) {
+  __shared__ float bc[2];
+  if (threadIdx.x == 0) {
+    const float t = a.state[0];
+    bc[0] = 1.0f - powf(a.b1, t), bc[1] = 1.0f - powf(a.b2, t);
+  }
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool in = i < a.n;
+  float p = in ? a.p[i] : 0.f, g = in ? a.g[i] : 0.f, m = in ? a.m[i] : 0.f, v = in ? a.v[i] : 0.f;
+  int2 w = int2{-1, -1};
+  if (in && i < a.n_packed) w = reinterpret_cast<const int2*>(a.pack.map)[i];
+  __syncthreads();
+  if (!in) return;
+  const float lr = a.lr < 0.f ? a.state[1] : a.lr;
+  adam_one(p, g, m, v, lr / bc[0], a.b1, a.b2, a.eps, a.grad_scale, sqrtf(bc[1]), a.zero_grad);
+  a.p[i] = p, a.m[i] = m, a.v[i] = v;
+  if (a.zero_grad) a.g[i] = 0.f;
+  if (i < a.n_packed) pack_scatter_words(a.pack, w, p);
 }
 
 }  // namespace sr
@@ -808,18 +881,19 @@ extern "C" int sr_sky_bwd(const float* sun, int sun_stride, int64_t n, int hidde
   return check_launch("sky_bwd_kernel");
 }
 
-extern "C" int sr_grad_tail(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, const int32_t* blocks,
+extern "C" int sr_grad_tail(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, const int32_t* blocks, int n_blocks,
                             float* grad, int accumulate, const float* sun, int sun_stride, int64_t n_rays, int hidden, const float* w1,
                             const float* b1, const float* w2, const float* sky, const float* d_sky, float* g_w1, float* g_b1, float* g_w2,
                             float* g_b2, const float* d_t, const int64_t* ts, int n_samples, int tau, float* g_emb, void* stream) {
   SR_REQUIRE(partial && gidx && gscale && blocks && grad && sun && w1 && b1 && w2 && sky && d_sky && g_w1 && g_b1 && g_w2 && g_b2 && d_t && ts && g_emb,
              "sr_grad_tail: null pointer");
+  SR_REQUIRE(n_blocks >= 1, "sr_grad_tail: n_blocks = %d", n_blocks);
   if (n_rays <= 0) return 0;
   GradTailParams q;
   q.partial = partial, q.gidx = gidx, q.gscale = gscale, q.n_params = n_params, q.blocks = blocks, q.grad = grad;
   q.accumulate = accumulate, q.sun = sun, q.sun_stride = sun_stride, q.n_rays = n_rays, q.hidden = hidden, q.w1 = w1, q.b1 = b1, q.w2 = w2;
   q.sky = sky, q.d_sky = d_sky, q.g_w1 = g_w1, q.g_b1 = g_b1, q.g_w2 = g_w2, q.g_b2 = g_b2, q.d_t = d_t, q.ts = (const long long*)ts;
-  q.S = n_samples, q.tau = tau, q.g_emb = g_emb;
+  q.S = n_samples, q.tau = tau, q.g_emb = g_emb, q.n_blocks = n_blocks;
   q.blocks_unpack = (int)((n_params + 255) / 256);
   q.blocks_sky = (int)((n_rays + kSkyRays - 1) / kSkyRays);
   q.blocks_emb = (int)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
@@ -827,7 +901,7 @@ extern "C" int sr_grad_tail(const float* partial, const int32_t* gidx, const flo
   return check_launch("grad_tail_kernel");
 }
 
-extern "C" int sr_grad_tail_adam(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, const int32_t* blocks,
+extern "C" int sr_grad_tail_adam(const float* partial, const int32_t* gidx, const float* gscale, int64_t n_params, const int32_t* blocks, int n_blocks,
                                  float* grad, int accumulate, const float* sun, int sun_stride, int64_t n_rays, int hidden, const float* w1,
                                  const float* b1, const float* w2, const float* sky, const float* d_sky, float* g_w1, float* g_b1, float* g_w2,
                                  float* g_b2, const float* d_t, const int64_t* ts, int n_samples, int tau, float* g_emb, float* params,
@@ -835,6 +909,7 @@ extern "C" int sr_grad_tail_adam(const float* partial, const int32_t* gidx, cons
                                  float beta2, float eps, float grad_scale, const sr_pack_scatter* pack, void* stream) {
   SR_REQUIRE(partial && gidx && gscale && blocks && grad && sun && w1 && b1 && w2 && sky && d_sky && g_w1 && g_b1 && g_w2 && g_b2 && d_t && ts && g_emb,
              "sr_grad_tail_adam: null pointer");
+  SR_REQUIRE(n_blocks >= 1, "sr_grad_tail_adam: n_blocks = %d", n_blocks);
   SR_REQUIRE(params && exp_avg && exp_avg_sq && state && (late_idx || n_late == 0) && n_late >= 0, "sr_grad_tail_adam: null optimizer pointer");
   if (n_rays <= 0) return 0;
   TailAdamParams a;
@@ -842,7 +917,7 @@ extern "C" int sr_grad_tail_adam(const float* partial, const int32_t* gidx, cons
   q.partial = partial, q.gidx = gidx, q.gscale = gscale, q.n_params = n_params, q.blocks = blocks, q.grad = grad;
   q.accumulate = accumulate, q.sun = sun, q.sun_stride = sun_stride, q.n_rays = n_rays, q.hidden = hidden, q.w1 = w1, q.b1 = b1, q.w2 = w2;
   q.sky = sky, q.d_sky = d_sky, q.g_w1 = g_w1, q.g_b1 = g_b1, q.g_w2 = g_w2, q.g_b2 = g_b2, q.d_t = d_t, q.ts = (const long long*)ts;
-  q.S = n_samples, q.tau = tau, q.g_emb = g_emb;
+  q.S = n_samples, q.tau = tau, q.g_emb = g_emb, q.n_blocks = n_blocks;
   q.blocks_unpack = (int)((n_params + 255) / 256);
   q.blocks_sky = (int)((n_rays + kSkyRays - 1) / kSkyRays);
   q.blocks_emb = (int)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
@@ -856,6 +931,23 @@ extern "C" int sr_grad_tail_adam(const float* partial, const int32_t* gidx, cons
   }
   hipLaunchKernelGGL(grad_tail_adam_kernel, dim3(q.blocks_unpack + q.blocks_sky + q.blocks_emb), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("grad_tail_adam_kernel");
+}
+
+extern "C" int sr_adam_step_pack(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                                 float eps, float grad_scale, float* state, int zero_grad, int64_t n_packed, const sr_pack_scatter* pack, void* stream) {
+  SR_REQUIRE(params && grads && exp_avg && exp_avg_sq && state, "sr_adam_step_pack: null pointer");
+  SR_REQUIRE(n_packed >= 0 && n_packed <= n, "sr_adam_step_pack: n_packed = %lld of %lld", (long long)n_packed, (long long)n);
+  if (n <= 0) return 0;
+  AdamPackParams a;
+  a.p = params, a.g = grads, a.m = exp_avg, a.v = exp_avg_sq, a.n = n, a.n_packed = 0, a.state = state;
+  a.lr = lr, a.b1 = beta1, a.b2 = beta2, a.eps = eps, a.grad_scale = grad_scale, a.zero_grad = zero_grad;
+  a.pack = sr_pack_scatter{};
+  if (pack != nullptr && pack->map != nullptr && n_packed > 0) {
+    SR_REQUIRE(pack->hi && pack->l0 && pack->n_f16 >= 0, "sr_adam_step_pack: pack needs the stream and the fc_net.0 table");
+    a.pack = *pack, a.n_packed = n_packed;
+  }
+  hipLaunchKernelGGL(adam_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("adam_pack_kernel");
 }
 
 extern "C" int sr_embedding_bwd(const float* d_t, const int64_t* ts, int64_t n_rays, int n_samples, int tau, float* g_emb, void* stream) {

@@ -284,8 +284,10 @@ extern "C" int sr_wgrad_plan(int32_t* blocks, int n_blocks, int64_t n_points, in
     // touches it, numbered in tile order.  SATNERF_WGRAD_STREAMK = 0 / 1 forces the choice (A/B).
     const long total = (long)n_blocks * n_tiles, span = (total + n_wg - 1) / n_wg;
     const long worst = q > 0 ? (n_tiles + q - 1) / q : n_tiles;
-    bool streamk = q > 0 && span >= 8 && worst * 100 > span * 103;
-    if (const char* e = getenv("SATNERF_WGRAD_STREAMK")) streamk = e[0] == '1' && span >= 1;
+    // ... and only where the 4-wave kernel will run it: workspaces it cannot address with 32-bit per-lane offsets (wgrad9_fits; <= 208
+    // 1-KiB units per tile at either width) fall back to the r02 kernel, which takes equal slices only
+    bool streamk = q > 0 && span >= 8 && worst * 100 > span * 103 && n_tiles * 208l * 1024l < (1l << 32);
+    if (const char* e = getenv("SATNERF_WGRAD_STREAMK")) streamk = e[0] == '1' && span >= 1 && n_tiles * 208l * 1024l < (1l << 32);
     if (streamk) {
       for (int b = 0; b < n_blocks; ++b) sl[b] = (int)((((long)(b + 1) * n_tiles - 1) / span) - (((long)b * n_tiles) / span) + 1);
       blocks[kWgSpan] = (int32_t)span;

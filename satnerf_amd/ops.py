@@ -644,7 +644,7 @@ def gather_setup(rays, rgbs, ts, idx, out, n_samples, w1, b1, w2, b2, z, sky_rgb
 def grad_tail(partial, plan, gidx, gscale, grad_flat, sun, w1, b1, w2, sky_rgb, d_sky, g_w1, g_b1, g_w2, g_b2, d_t, ts, n_rays,
               n_samples, tau, g_emb):
     sun, stride = _rows(sun, "sun", 3)
-    _lib.call("sr_grad_tail", _p(partial), _p(_chk(gidx, "gidx", torch.int32)), _p(_chk(gscale, "gscale")), gidx.numel(), _p(plan),
+    _lib.call("sr_grad_tail", _p(partial), _p(_chk(gidx, "gidx", torch.int32)), _p(_chk(gscale, "gscale")), gidx.numel(), _p(plan), plan.shape[0],
               _p(_chk(grad_flat, "grad_flat")), 1, _p(sun), stride, n_rays, w1.shape[0], _p(w1), _p(b1), _p(w2), _p(_chk(sky_rgb, "sky")),
               _p(_chk(d_sky, "d_sky")), _p(g_w1), _p(g_b1), _p(g_w2), _p(g_b2), _p(_chk(d_t, "d_t")), _p(_chk(ts, "ts", torch.int64)), n_samples, tau,
               _p(_chk(g_emb, "g_emb")), _stream())
@@ -662,12 +662,28 @@ def grad_tail_adam(partial, plan, gidx, gscale, grad_flat, sun, w1, b1, w2, sky_
             raise ValueError("pack map does not match the parameter count")
         ps = _lib.PackScatter(_p(_chk(pack["map"], "pack map", torch.int32)), _p(pack["hi"]), _p(pack["lo"]), _p(_chk(pack["l0"], "pack l0")),
                               int(pack["n_f16"]), (C.c_float * 4)(*[float(x) for x in pack["scales"]]))
-    _lib.call("sr_grad_tail_adam", _p(partial), _p(_chk(gidx, "gidx", torch.int32)), _p(_chk(gscale, "gscale")), gidx.numel(), _p(plan),
+    _lib.call("sr_grad_tail_adam", _p(partial), _p(_chk(gidx, "gidx", torch.int32)), _p(_chk(gscale, "gscale")), gidx.numel(), _p(plan), plan.shape[0],
               _p(_chk(grad_flat, "grad_flat")), 1, _p(sun), stride, n_rays, w1.shape[0], _p(w1), _p(b1), _p(w2), _p(_chk(sky_rgb, "sky")),
               _p(_chk(d_sky, "d_sky")), _p(g_w1), _p(g_b1), _p(g_w2), _p(g_b2), _p(_chk(d_t, "d_t")), _p(_chk(ts, "ts", torch.int64)), n_samples, tau,
               _p(_chk(g_emb, "g_emb")), _p(_chk(params, "params")), _p(_chk(exp_avg, "exp_avg")), _p(_chk(exp_avg_sq, "exp_avg_sq")),
               _p(_chk(late_idx, "late_idx", torch.int32)), late_idx.numel(), _p(_chk(state, "state")), float(lr), float(betas[0]), float(betas[1]),
               float(eps), float(grad_scale), C.byref(ps) if ps is not None else None, _stream())
+
+
+def _pack_scatter_struct(pack, n_model):
+    if pack["map"].shape != (n_model, 2):
+        raise ValueError("pack map does not match the parameter count")
+    return _lib.PackScatter(_p(_chk(pack["map"], "pack map", torch.int32)), _p(pack["hi"]), _p(pack["lo"]), _p(_chk(pack["l0"], "pack l0")),
+                            int(pack["n_f16"]), (C.c_float * 4)(*[float(x) for x in pack["scales"]]))
+
+
+def adam_step_pack(params, grads, exp_avg, exp_avg_sq, state, pack=None, lr=-1.0, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, zero_grad=True):
+    """``adam_step_graph`` that also writes the first ``pack['map'].shape[0]`` parameters (the coarse model's) into the weight streams
+    (sr_adam_step_pack): the update launch of a data-parallel step, issued after the gradient all-reduce."""
+    ps = _pack_scatter_struct(pack, pack["map"].shape[0]) if pack is not None else None
+    _lib.call("sr_adam_step_pack", _p(_chk(params, "params")), _p(_chk(grads, "grads")), _p(_chk(exp_avg, "exp_avg")), _p(_chk(exp_avg_sq, "exp_avg_sq")),
+              params.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), float(grad_scale), _p(_chk(state, "state")), int(zero_grad),
+              0 if pack is None else pack["map"].shape[0], C.byref(ps) if ps is not None else None, _stream())
 
 
 def adam_step_graph(params, grads, exp_avg, exp_avg_sq, state, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, zero_grad=True):

@@ -336,15 +336,29 @@ class Trainer:
             ops.grad_tail_adam(*tail, self.state.params, self.exp_avg, self.exp_avg_sq, self._late_idx, self.adam_state, lr=-1.0,
                                grad_scale=1.0 / self.world, pack=model.pack_scatter(mode) if pit else None)
             return loss
-        if pit:
-            raise RuntimeError("pack-in-tail steps end in sr_grad_tail_adam")
+        if pit and not self._collective:
+            raise RuntimeError("single-GPU pack-in-tail steps end in sr_grad_tail_adam")
+        # data parallel (r06): the N > 1 step is the N = 1 step split at the collective -- sr_grad_tail (the reduction) | all-reduce of the flat
+        # gradient | sr_adam_step_pack (Adam + the re-pack of the weight streams, `_update_and_pack`): no sr_pack_all, no separate Adam launch
         ops.grad_tail(*tail)
         if self._adam_in_graph:  # the update rides in the same graph (the RCCL all-reduce captured with it, or the A/B switch above)
             if self._collective:
                 dist.all_reduce(self.state.grads, op=dist.ReduceOp.SUM)
-            ops.adam_step_graph(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.adam_state, lr=-1.0,
-                                grad_scale=1.0 / self.world, zero_grad=True)
+            if pit:
+                self._update_and_pack()
+            else:
+                ops.adam_step_graph(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.adam_state, lr=-1.0,
+                                    grad_scale=1.0 / self.world, zero_grad=True)
         return loss
+
+    def _update_and_pack(self):
+        """(data-parallel pack-in-tail steps, after the all-reduce) Adam over the flat buffers with the device-side step count / rate, each
+        coarse-model parameter written into the weight streams by the same launch."""
+        from . import ops
+        from .rendering import _mode_of
+
+        ops.adam_step_pack(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.adam_state,
+                           pack=self.models["coarse"].pack_scatter(_mode_of(self.args)), lr=-1.0, grad_scale=1.0 / self.world, zero_grad=True)
 
     def _fused_forward(self):
         """True when the colour pass's forward is ONE launch (sr_satnerf_render_train): 8-bit saved state, <= 64 samples dividing a
@@ -478,8 +492,11 @@ class Trainer:
         """Resume (main.py:251 ``resume_from_checkpoint``): restore what ``save_ckpt`` wrote -- weights by Lightning's key prefixes, the
         Adam moments, the step count (host side: schedule; device side: bias corrections and the jitter stream of captured steps) -- so that
         the next step is the one the saved run would have taken.  A checkpoint without an ``optimizer`` entry (a reference ``epoch=N.ckpt``:
-        Lightning keeps its optimizer state under other keys) restores the weights and the step count only; the moments restart at zero."""
-        ck = torch.load(path, map_location="cpu")
+        Lightning keeps its optimizer state under other keys) restores the weights and the step count only; the moments restart at zero.
+        NOT part of a checkpoint: the data position (a RayBank's epoch permutation and cursor) -- as in the reference, whose resumed
+        DataLoader reshuffles; "the step the saved run would have taken" therefore holds for batches the caller supplies."""
+        # weights_only=False as in checkpoint.load_ckpt: a Lightning checkpoint pickles its hparams Namespace and callback states
+        ck = torch.load(path, map_location="cpu", weights_only=False)
         sd = ck["state_dict"]
         for prefix, key in (("nerf_coarse.", "coarse"), ("nerf_fine.", "fine"), ("embedding_t.", "t")):
             if key in self.models and not (self._snerf and key == "t"):
@@ -552,10 +569,12 @@ class Trainer:
                               and dist.get_backend() == "nccl" and not getattr(self, "_collective_capture_failed", False))
         self._adam_in_graph = (not self._collective) or capture_collective
         self._kernel_rng = float(self.args.noise_std) == 0.0  # (a noisy step still draws randn from torch's generator)
-        # single GPU: the tail applies Adam and re-packs the weight streams, the forward opens the step (no sr_pack_all launch)
-        self._pack_in_tail = (self._adam_in_graph and not self._collective and self._late_idx is not None and self._kernel_rng
-                              and self._fused_forward() and os.environ.get("SATNERF_TAIL_ADAM", "1") != "0"
-                              and os.environ.get("SATNERF_TAIL_PACK", "1") != "0")
+        # the launch that updates the parameters re-packs the weight streams and the forward opens the step (no sr_pack_all launch): on a
+        # single GPU that launch is the gradient tail (sr_grad_tail_adam), with a collective it is sr_adam_step_pack behind the all-reduce
+        # (in the graph when the collective is captured, eagerly after the replay otherwise).  SATNERF_DP_PACK=0: the r05 N > 1 step (A/B)
+        self._pack_in_tail = (self._late_idx is not None and self._kernel_rng and self._fused_forward()
+                              and os.environ.get("SATNERF_TAIL_ADAM", "1") != "0" and os.environ.get("SATNERF_TAIL_PACK", "1") != "0"
+                              and (not self._collective or os.environ.get("SATNERF_DP_PACK", "1") != "0"))
         if self._pack_in_tail:
             self._repack_static()
         snapshot = (self.state.params.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.adam_state.clone())
@@ -661,10 +680,10 @@ class Trainer:
         banks = (bank,) + ((depth_bank,) if depth_bank is not None else ())
         if (self.direct and self.use_graph and float(self.args.noise_std) == 0.0 and all(b.drop_last for b in banks)
                 and os.environ.get("SATNERF_GRAPH_SAMPLER", "1" if self._sampler_in_forward(banks) else "0") == "1"):
-            # opt-in: the captured step samples for itself -- its first launches gather the banks' next batches (device cursors over
-            # the epoch's shuffled indices), so a step is ONE graph replay with no eager launch and no host-side index arithmetic.
-            # Off by default: on MI355X it is exactly as fast as the eager gather in front of the replay (0.420-0.425 ms per step
-            # either way; the launch gap between two replays equals the gap between a replay and an eager launch)
+            # the captured step samples for itself (device cursors over the epoch's shuffled indices): a step is ONE graph replay with no
+            # eager launch and no host-side index arithmetic.  ON by default when the forward launch can do the sampling itself
+            # (_sampler_in_forward: r05, sr_satnerf_render_train's gather); otherwise opt-in (SATNERF_GRAPH_SAMPLER=1) -- as separate
+            # gather launches in the graph it is exactly as fast as the eager gather in front of the replay (r02: 0.420-0.425 ms either way)
             if self._graph is None or getattr(self, "_graph_banks", None) is None or tuple(map(id, self._graph_banks)) != tuple(map(id, banks)):
                 first = [b.gather(b.graph_source()[0][:b.batch_size]) for b in banks]
                 self._apply_schedule()
@@ -721,7 +740,7 @@ class Trainer:
                 loss = self._static_loss
             else:
                 inputs = tuple(t.contiguous() for t in inputs)
-                if self._pack_in_tail and self._adam_in_graph and self.models["coarse"].weights_version() != self._packed_version:
+                if self._pack_in_tail and self.models["coarse"].weights_version() != self._packed_version:
                     self._repack_static()
                 loss = self._forward_backward(*inputs[:3], depth=inputs[3:] or None)
             in_graph = self._adam_in_graph and self._graph is not None and self.use_graph and float(self.args.noise_std) == 0.0
@@ -729,8 +748,11 @@ class Trainer:
                 dist.all_reduce(self.state.grads, op=dist.ReduceOp.SUM)
             self.n_steps += 1
             if not in_graph and not self._adam_in_graph:  # (an eager direct step after a capture already stepped Adam)
-                ops.adam_step(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.n_steps, lr=self.lr,
-                              grad_scale=1.0 / self.world, zero_grad=True)
+                if self._pack_in_tail:  # the forward ticked the device-side step count; the update launch also re-packs the streams
+                    self._update_and_pack()
+                else:
+                    ops.adam_step(self.state.params, self.state.grads, self.exp_avg, self.exp_avg_sq, self.n_steps, lr=self.lr,
+                                  grad_scale=1.0 / self.world, zero_grad=True)
             loss = _LazyLoss(loss)
         else:
             from .rendering import render_rays
@@ -767,7 +789,7 @@ class Trainer:
         for m in self.state.modules:
             if hasattr(m, "mark_weights_changed"):
                 m.mark_weights_changed()
-        if self.direct and self._pack_in_tail and self._adam_in_graph:  # ... and the step's last launch re-packed the streams
+        if self.direct and self._pack_in_tail:  # ... and the step's update launch re-packed the streams
             from .rendering import _mode_of
 
             self.models["coarse"].note_packed(_mode_of(self.args))

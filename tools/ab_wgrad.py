@@ -10,9 +10,9 @@ blocks = torch.from_numpy(maps["blocks"]).to(dev).contiguous()
 if os.environ.get("AB_BLOCKS"):  # e.g. AB_BLOCKS=14 or 1,2,3: time a sub-table
     blocks = blocks[[int(b) for b in os.environ["AB_BLOCKS"].split(",")]].contiguous()
 tiles = (n_points + 31) // 32
-act_e = _lib.lib().sr_act_elems_per_tile(256); dp_e = _lib.lib().sr_dpre_elems_per_tile(256)
+act_e = _lib.lib().sr_act_elems_per_tile(256, 16); dp_e = _lib.lib().sr_dpre_elems_per_tile(256, 16)
 acts = torch.randint(0, 30000, (tiles * act_e,), dtype=torch.int16, device=dev)
-dpre = torch.randint(0, 30000, (tiles * dp_e,), dtype=torch.int16, device=dev)
+dpre = torch.randint(0, 30000, (_lib.lib().sr_dpre_workspace_elems(n_points, 256, 16),), dtype=torch.int16, device=dev)  # (the 16-bit kernel reads no table behind it)
 n_wgs = [int(a) for a in sys.argv[2:]] or [0]
 def make(n_wg):
     plan, n_slices, span = ops.wgrad_plan(blocks, n_points, n_wg)

@@ -13,7 +13,11 @@ tiles = (n_points + 31) // 32
 act_e = _lib.lib().sr_act_elems_per_tile(256, 8); dp_e = _lib.lib().sr_dpre_elems_per_tile(256, 8)
 loads = torch.from_numpy(packing.wgrad8_loads(256, 4)).to(dev).contiguous()
 acts = torch.randint(0, 30000, (tiles * act_e,), dtype=torch.int16, device=dev)
-dpre = torch.randint(0, 30000, (tiles * dp_e,), dtype=torch.int16, device=dev)
+# the whole dpre workspace INCLUDING the table of exponent maxima the 4-wave kernel reads behind the last tile (sr_dpre_workspace_elems;
+# tiles * sr_dpre_elems_per_tile is too short and the scales were read out of bounds); the table gets plausible exponent bytes
+ws_tiles = _lib.lib().sr_workspace_tiles(n_points)
+dpre = torch.randint(0, 30000, (_lib.lib().sr_dpre_workspace_elems(n_points, 256, 8),), dtype=torch.int16, device=dev)
+dpre[ws_tiles * dp_e:].view(torch.uint8).fill_(120)
 n_wgs = [int(a) for a in sys.argv[2:]] or [0]
 dbg = None
 if os.environ.get("AB_TIMING"):  # kernel built with -DSR_W8_TIMING: per-wave s_memtime stamps of workgroup 0
