@@ -136,16 +136,31 @@ def _cpu_pass(phase, n, n_samples):
     return one
 
 
-def cpu_baseline(phase, n_rays, n_samples, budget_s=14.0):
-    """The oracle (port of the reference's CPU PyTorch path) on this box's host cores: the WHOLE batch of the workload (1024 rays), the
-    intra-op pool size swept over 16 .. 128 threads (the physical-core counts of the pool's hosts included) and the best one timed for a
-    bounded ~14 s.  torch's pool does not scale to the host's 256 hardware threads on these 5120 x 256 operators (r04 measured 2.6 rays/s
-    there: one pass takes ~100 s), so that setting is not run; `sweep` lists what was."""
+def _cpu_worker(phase, n, n_samples, threads, budget_s):
+    """child process of cpu_baseline's sharded leg: passes over its n rays with `threads` intra-op threads for ~budget_s; prints passes, seconds"""
+    torch.set_num_threads(threads)
+    one = _cpu_pass(phase, n, n_samples)
+    one()
+    t0, it = time.time(), 0
+    while time.time() - t0 < budget_s and it < 200:
+        one()
+        it += 1
+    print(json.dumps({"passes": it, "seconds": time.time() - t0, "rays": n}))
+
+
+def cpu_baseline(phase, n_rays, n_samples, budget_s=10.0):
+    """The oracle (port of the reference's CPU PyTorch path) on this box's host cores, the workload's 1024-ray batch, two ways:
+    (a) ONE process, torch's intra-op pool swept over 16 / 32 / 64 threads -- the pool does not scale on these 5120 x 256 operators (r04:
+    2.6 rays/s at 256 threads), so the best setting uses 16 of the host's threads;  (b) r06: the batch SHARDED over host_cpus / 16
+    processes of 16 threads each (every process renders and back-propagates its slice of the rays, started together) -- all of the host's
+    hardware threads at work on one batch.  `value` is the better of the two; both are reported."""
+    import subprocess
+
     cores = os.cpu_count() or 1
     n = n_rays
     one = _cpu_pass(phase, n, n_samples)
     sweep = {}
-    for thr in sorted({min(cores, c) for c in (16, 32, 64, 128)}):
+    for thr in sorted({min(cores, c) for c in (16, 32, 64)}):
         torch.set_num_threads(thr)
         one()
         t0 = time.time()
@@ -154,16 +169,43 @@ def cpu_baseline(phase, n_rays, n_samples, budget_s=14.0):
     best_thr = max(sweep, key=sweep.get)
     torch.set_num_threads(best_thr)
     t0, it = time.time(), 0
-    while time.time() - t0 < budget_s and it < 50:
+    while time.time() - t0 < budget_s / 2 and it < 50:
         one()
         it += 1
-    dt = (time.time() - t0) / it
-    return {"value": n / dt, "unit": "rays/s", "cores": best_thr, "host_cpus": cores, "kind": "port",
-            "sample": f"{it} x {n} rays x {n_samples} samples, {phase}, torch {torch.__version__} CPU fp32",
-            "sweep_rays_per_s": {str(k): round(v, 1) for k, v in sweep.items()}}
+    single = n / ((time.time() - t0) / it)
+    out = {"value": single, "unit": "rays/s", "cores": best_thr, "host_cpus": cores, "kind": "port",
+           "sample": f"{it} x {n} rays x {n_samples} samples, {phase}, torch {torch.__version__} CPU fp32",
+           "single_process": {"value": single, "threads": best_thr, "sweep_rays_per_s": {str(k): round(v, 1) for k, v in sweep.items()}}}
+    # (b) the batch sharded over processes
+    per = 16 if cores >= 32 else max(cores // 2, 1)
+    procs = max(min(cores // per, n // 8), 1)
+    if procs > 1:
+        shard = n // procs
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", phase, str(shard), str(n_samples), str(per), str(budget_s)]
+        env = dict(os.environ, OMP_NUM_THREADS=str(per), MKL_NUM_THREADS=str(per), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        t0 = time.time()
+        kids = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(procs)]
+        rates = []
+        for k in kids:
+            try:
+                txt, _ = k.communicate(timeout=budget_s * 6 + 120)
+                r = json.loads(txt.strip().splitlines()[-1])
+                rates.append(r["rays"] * r["passes"] / r["seconds"])
+            except Exception:  # noqa: BLE001  (a baseline leg must not take the bench line down)
+                k.kill()
+        if len(rates) == procs:
+            sharded = sum(rates)
+            out["sharded"] = {"value": sharded, "processes": procs, "threads_per_process": per, "rays_per_process": shard,
+                              "wall_s": round(time.time() - t0, 1)}
+            if sharded > single:
+                out.update(value=sharded, cores=procs * per,
+                           sample=f"{procs} processes x {per} threads, each {shard} of the batch's {n} rays x {n_samples} samples, {phase}, "
+                                  f"~{budget_s:.0f} s, torch {torch.__version__} CPU fp32")
+    return out
 
 
-def measure(phase, mode, n_rays, n_samples, steps, warmup, world, rank, dev, want_kernels=True, bwd_fmt=None, fc_units=None):
+def measure(phase, mode, n_rays, n_samples, steps, warmup, world, rank, dev, want_kernels=True, bwd_fmt=None, fc_units=None, sc_lambda=0.0,
+            ds_lambda=0.0):
     """Run one phase in one numeric mode: returns (seconds for `steps` steps on this rank, {kernel: mean ms} from the eager leg)."""
     from satnerf_amd import ops, rendering
     from satnerf_amd import train as train_mod
@@ -175,6 +217,8 @@ def measure(phase, mode, n_rays, n_samples, steps, warmup, world, rank, dev, wan
         args.bwd_fmt = bwd_fmt
     if fc_units is not None:
         args.fc_units = fc_units
+    # the two other sat-nerf lines of run_all.sh: solar correction (--sc_lambda 0.1, :56-62) and depth supervision (--ds_lambda 1000, :76-83)
+    args.sc_lambda, args.ds_lambda = float(sc_lambda), float(ds_lambda)
     torch.manual_seed(0)  # identical init on every rank
     model = load_model(args).to(dev)
     emb = torch.nn.Embedding(args.t_embbeding_vocab, args.t_embbeding_tau).to(dev)
@@ -195,8 +239,18 @@ def measure(phase, mode, n_rays, n_samples, steps, warmup, world, rank, dev, wan
         stepper.n_steps = 2 * spe
         measure.schedule = {"steps_per_epoch": spe, "first_measured_step": stepper.n_steps, "warming_up": bool(stepper.warming_up())}
 
+        depth_bank = None
+        if ds_lambda > 0:  # main.py:103-109,134-141: a second shuffled loader of (ray, [target depth, weight]) items, one batch of it per step
+            from satnerf_amd.data import DepthBank
+
+            n_dbank = 1 << 18
+            d_rays, d_ts = synthetic_rays(n_dbank, seed=20240629)
+            gd = torch.Generator().manual_seed(8)
+            depths = torch.stack([0.2 + 0.5 * torch.rand(n_dbank, generator=gd), 0.5 + torch.rand(n_dbank, generator=gd)], 1)
+            depth_bank = DepthBank(d_rays.to(dev), depths.to(dev), d_ts.to(dev), n_rays, seed=12, rank=rank, world_size=world)
+
         def step():
-            stepper.step_from_bank(bank)
+            stepper.step_from_bank(bank, depth_bank)
     else:
         # one kernel per step: the render kernel walks this rank's share of the HBM-resident bank chunk by chunk (as
         # eval_satnerf.batched_inference walks an image) and draws the stratified jitter itself (Philox, per-rank seed)
@@ -417,6 +471,19 @@ def main():
             vdt, _, vfmt = measure("train", "bf16", a.rays, a.samples, n512, 0, 1, 0, dev, want_kernels=False, fc_units=512)
             out["train_width512"] = {"metric": f"training rays/sec at fc_units=512, mlp_mode=bf16, saved state {vfmt}-bit",
                                      "value": a.rays * n512 / vdt, "ms_per_step": vdt / n512 * 1e3, "steps": n512}
+            # ... and the two other configurations run_all.sh trains sat-nerf in, at that width: + solar correction (a second MLP pass
+            # along the sun rays, sigma and sun visibility only: forward + dX + dW again) and + depth supervision (a second batch of
+            # n rays rendered for depth, sigma gradient only).  passes = MLP passes (forward, dX or dW over one batch) per step
+            for key, kw, note in (("train_width512_sc", dict(sc_lambda=0.1), "sc_lambda=0.1 (run_all.sh:56-62)"),
+                                  ("train_width512_ds", dict(ds_lambda=1000.0), f"ds_lambda=1000 + {a.rays} depth rays per step (run_all.sh:76-83, main.py:134-141)")):
+                release_leg()
+                xdt, _, xfmt = measure("train", "bf16", a.rays, a.samples, n512, 0, 1, 0, dev, want_kernels=False, fc_units=512, **kw)
+                xms = xdt / n512 * 1e3
+                out[key] = {"metric": f"training rays/sec at fc_units=512, {note}, mlp_mode=bf16, saved state {xfmt}-bit",
+                            "value": a.rays * n512 / xdt, "ms_per_step": xms, "steps": n512, "mlp_passes_per_step": 6,
+                            "algorithmic_flop_per_step": 6 * flop512, "step_frac": 6 * flop512 / (xms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS}
+            out["train_width512"].update(mlp_passes_per_step=3, algorithmic_flop_per_step=3 * flop512,
+                                         step_frac=3 * flop512 / (out["train_width512"]["ms_per_step"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS)
         if a.mode != "bf16x3":
             release_leg()
             qdt, qk, _ = measure("forward", "bf16x3", a.rays, a.samples, n_fwd, 0, 1, 0, dev)
@@ -433,4 +500,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        _cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6]))
+    else:
+        main()
