@@ -23,7 +23,134 @@ DEV = "cuda:0"
 # (r06 run recorded in DESIGN.md section 2 and, when the directory exists, in gpurun_out/benched_shape_errors.json); a tensor not
 # listed is held to DEFAULT_GATE.  Keys: (case, tensor name).
 DEFAULT_GATE = 3.0e-2
-GATES = {}
+GATES = {
+    # bf16/256/1024x64: measured max 1.60e-02, flat 2-norm 4.42e-03
+    ('bf16/256/1024x64', 'beta_from_xyz.0.bias'): 4.0e-03,  # measured 2.61e-03
+    ('bf16/256/1024x64', 'beta_from_xyz.0.weight'): 6.6e-03,  # measured 4.38e-03
+    ('bf16/256/1024x64', 'beta_from_xyz.2.bias'): 2.0e-04,  # measured 1.55e-05
+    ('bf16/256/1024x64', 'beta_from_xyz.2.weight'): 7.5e-03,  # measured 4.99e-03
+    ('bf16/256/1024x64', 'embedding_t.weight'): 2.4e-03,  # measured 1.60e-03
+    ('bf16/256/1024x64', 'fc_net.0.bias'): 2.5e-02,  # measured 1.60e-02
+    ('bf16/256/1024x64', 'fc_net.0.weight'): 8.7e-03,  # measured 5.74e-03
+    ('bf16/256/1024x64', 'fc_net.10.bias'): 5.6e-03,  # measured 3.69e-03
+    ('bf16/256/1024x64', 'fc_net.10.weight'): 7.6e-03,  # measured 5.06e-03
+    ('bf16/256/1024x64', 'fc_net.12.bias'): 4.7e-03,  # measured 3.09e-03
+    ('bf16/256/1024x64', 'fc_net.12.weight'): 8.2e-03,  # measured 5.46e-03
+    ('bf16/256/1024x64', 'fc_net.14.bias'): 3.5e-03,  # measured 2.27e-03
+    ('bf16/256/1024x64', 'fc_net.14.weight'): 8.7e-03,  # measured 5.75e-03
+    ('bf16/256/1024x64', 'fc_net.2.bias'): 8.3e-03,  # measured 5.52e-03
+    ('bf16/256/1024x64', 'fc_net.2.weight'): 1.2e-02,  # measured 7.41e-03
+    ('bf16/256/1024x64', 'fc_net.4.bias'): 8.7e-03,  # measured 5.78e-03
+    ('bf16/256/1024x64', 'fc_net.4.weight'): 1.7e-02,  # measured 1.12e-02
+    ('bf16/256/1024x64', 'fc_net.6.bias'): 8.6e-03,  # measured 5.72e-03
+    ('bf16/256/1024x64', 'fc_net.6.weight'): 1.2e-02,  # measured 7.62e-03
+    ('bf16/256/1024x64', 'fc_net.8.bias'): 6.1e-03,  # measured 4.06e-03
+    ('bf16/256/1024x64', 'fc_net.8.weight'): 8.4e-03,  # measured 5.58e-03
+    ('bf16/256/1024x64', 'feats_from_xyz.bias'): 3.2e-03,  # measured 2.12e-03
+    ('bf16/256/1024x64', 'feats_from_xyz.weight'): 8.8e-03,  # measured 5.81e-03
+    ('bf16/256/1024x64', 'rgb_from_xyzdir.0.bias'): 3.2e-03,  # measured 2.10e-03
+    ('bf16/256/1024x64', 'rgb_from_xyzdir.0.weight'): 8.4e-03,  # measured 5.57e-03
+    ('bf16/256/1024x64', 'rgb_from_xyzdir.2.bias'): 2.0e-04,  # measured 1.30e-04
+    ('bf16/256/1024x64', 'rgb_from_xyzdir.2.weight'): 1.2e-02,  # measured 7.87e-03
+    ('bf16/256/1024x64', 'sigma_from_xyz.0.bias'): 4.3e-03,  # measured 2.84e-03
+    ('bf16/256/1024x64', 'sigma_from_xyz.0.weight'): 9.4e-03,  # measured 6.23e-03
+    ('bf16/256/1024x64', 'sky_color.0.bias'): 3.7e-04,  # measured 2.44e-04
+    ('bf16/256/1024x64', 'sky_color.0.weight'): 3.8e-04,  # measured 2.52e-04
+    ('bf16/256/1024x64', 'sky_color.2.bias'): 6.5e-04,  # measured 4.29e-04
+    ('bf16/256/1024x64', 'sky_color.2.weight'): 6.6e-04,  # measured 4.34e-04
+    ('bf16/256/1024x64', 'sun_v_net.0.bias'): 5.1e-03,  # measured 3.36e-03
+    ('bf16/256/1024x64', 'sun_v_net.0.weight'): 5.1e-03,  # measured 3.38e-03
+    ('bf16/256/1024x64', 'sun_v_net.2.bias'): 3.4e-03,  # measured 2.22e-03
+    ('bf16/256/1024x64', 'sun_v_net.2.weight'): 2.4e-02,  # measured 1.54e-02
+    ('bf16/256/1024x64', 'sun_v_net.4.bias'): 3.8e-03,  # measured 2.53e-03
+    ('bf16/256/1024x64', 'sun_v_net.4.weight'): 9.2e-03,  # measured 6.07e-03
+    ('bf16/256/1024x64', 'sun_v_net.6.bias'): 2.5e-04,  # measured 1.61e-04
+    ('bf16/256/1024x64', 'sun_v_net.6.weight'): 5.7e-03,  # measured 3.75e-03
+    # bf16/512/1024x64: measured max 3.36e-02, flat 2-norm 5.00e-03
+    ('bf16/512/1024x64', 'beta_from_xyz.0.bias'): 4.4e-03,  # measured 2.89e-03
+    ('bf16/512/1024x64', 'beta_from_xyz.0.weight'): 4.6e-03,  # measured 3.01e-03
+    ('bf16/512/1024x64', 'beta_from_xyz.2.bias'): 2.0e-04,  # measured 3.41e-05
+    ('bf16/512/1024x64', 'beta_from_xyz.2.weight'): 6.9e-03,  # measured 4.58e-03
+    ('bf16/512/1024x64', 'embedding_t.weight'): 2.3e-03,  # measured 1.50e-03
+    ('bf16/512/1024x64', 'fc_net.0.bias'): 1.2e-02,  # measured 7.77e-03
+    ('bf16/512/1024x64', 'fc_net.0.weight'): 1.2e-02,  # measured 7.80e-03
+    ('bf16/512/1024x64', 'fc_net.10.bias'): 6.7e-03,  # measured 4.41e-03
+    ('bf16/512/1024x64', 'fc_net.10.weight'): 1.4e-02,  # measured 8.93e-03
+    ('bf16/512/1024x64', 'fc_net.12.bias'): 5.1e-03,  # measured 3.34e-03
+    ('bf16/512/1024x64', 'fc_net.12.weight'): 8.7e-03,  # measured 5.76e-03
+    ('bf16/512/1024x64', 'fc_net.14.bias'): 5.1e-03,  # measured 3.36e-03
+    ('bf16/512/1024x64', 'fc_net.14.weight'): 9.4e-03,  # measured 6.25e-03
+    ('bf16/512/1024x64', 'fc_net.2.bias'): 6.2e-03,  # measured 4.11e-03
+    ('bf16/512/1024x64', 'fc_net.2.weight'): 7.3e-03,  # measured 4.86e-03
+    ('bf16/512/1024x64', 'fc_net.4.bias'): 6.5e-03,  # measured 4.27e-03
+    ('bf16/512/1024x64', 'fc_net.4.weight'): 1.2e-02,  # measured 7.58e-03
+    ('bf16/512/1024x64', 'fc_net.6.bias'): 7.4e-03,  # measured 4.88e-03
+    ('bf16/512/1024x64', 'fc_net.6.weight'): 1.3e-02,  # measured 8.03e-03
+    ('bf16/512/1024x64', 'fc_net.8.bias'): 5.5e-03,  # measured 3.61e-03
+    ('bf16/512/1024x64', 'fc_net.8.weight'): 1.2e-02,  # measured 7.47e-03
+    ('bf16/512/1024x64', 'feats_from_xyz.bias'): 3.6e-03,  # measured 2.35e-03
+    ('bf16/512/1024x64', 'feats_from_xyz.weight'): 7.6e-03,  # measured 5.03e-03
+    ('bf16/512/1024x64', 'rgb_from_xyzdir.0.bias'): 2.9e-03,  # measured 1.88e-03
+    ('bf16/512/1024x64', 'rgb_from_xyzdir.0.weight'): 8.8e-03,  # measured 5.82e-03
+    ('bf16/512/1024x64', 'rgb_from_xyzdir.2.bias'): 5.9e-04,  # measured 3.88e-04
+    ('bf16/512/1024x64', 'rgb_from_xyzdir.2.weight'): 1.5e-02,  # measured 9.82e-03
+    ('bf16/512/1024x64', 'sigma_from_xyz.0.bias'): 6.4e-03,  # measured 4.26e-03
+    ('bf16/512/1024x64', 'sigma_from_xyz.0.weight'): 6.7e-03,  # measured 4.44e-03
+    ('bf16/512/1024x64', 'sky_color.0.bias'): 2.4e-04,  # measured 1.59e-04
+    ('bf16/512/1024x64', 'sky_color.0.weight'): 2.6e-04,  # measured 1.71e-04
+    ('bf16/512/1024x64', 'sky_color.2.bias'): 3.8e-04,  # measured 2.49e-04
+    ('bf16/512/1024x64', 'sky_color.2.weight'): 3.8e-04,  # measured 2.52e-04
+    ('bf16/512/1024x64', 'sun_v_net.0.bias'): 4.9e-03,  # measured 3.24e-03
+    ('bf16/512/1024x64', 'sun_v_net.0.weight'): 5.1e-03,  # measured 3.40e-03
+    ('bf16/512/1024x64', 'sun_v_net.2.bias'): 3.5e-03,  # measured 2.28e-03
+    ('bf16/512/1024x64', 'sun_v_net.2.weight'): 5.1e-02,  # measured 3.36e-02
+    ('bf16/512/1024x64', 'sun_v_net.4.bias'): 5.0e-03,  # measured 3.30e-03
+    ('bf16/512/1024x64', 'sun_v_net.4.weight'): 1.4e-02,  # measured 9.07e-03
+    ('bf16/512/1024x64', 'sun_v_net.6.bias'): 2.0e-04,  # measured 1.78e-05
+    ('bf16/512/1024x64', 'sun_v_net.6.weight'): 7.0e-03,  # measured 4.65e-03
+    # f16/256/1024x64: measured max 1.40e-02, flat 2-norm 3.68e-03
+    ('f16/256/1024x64', 'beta_from_xyz.0.bias'): 4.0e-03,  # measured 2.61e-03
+    ('f16/256/1024x64', 'beta_from_xyz.0.weight'): 7.0e-03,  # measured 4.62e-03
+    ('f16/256/1024x64', 'beta_from_xyz.2.bias'): 2.0e-04,  # measured 9.07e-06
+    ('f16/256/1024x64', 'beta_from_xyz.2.weight'): 6.0e-03,  # measured 3.95e-03
+    ('f16/256/1024x64', 'embedding_t.weight'): 2.6e-03,  # measured 1.67e-03
+    ('f16/256/1024x64', 'fc_net.0.bias'): 1.8e-02,  # measured 1.19e-02
+    ('f16/256/1024x64', 'fc_net.0.weight'): 7.9e-03,  # measured 5.26e-03
+    ('f16/256/1024x64', 'fc_net.10.bias'): 5.6e-03,  # measured 3.72e-03
+    ('f16/256/1024x64', 'fc_net.10.weight'): 7.3e-03,  # measured 4.86e-03
+    ('f16/256/1024x64', 'fc_net.12.bias'): 4.6e-03,  # measured 3.06e-03
+    ('f16/256/1024x64', 'fc_net.12.weight'): 6.6e-03,  # measured 4.34e-03
+    ('f16/256/1024x64', 'fc_net.14.bias'): 3.7e-03,  # measured 2.42e-03
+    ('f16/256/1024x64', 'fc_net.14.weight'): 4.6e-03,  # measured 3.02e-03
+    ('f16/256/1024x64', 'fc_net.2.bias'): 7.0e-03,  # measured 4.62e-03
+    ('f16/256/1024x64', 'fc_net.2.weight'): 1.0e-02,  # measured 6.63e-03
+    ('f16/256/1024x64', 'fc_net.4.bias'): 7.9e-03,  # measured 5.23e-03
+    ('f16/256/1024x64', 'fc_net.4.weight'): 1.4e-02,  # measured 9.09e-03
+    ('f16/256/1024x64', 'fc_net.6.bias'): 9.5e-03,  # measured 6.31e-03
+    ('f16/256/1024x64', 'fc_net.6.weight'): 9.8e-03,  # measured 6.52e-03
+    ('f16/256/1024x64', 'fc_net.8.bias'): 5.4e-03,  # measured 3.59e-03
+    ('f16/256/1024x64', 'fc_net.8.weight'): 7.0e-03,  # measured 4.61e-03
+    ('f16/256/1024x64', 'feats_from_xyz.bias'): 3.1e-03,  # measured 2.04e-03
+    ('f16/256/1024x64', 'feats_from_xyz.weight'): 4.1e-03,  # measured 2.71e-03
+    ('f16/256/1024x64', 'rgb_from_xyzdir.0.bias'): 3.4e-03,  # measured 2.25e-03
+    ('f16/256/1024x64', 'rgb_from_xyzdir.0.weight'): 4.2e-03,  # measured 2.74e-03
+    ('f16/256/1024x64', 'rgb_from_xyzdir.2.bias'): 2.5e-04,  # measured 1.61e-04
+    ('f16/256/1024x64', 'rgb_from_xyzdir.2.weight'): 1.8e-02,  # measured 1.18e-02
+    ('f16/256/1024x64', 'sigma_from_xyz.0.bias'): 3.1e-04,  # measured 2.06e-04
+    ('f16/256/1024x64', 'sigma_from_xyz.0.weight'): 1.5e-03,  # measured 9.71e-04
+    ('f16/256/1024x64', 'sky_color.0.bias'): 2.0e-04,  # measured 1.20e-04
+    ('f16/256/1024x64', 'sky_color.0.weight'): 2.0e-04,  # measured 1.20e-04
+    ('f16/256/1024x64', 'sky_color.2.bias'): 2.0e-04,  # measured 1.29e-04
+    ('f16/256/1024x64', 'sky_color.2.weight'): 2.0e-04,  # measured 1.28e-04
+    ('f16/256/1024x64', 'sun_v_net.0.bias'): 5.1e-03,  # measured 3.39e-03
+    ('f16/256/1024x64', 'sun_v_net.0.weight'): 5.2e-03,  # measured 3.40e-03
+    ('f16/256/1024x64', 'sun_v_net.2.bias'): 3.3e-03,  # measured 2.17e-03
+    ('f16/256/1024x64', 'sun_v_net.2.weight'): 2.1e-02,  # measured 1.40e-02
+    ('f16/256/1024x64', 'sun_v_net.4.bias'): 3.4e-03,  # measured 2.26e-03
+    ('f16/256/1024x64', 'sun_v_net.4.weight'): 7.7e-03,  # measured 5.12e-03
+    ('f16/256/1024x64', 'sun_v_net.6.bias'): 2.0e-04,  # measured 6.36e-05
+    ('f16/256/1024x64', 'sun_v_net.6.weight'): 3.6e-03,  # measured 2.39e-03
+}
 
 
 def _record(case, errs, rel2):

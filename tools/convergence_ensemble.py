@@ -1,0 +1,222 @@
+"""g1 as a statistical statement (VERDICT r05 Next #6): the DSM-level metric of an ENSEMBLE of trainings in the benchmarked arithmetic against
+an ensemble of fp32-reference trainings, every run on its own initialisation and its own stratified jitter.
+
+north_star: "DSM MAE on JAX_068 within 2 cm of the reference" (sat_utils.py:197-219 computes that MAE from a trained model's depths).  JAX_068
+is absent offline; the stand-in is tools/convergence.py's synthetic height-field scene (known surface, 19 tilted views, depth supervision as
+BASELINE configs[3]).  r04 / r05 compared SINGLE trajectories on identical jitter: the metric of one trajectory moves by several
+centimetres between checkpoints, so a single pair cannot support a 2-cm statement either way.  Here:
+
+  arm "hip": K trainings with the kernel-direct HIP Trainer (mlp_mode bf16, 8-bit saved state, fp16-operand weight gradients: bench.py's step)
+  arm "ref": K trainings with the fp32 oracle + torch.optim.Adam (the reference's arithmetic, on the GPU through torch)
+
+on ONE scene (the same ray banks, the same 2,048-ray evaluation set with fixed draws), run r seeded (arm, r): its own initial weights,
+embedding and per-step jitter -- nothing shared between runs but the data.  Per run the final metric is the MEAN of the altitude-like MAE
+against the true surface over the last three checkpoints (steps - 2 every, steps - every, steps; metres at a 175 m scene range).  Reported:
+both ensembles' means and standard deviations, the difference of means and its 95 % confidence interval (Welch: unequal variances,
+Welch-Satterthwaite degrees of freedom), and whether +-2 cm lies inside that interval.
+
+    python tools/convergence_ensemble.py run --arm hip --run 3 [--steps 20000] > gpurun_out/ens_hip_3.json      # one training
+    python tools/convergence_ensemble.py combine gpurun_out/ens_*.json > profiles/r06_convergence_ensemble.json
+    python tools/convergence_ensemble.py short --k 3 --steps 600                                                # what the -m gpu test gates
+
+The oracle is test infrastructure; this is a measurement tool, not a product path.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+import warnings
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools.convergence import SCENE_RANGE_M, make_scene  # noqa: E402
+
+SCENE_SEED = 0
+ARM_OFFSET = {"hip": 0, "ref": 500}  # run r of an arm is seeded ARM_OFFSET + r: no two runs of the study share a seed
+
+
+def _jitter(seed, k, batch):
+    g = torch.Generator().manual_seed(seed * 1000003 + k)
+    return torch.rand(batch, 64, generator=g), torch.rand(batch, 64, generator=g)
+
+
+# Student-t 97.5 % quantiles (two-sided 95 %) for the Welch interval; linear interpolation in 1 / df beyond the table
+_T975 = {1: 12.706, 2: 4.303, 3: 3.182, 4: 2.776, 5: 2.571, 6: 2.447, 7: 2.365, 8: 2.306, 9: 2.262, 10: 2.228, 12: 2.179, 14: 2.145, 16: 2.120,
+         20: 2.086, 25: 2.060, 30: 2.042, 40: 2.021, 60: 2.000, 120: 1.980}
+
+
+def t975(df):
+    if df <= 1:
+        return _T975[1]
+    keys = sorted(_T975)
+    if df >= keys[-1]:
+        return 1.960 + (_T975[keys[-1]] - 1.960) * keys[-1] / df
+    lo = max(k for k in keys if k <= df)
+    hi = min(k for k in keys if k >= df)
+    if lo == hi:
+        return _T975[lo]
+    w = (1.0 / df - 1.0 / hi) / (1.0 / lo - 1.0 / hi)
+    return _T975[hi] + w * (_T975[lo] - _T975[hi])
+
+
+def welch(a, b):
+    """difference of means a - b with its 95 % confidence interval (Welch's t, unequal variances)"""
+    na, nb = len(a), len(b)
+    ma, mb = sum(a) / na, sum(b) / nb
+    va = sum((x - ma) ** 2 for x in a) / (na - 1) if na > 1 else 0.0
+    vb = sum((x - mb) ** 2 for x in b) / (nb - 1) if nb > 1 else 0.0
+    se2 = va / na + vb / nb
+    if se2 <= 0:
+        return {"delta": ma - mb, "se": 0.0, "df": float(na + nb - 2), "ci95": [ma - mb, ma - mb]}
+    df = se2 ** 2 / ((va / na) ** 2 / max(na - 1, 1) + (vb / nb) ** 2 / max(nb - 1, 1))
+    h = t975(df) * math.sqrt(se2)
+    return {"delta": ma - mb, "se": math.sqrt(se2), "df": df, "ci95": [ma - mb - h, ma - mb + h]}
+
+
+def summarise(finals_hip, finals_ref, bar_m=0.02):
+    w = welch(finals_hip, finals_ref)
+    lo, hi = w["ci95"]
+    mean = lambda v: sum(v) / len(v)  # noqa: E731
+    sd = lambda v: math.sqrt(sum((x - mean(v)) ** 2 for x in v) / (len(v) - 1)) if len(v) > 1 else 0.0  # noqa: E731
+    return {"k_hip": len(finals_hip), "k_ref": len(finals_ref), "mean_hip_m": mean(finals_hip), "mean_ref_m": mean(finals_ref),
+            "sd_hip_m": sd(finals_hip), "sd_ref_m": sd(finals_ref), "delta_mean_m": w["delta"], "abs_delta_mean_m": abs(w["delta"]),
+            "se_m": w["se"], "welch_df": w["df"], "ci95_m": [lo, hi], "bar_m": bar_m,
+            # the three readings a reader may want: is a 2-cm difference excluded, is it established, or is the study too small to say
+            "ci_inside_bar": bool(-bar_m <= lo and hi <= bar_m), "ci_excludes_zero": bool(lo > 0 or hi < 0),
+            "bar_inside_ci": bool(lo <= -bar_m or hi >= bar_m)}
+
+
+def train_one(arm, run, steps, batch, bank_steps, n_eval, every, dev, verbose=True):
+    """one training of the scene; returns {checkpoint: MAE vs the true surface in metres}"""
+    from oracle import satnerf_oracle as O
+    from satnerf_amd import rendering
+    from satnerf_amd.models import load_model
+    from satnerf_amd.train import Trainer
+
+    ds_lambda = 1000.0
+    seed = ARM_OFFSET[arm] + run
+    cps = [c for c in (steps - 2 * every, steps - every, steps) if c > 0]
+    n_bank = bank_steps * batch
+    rays, ts, rgbs, _ = make_scene(n_bank, seed=SCENE_SEED + 1)
+    d_rays, d_ts, _, d_depth = make_scene(n_bank, seed=SCENE_SEED + 2)
+    depths = torch.stack([d_depth, torch.ones_like(d_depth)], 1)
+    data = tuple(t.to(dev) for t in (rays, ts, rgbs, d_rays, d_ts, depths))
+    ev_rays, ev_ts, _, ev_depth = make_scene(n_eval, seed=SCENE_SEED + 3)
+    gen = torch.Generator().manual_seed(SCENE_SEED + 4)
+    ev_u, ev_noise = torch.rand(n_eval, 64, generator=gen), torch.zeros(n_eval, 64)
+    ev = tuple(t.to(dev) for t in (ev_rays, ev_ts, ev_u, ev_noise))
+    torch.manual_seed(10_000 + seed)  # this run's own initialisation
+    init = {k: v.detach().clone() for k, v in load_model(O.default_args()).state_dict().items()}
+    emb_init = torch.nn.Embedding(30, 4).weight.detach().clone()
+    mae = lambda x: float((x - ev_depth).abs().mean()) * SCENE_RANGE_M  # noqa: E731
+    out, t0 = {}, time.time()
+    rays, ts, rgbs, d_rays, d_ts, depths = data
+    if arm == "ref":
+        args_ref = O.default_args(ds_lambda=ds_lambda)
+        po = {k: v.clone().to(dev).requires_grad_(True) for k, v in init.items()}
+        eo = emb_init.clone().to(dev).requires_grad_(True)
+        opt = torch.optim.Adam(list(po.values()) + [eo], lr=5e-4)
+        zeros = torch.zeros(batch, 64, device=dev)
+        for k in range(steps):
+            b = k % bank_steps
+            sl = slice(b * batch, (b + 1) * batch)
+            u_c, u_d = (u.to(dev) for u in _jitter(seed, k, batch))
+            mo = {"coarse": po, "t": eo}
+            l_c = O.satnerf_loss(O.render_rays(mo, args_ref, rays[sl], ts[sl], O.ReplayRng([u_c, zeros])), rgbs[sl])
+            l_d = O.depth_loss(O.render_rays(mo, args_ref, d_rays[sl], d_ts[sl], O.ReplayRng([u_d, zeros])), depths[sl, 0], depths[sl, 1], ds_lambda)
+            opt.zero_grad()
+            (l_c + l_d).backward()
+            opt.step()
+            if k + 1 in cps:
+                with torch.no_grad():
+                    d = O.render_rays({"coarse": {n: v.detach() for n, v in po.items()}, "t": eo.detach()}, args_ref, ev[0], ev[1],
+                                      O.ReplayRng([ev[2], ev[3]]))["depth_coarse"].cpu()
+                out[k + 1] = mae(d)
+                if verbose:
+                    print(f"ref run {run} step {k + 1}: MAE vs truth {out[k + 1]:.3f} m  ({time.time() - t0:.0f} s)", file=sys.stderr)
+    else:
+        args_hip = O.default_args(mlp_mode="bf16", ds_lambda=ds_lambda)
+        model = load_model(args_hip)
+        model.load_state_dict(init)
+        emb = torch.nn.Embedding(30, 4)
+        emb.load_state_dict({"weight": emb_init})
+        models = {"coarse": model.to(dev), "t": emb.to(dev)}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tr = Trainer(models, args_hip, use_graph=False)
+        queue = []
+        tr.jitter = lambda n, s, device: queue.pop(0).to(device)
+        out_bf16 = {}
+        for k in range(steps):
+            b = k % bank_steps
+            sl = slice(b * batch, (b + 1) * batch)
+            queue[:] = list(_jitter(seed, k, batch))
+            tr.step(rays[sl], ts[sl], rgbs[sl], depth=(d_rays[sl], d_ts[sl], depths[sl]), _inputs_in_place=True)
+            if k + 1 in cps:
+                # evaluated in the parity arithmetic (bf16x3): DSM extraction runs there, so the metric measures the TRAINING arithmetic
+                with torch.no_grad(), rendering.replay_rng([ev[2], ev[3], ev[2], ev[3]]):
+                    d = rendering.render_rays(models, O.default_args(mlp_mode="bf16x3"), ev[0], ev[1])["depth_coarse"].cpu()
+                    d16 = rendering.render_rays(models, O.default_args(mlp_mode="bf16"), ev[0], ev[1])["depth_coarse"].cpu()
+                out[k + 1], out_bf16[k + 1] = mae(d), mae(d16)  # (secondary: the same weights rendered in single-pass bf16)
+                if verbose:
+                    print(f"hip run {run} step {k + 1}: MAE vs truth {out[k + 1]:.3f} m  ({time.time() - t0:.0f} s)", file=sys.stderr)
+    res = {"arm": arm, "run": run, "seed": seed, "steps": steps, "batch": batch, "bank_steps": bank_steps, "checkpoints": {str(k): v for k, v in out.items()},
+           "final_m": sum(out.values()) / len(out), "seconds": time.time() - t0}
+    if arm == "hip":
+        res["final_bf16_inference_m"] = sum(out_bf16.values()) / len(out_bf16)
+    return res
+
+
+def short_study(k=3, steps=600, batch=256, n_eval=2048, dev=None):
+    """the statistic of the full study at a size a test can run: K runs per arm, `steps` steps, checkpoints every steps / 6"""
+    dev = dev or torch.device("cuda:0")
+    every = max(steps // 6, 1)
+    runs = {arm: [train_one(arm, r, steps, batch, min(steps, 2000), n_eval, every, dev, verbose=False) for r in range(k)] for arm in ("hip", "ref")}
+    s = summarise([r["final_m"] for r in runs["hip"]], [r["final_m"] for r in runs["ref"]])
+    s["runs"] = {arm: [r["final_m"] for r in runs[arm]] for arm in runs}
+    return s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    r = sub.add_parser("run")
+    r.add_argument("--arm", choices=["hip", "ref"], required=True)
+    r.add_argument("--run", type=int, required=True)
+    r.add_argument("--steps", type=int, default=20000)
+    r.add_argument("--batch", type=int, default=256)
+    r.add_argument("--bank-steps", type=int, default=2000)
+    r.add_argument("--eval", type=int, default=2048)
+    r.add_argument("--every", type=int, default=1000, help="spacing of the last three checkpoints")
+    c = sub.add_parser("combine")
+    c.add_argument("files", nargs="+")
+    s = sub.add_parser("short")
+    s.add_argument("--k", type=int, default=3)
+    s.add_argument("--steps", type=int, default=600)
+    a = ap.parse_args()
+    if a.cmd == "run":
+        print(json.dumps(train_one(a.arm, a.run, a.steps, a.batch, a.bank_steps, a.eval, a.every, torch.device("cuda:0"))))
+    elif a.cmd == "short":
+        print(json.dumps(short_study(a.k, a.steps)))
+    else:
+        runs = []
+        for f in a.files:
+            with open(f) as fh:
+                txt = fh.read().strip()
+            if txt:
+                runs.append(json.loads(txt.splitlines()[-1]))
+        hip = sorted((r for r in runs if r["arm"] == "hip"), key=lambda r: r["run"])
+        ref = sorted((r for r in runs if r["arm"] == "ref"), key=lambda r: r["run"])
+        doc = {"study": "ensemble of independent trainings: HIP bf16 / 8-bit state vs fp32 oracle, one synthetic scene, own init + jitter per run",
+               "metric": "altitude-like MAE vs the true surface, mean of the last three checkpoints, metres at a 175 m scene range",
+               "steps": hip[0]["steps"] if hip else None, "batch": hip[0]["batch"] if hip else None,
+               "summary": summarise([r["final_m"] for r in hip], [r["final_m"] for r in ref]),
+               "hip_runs": hip, "ref_runs": ref}
+        print(json.dumps(doc, indent=1))
+
+
+if __name__ == "__main__":
+    main()

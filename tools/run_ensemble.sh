@@ -1,0 +1,18 @@
+#!/bin/bash
+# tools/run_ensemble.sh [K] [steps]: the g1 ensemble study (tools/convergence_ensemble.py) on one GPU box -- K fp32-oracle trainings side by
+# side (they are host-bound: ~600 small torch launches per step), the K HIP trainings one after the other beside them; results under
+# gpurun_out/ens/, combined into gpurun_out/r06_convergence_ensemble.json.
+K=${1:-8}; STEPS=${2:-20000}
+mkdir -p gpurun_out/ens
+export PYTHONDONTWRITEBYTECODE=1 OMP_NUM_THREADS=8 MKL_NUM_THREADS=8
+pids=""
+for r in $(seq 0 $((K-1))); do
+  python tools/convergence_ensemble.py run --arm ref --run $r --steps $STEPS > gpurun_out/ens/ref_$r.json 2> gpurun_out/ens/ref_$r.err &
+  pids="$pids $!"
+done
+for r in $(seq 0 $((K-1))); do
+  python tools/convergence_ensemble.py run --arm hip --run $r --steps $STEPS > gpurun_out/ens/hip_$r.json 2> gpurun_out/ens/hip_$r.err
+done
+for p in $pids; do wait $p; done
+python tools/convergence_ensemble.py combine gpurun_out/ens/ref_*.json gpurun_out/ens/hip_*.json > gpurun_out/r06_convergence_ensemble.json
+python -c "import json; d=json.load(open('gpurun_out/r06_convergence_ensemble.json')); print(json.dumps(d['summary']))"
