@@ -236,7 +236,7 @@ int sr_satnerf_wgrad(int feat, int tau, int64_t n_points, const uint16_t* dpre, 
  * sine, MX8 -> fp16 value scaled per workgroup) and contracts 128 x 128 register tiles with fp16 MFMAs; SATNERF_WGRAD_V1=1 (and
  * workspaces of 4 GiB or more) run the r02 kernel, which expands the fragments in the LDS to bf16.  `loads` (n_blocks x
  * sr_wgrad8_load_ints() int32, device; packing.wgrad8_loads) says which unit of which workspace each wave of a block fetches and where
- * it goes -- ints 0..19 for the r02 kernel, 20..108 the duty table, the exponent groups of the row pairs and the quadrant mask of the default one
+ * it goes -- ints 0..19 for the r02 kernel, 20..112 the duty table, the exponent groups of the row pairs, the quadrant mask and the per-wave stream variants (r06: thin streams for one-row blocks) of the default one
  * (which reads the exponent maxima behind the dpre workspace: dpre must be the buffer sr_satnerf_mlp_bwd wrote, sr_dpre_workspace_elems long); `blocks` is
  * the same planned table.  sr_wgrad_plan hands the default kernel equal slices (it runs one instruction stream for every block) and the
  * r02 kernel cost-weighted ones.

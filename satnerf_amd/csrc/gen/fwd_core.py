@@ -437,6 +437,10 @@ class Core:
             drop |= {"waitl"}
         if "nonop" in ab:
             drop |= {"nop"}
+        if "nostore" in ab:   # (saving cores) the workspace stores and their address steps
+            drop |= {"store", "store2", "soff"}
+        if "noenc" in ab:     # (saving cores) the PHASE8 / MX8 encodes of the saved state
+            drop |= {"phase", "mx_max", "mx_e1", "mx_e2", "mx_e3a", "mx_e3", "mx_e4", "mx_e5", "mx_e6", "mx_q1", "mx_q2"}
         if "empty" in ab:
             return ["s_mov_b32 %[m0save], m0", "v_mov_b32 v208, 0"] + [f"v_mov_b32 v{HEAD + g}, 0" for g in range(16)]
         out = []
@@ -735,7 +739,7 @@ def main():
 
     ap = argparse.ArgumentParser(description=__doc__)
     ap.add_argument("--out", default=None, help="output directory (default: csrc/)")
-    ap.add_argument("--ablate", default="", help="comma list of timing ablations: nodma,nobarrier,nosync,noepi,noread,nowaitl,nonop")
+    ap.add_argument("--ablate", default="", help="comma list of timing ablations: nodma,nobarrier,nosync,noepi,noread,nowaitl,nonop,nostore,noenc")
     ap.add_argument("--R", type=int, default=128)
     ap.add_argument("--PF", type=int, default=5)
     ap.add_argument("--GROUP", type=int, default=2)

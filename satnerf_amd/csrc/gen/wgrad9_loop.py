@@ -82,14 +82,42 @@ def acc(a, c):
     return 16 * (4 * a + c)
 
 
+# Thin streams (r06): the job blocks whose row operand is ONE raw bf16 fragment (the head rows d_head, d_sigma_pre: one live 32-row pair) used
+# to run the full stream -- two dump row duties decoded at full price, 36 MFMAs on stale rows -- so a narrow block cost a workgroup what a
+# full 256 x 256 block costs.  A thin stream is the same slice loop with only what such a block needs: `n_df` column double fragments
+# (PHASE8, read from the activation workspace through duty slots 0 .. n_df - 1), optionally the raw fragment, and either the 5 MFMAs per
+# k-step of ONE row pair (A0 x B0..B3 + the aux tile) or none at all (a wave that only decodes for the others).  Same LDS image, same
+# publish / consume protocol, same registers.  THIN lists the variants wgrad9.hip compiles: (n_df, raw, mfma) -> file tag.
+THIN = {(1, True, "thin"): "t1", (3, False, "none"): "d3", (0, True, "thin"): "t0", (2, True, "none"): "r2", (2, False, "none"): "d2",
+        (0, False, "none"): "d0"}
+
+
 class Stream:
-    def __init__(self, col_codec, ablate=(), main=True):
+    def __init__(self, col_codec, ablate=(), main=True, thin=None):
         assert col_codec in ("phase", "mx")
         self.col_codec = col_codec
         self.main = main               # False: a wave whose quadrant nobody reads (narrow blocks): aux tiles only, same loads / decode / rendezvous
         self.ablate = set(ablate)      # timing experiments (wrong results): nomfma, noload, nodec, noread, nowrite, nobar
-        self.ns = 2 if col_codec == "phase" else 4     # scale-byte loads per tile
-        self.nld = 4 + self.ns + 1                     # global loads per tile and wave
+        self.thin = thin               # None, or (n_df, raw, mfma) of THIN
+        if thin is not None:
+            assert col_codec == "phase" and thin in THIN
+            self.n_df, self.raw, self.mfma_set = thin
+            self.duties = list(range(self.n_df))
+            self.ns = 0
+        else:
+            self.n_df, self.raw, self.mfma_set = 4, True, ("full" if main else "aux")
+            self.duties = [0, 2, 1, 3]                 # decode order: row, column, row, column
+            self.ns = 2 if col_codec == "phase" else 4     # scale-byte loads per tile
+        self.nld = self.n_df + self.ns + (1 if self.raw else 0)   # global loads per tile and wave
+        # the operands a k-step reads (in read order) and the MFMAs it issues at which of the 18 slots of the k-step
+        if self.mfma_set == "full":
+            self.rq = list(OPS)
+        elif self.mfma_set == "aux":
+            self.rq = ["A0", "A1", "X"]
+        elif self.mfma_set == "thin":
+            self.rq = ["B0", "A0", "B1", "B2", "B3", "X"]
+        else:
+            self.rq = []
         self.ins = []
         self.lgkm = []
         self.n = {}
@@ -158,13 +186,15 @@ class Stream:
         V = lambda text: it.append(lambda: self.e(text))                     # noqa: E731
         S = lambda text: it.append(lambda: self.e(text, "salu"))             # noqa: E731
         M = lambda text: it.append(lambda: self.e(text, "vmem"))             # noqa: E731
-        for d in range(4):
+        for d in range(self.n_df):
             r = STG + 16 * sset + 4 * d
-            M(f"global_load_dwordx4 v[{r}:{r + 3}], v{VOFF_D if d < 2 else VOFF_A}, %[b{d}]")
+            from_acts = d >= 2 or self.thin is not None   # (thin streams: every double fragment is a column duty)
+            M(f"global_load_dwordx4 v[{r}:{r + 3}], v{VOFF_A if from_acts else VOFF_D}, %[b{d}]")
         for d in range(self.ns):
             M(f"global_load_ubyte v{SCS + 4 * sset + d}, v{VOFF_D if d < 2 else VOFF_A}, %[sb{d}]")
-        r = RAWX + 4 * sset
-        M(f"global_load_dwordx4 v[{r}:{r + 3}], v{VOFF_X}, %[bx]")
+        if self.raw:
+            r = RAWX + 4 * sset
+            M(f"global_load_dwordx4 v[{r}:{r + 3}], v{VOFF_X}, %[bx]")
         S(f"s_cmp_lg_u32 {S_ADV}, 0")
         S(f"s_cselect_b32 {S_T0}, %[strd], 0")
         S(f"s_cselect_b32 {S_T1}, %[stra], 0")
@@ -179,7 +209,7 @@ class Stream:
     def decode_items(self, d, sset, slot):
         """D: double fragment d (0, 1 rows: MX8; 2, 3 columns: self.col_codec) of staging set `sset` -> two fp16 fragments in LDS slot
         `slot`.  Value n = byte n & 3 of raw dword n >> 2 -> output dword n >> 1 (codec8.h)."""
-        codec = "mx" if d < 2 else self.col_codec
+        codec = self.col_codec if (d >= 2 or self.thin is not None) else "mx"
         raw = STG + 16 * sset + 4 * d
         it = []
         V = lambda text: it.append(lambda: self.e(text, "dec"))              # noqa: E731
@@ -225,10 +255,13 @@ class Stream:
         return it
 
     def decode_tile(self, sset, slot):
-        it = [lambda: self.e(f"s_waitcnt vmcnt({3 * self.nld})", "wait")]    # only the three newest tiles may still be in flight
-        for d in (0, 2, 1, 3):
+        it = []
+        if self.nld:
+            it.append(lambda: self.e(f"s_waitcnt vmcnt({3 * self.nld})", "wait"))    # only the three newest tiles may still be in flight
+        for d in self.duties:
             it += self.decode_items(d, sset, slot)
-        it += self.rawcopy_items(sset, slot)
+        if self.raw:
+            it += self.rawcopy_items(sset, slot)
         return it
 
     def publish(self, slot):
@@ -277,6 +310,11 @@ class Stream:
         """one tile: L(i + 5), M(i) on slot s, rendezvous, D(i + 2), K0(i + 1)"""
         # the prefetched k-step-0 operands are now the current tile's
         self.lgkm = [("cur",) + t[1:] if t[0] == "nxt" else t for t in self.lgkm]
+        if s == 0 and not self.rq:
+            # a stream without operand reads has no wait at the top of the first body: over the back edge the fourth body's late writes
+            # are still in flight (the bookkeeping at the loop label is the prologue's: nothing) -- drain them before the publish below
+            self.e("s_waitcnt lgkmcnt(0)", "wait")
+            self.lgkm = []
         nslot = (s + 1) % 4
         def publish_prev():   # the previous iteration's decode (tile i + 1): its writes are older than anything issued since, long retired
             w = [t for t in self.lgkm if t[0] == "w"]
@@ -297,16 +335,16 @@ class Stream:
                     fi += 1
 
         for ks in range(2):
-            rq = list(OPS) if self.main else ["A0", "A1", "X"]
+            rq = list(self.rq)
             for idx in range(18):
                 if idx == 0:   # every operand of this k-step has landed (they were read one k-step ago): one wait instead of one per MFMA
                     self.wait_for(("cur", ks, "X", 1))
                     if ks == 1:  # the next tile is complete (all four waves) before its first operand is prefetched; tile i + 1 of the
                         self.consume_check(nslot, 4 if s < 3 else 8)  # fourth body belongs to the next trip
                 if idx < 16:
-                    if self.main:
+                    if self.mfma_set == "full" or (self.mfma_set == "thin" and order[idx][0] == 0):
                         self.mfma(ks, *order[idx])
-                else:
+                elif self.mfma_set in ("full", "aux") or (self.mfma_set == "thin" and idx == 16):
                     self.mfma_aux(ks, idx - 16)
                 if ks == 0 and idx == 12:   # the other waves published tile i + 1 some ten MFMAs ago: read its counter now, compare at the k-step's end
                     self.consume_fetch(nslot)
@@ -372,7 +410,7 @@ class Stream:
         e("s_waitcnt lgkmcnt(0)", "wait")   # (tile 1 is published by the first iteration, as every iteration publishes its predecessor's decode)
         self.lgkm = []
         e("s_barrier", "salu")
-        for name in (OPS if self.main else ("A0", "A1", "X")):
+        for name in self.rq:
             self.read_operand("nxt", 0, 0, name)
         # ---- the loop: four tiles per trip -------------------------------------------------------------------------------------
         # LDS-counter bookkeeping at the loop label: the first body is generated from the prologue's state (the 18 reads of K0(0) in
@@ -382,7 +420,7 @@ class Stream:
         e("1:", "label")
         self.in_loop = True
         for s in range(4):
-            if s == 0:
+            if s == 0 and self.rq:
                 assert self.lgkm and self.lgkm[-1][:3] == ("nxt", 0, "X"), self.lgkm[-3:]
             self.states.append(self.body(s))
             e("s_sub_u32 %[nt], %[nt], 1", "salu")
@@ -397,7 +435,8 @@ class Stream:
             e("s_nop 15", "salu")    # the last MFMAs' results -> the epilogue's v_accvgpr_read (inline asm is not hazard-padded)
 
     def inc_file(self):
-        head = [f"// GENERATED by csrc/gen/wgrad9_loop.py -- do not edit.  Column codec: {self.col_codec}; {len(self.ins)} lines: "
+        kind = "" if self.thin is None else f"thin stream {self.thin}; "
+        head = [f"// GENERATED by csrc/gen/wgrad9_loop.py -- do not edit.  {kind}Column codec: {self.col_codec}; {len(self.ins)} lines: "
                 + ", ".join(f"{v} {k}" for k, v in sorted(self.n.items()))]
         return "\n".join(head + ['"' + t + '\\n"' for t in self.ins]) + "\n"
 
@@ -417,6 +456,11 @@ def main():
     ablate = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ()
     for codec, tag in (("phase", "p"), ("mx", "m"), ("phase", "px"), ("mx", "mx")):
         s = Stream(codec, ablate=ablate, main=len(tag) == 1)
+        with open(os.path.join(out_dir, f"wgrad9_loop_{tag}{suffix}.inc"), "w") as f:
+            f.write(s.inc_file())
+        print(tag, s.n, len(s.ins), "LDS operations in flight at body ends:", [len(x) for x in s.states])
+    for thin, tag in THIN.items():
+        s = Stream("phase", ablate=ablate, thin=thin)
         with open(os.path.join(out_dir, f"wgrad9_loop_{tag}{suffix}.inc"), "w") as f:
             f.write(s.inc_file())
         print(tag, s.n, len(s.ins), "LDS operations in flight at body ends:", [len(x) for x in s.states])

@@ -270,7 +270,51 @@ extern "C" int sr_wgrad_plan(int32_t* blocks, int n_blocks, int64_t n_points, in
   static thread_local int sl[4096];
   const bool weighted = fmt == SR_FMT8 && n_blocks <= n_wg;
   blocks[kWgSpan] = 0;
-  if (weighted && !old_kernel) {
+  // r06: blocks whose row operand is one raw bf16 fragment (head rows: 1 row fragment, PHASE8 columns) run THIN streams in the 4-wave
+  // kernel (gen/wgrad9_loop.py THIN, packing.wgrad9_thin_blocks): a tile of theirs costs a fraction of a full block's.  Relative costs
+  // measured with tools/ab_wgrad8.py on sub-tables (profiles/r06_ab_variants.txt); SATNERF_WGRAD_THIN_COST="c16,c8" overrides them,
+  // SATNERF_WGRAD_THIN=0 (full streams everywhere, packing reads the same switch) makes every block cost 1 again.
+  double thin16 = 0.5, thin8 = 0.4;
+  bool thin_on = true;
+  if (const char* e = getenv("SATNERF_WGRAD_THIN")) thin_on = e[0] != '0';
+  if (const char* e = getenv("SATNERF_WGRAD_THIN_COST")) sscanf(e, "%lf,%lf", &thin16, &thin8);
+  bool any_thin = false;
+  static thread_local double w9cost[4096];
+  for (int b = 0; b < n_blocks; ++b) {
+    const int32_t* t = blocks + kWgTableInts * b;
+    const int nr = t[1] + t[3], nc = t[5] + t[7];
+    const bool thin = thin_on && nr == 1 && t[8] == 1 && (nc == 8 || nc == 16);
+    w9cost[b] = thin ? (nc == 16 ? thin16 : thin8) : 1.0;
+    any_thin |= thin && w9cost[b] != 1.0;
+  }
+  bool use_weights = false;
+  if (weighted && !old_kernel && any_thin && n_blocks <= 64 && n_wg >= n_blocks) {
+    // cost-weighted slices for the 4-wave kernel: greedily to the block whose workgroups would finish last (minimises
+    // max_b cost_b * ceil(tiles / slices_b)); the kernel numbers workgroups slice-major over the blocks that still have slices
+    for (int b = 0; b < n_blocks; ++b) sl[b] = 1;
+    for (int left = n_wg - n_blocks; left > 0; --left) {
+      int worst = -1;
+      double wt = -1;
+      for (int b = 0; b < n_blocks; ++b) {
+        const double tb = w9cost[b] * (double)((n_tiles + sl[b] - 1) / sl[b]);
+        if (tb > wt && sl[b] < n_tiles) wt = tb, worst = b;
+      }
+      if (worst < 0) break;
+      ++sl[worst];
+    }
+    double makespan = 0;
+    for (int b = 0; b < n_blocks; ++b) {
+      const double tb = w9cost[b] * (double)((n_tiles + sl[b] - 1) / sl[b]);
+      makespan = tb > makespan ? tb : makespan;
+    }
+    // ... unless a stream-K plan (below: equal tile spans, thin blocks simply finish early) is shorter still -- width 512's 47 blocks
+    const long span = ((long)n_blocks * n_tiles + n_wg - 1) / n_wg;
+    use_weights = makespan <= (double)span * 1.03 || n_tiles * 208l * 1024l >= (1l << 32);
+    if (const char* e = getenv("SATNERF_WGRAD_STREAMK")) use_weights = e[0] != '1';
+  }
+  if (use_weights) {
+    // (sl[] holds the weighted split)
+  } else if (weighted && !old_kernel) {
     // equal split, the remainder to the first blocks: what wgrad9.hip's workgroup numbering (slice-major, blocks 8 positions apart on one
     // XCD) assumes; a block never gets more slices than it has tiles
     const long q = n_wg / n_blocks, r = n_wg % n_blocks;

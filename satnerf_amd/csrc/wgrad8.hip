@@ -46,7 +46,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 //   (0..15 rows, 16..31 columns; a DF expands into fragment and fragment + 1) | 18-19 scale area | 20-23 byte within the lane's 16 B
 // ints 16..18: the scale unit fetched into scale area 0..2 (bits 0-1 source, 4-11 unit; 0 = none), by waves 2..4.
 // ints 20..99: the duty table of the 4-wave kernel (wgrad9.hip, packing.wgrad9_duties); ints 100..107: the exponent groups of its row pairs, int 108: its quadrant mask.
-constexpr int kWg8LoadInts = 109;
+constexpr int kWg8LoadInts = 113;
 enum { kSrcDpre = 1, kSrcActs = 2, kRaw16 = 0, kPhase8 = 1, kMx8 = 2 };
 
 constexpr int kFragStride8 = 1088;  // as wgrad.hip: 1-KiB lane-linear fragment image + 64 B so that transposed reads spread over the banks

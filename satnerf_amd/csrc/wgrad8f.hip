@@ -39,7 +39,7 @@ typedef float f32x32 __attribute__((ext_vector_type(32)));
 typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
 
 namespace {
-constexpr int kLoadInts = 109;  // = wgrad8.hip kWg8LoadInts (ints 0..19 are this kernel's)
+constexpr int kLoadInts = 113;  // = wgrad8.hip kWg8LoadInts (ints 0..19 are this kernel's)
 enum { kSrcDpreF = 1, kSrcActsF = 2, kRaw16F = 0, kPhase8F = 1, kMx8F = 2 };
 constexpr int kFrag = 1088, kPair = 2 * kFrag, kOperandFragsF = 34, kScaleAreasF = 3;
 constexpr int kSlotBytes = kOperandFragsF * kFrag + kScaleAreasF * 1024;

@@ -34,6 +34,7 @@ namespace {
 constexpr int kFrag9 = 1088, kPair9 = 2 * kFrag9, kSlotFrags9 = 36, kSlot9 = kSlotFrags9 * kFrag9, kSlots9 = 4;  // = gen/wgrad9_loop.py
 constexpr int kEmaxFeatsByte = 14;  // = mlp_layout.h kEmaxFeats (this translation unit is width-agnostic and does not include the layout's namespace)
 constexpr int kOldInts = 20, kDutyInts = 4, kDuties = 5, kDumpFrag = 34, kPairs = 8;
+constexpr int kVariantAt = 4 * kDuties * kDutyInts + kPairs + 1;  // per-wave stream variant behind the duties, the pair groups and the quadrant mask (packing.WG9_VARIANT_INTS)
 
 struct Wgrad9Params {
   const char* dpre;
@@ -68,6 +69,7 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   // search (one lane per table row, one ballot) and fetches again
   int blk;
   int d[kWgTableInts], du[kDuties * kDutyInts], pairs[kPairs + 1];  // pairs[]: exponent group of each 32-row pair; [kPairs]: the quadrant mask
+  int variant = 0;  // this wave's instruction stream: 0 = full, k > 0 = thin stream k (gen/wgrad9_loop.py THIN, packing.WG9_THIN)
   auto fetch_tables = [&](int b) {
     const int* row = prm.blocks + kWgTableInts * b;
     const int* lt = prm.loads + (long)b * prm.load_ints + kOldInts;
@@ -77,6 +79,7 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
     for (int i = 0; i < kDuties * kDutyInts; ++i) du[i] = lt[wave * kDuties * kDutyInts + i];
 #pragma unroll
     for (int i = 0; i < kPairs + 1; ++i) pairs[i] = lt[4 * kDuties * kDutyInts + i];
+    variant = lt[kVariantAt + wave];
   };
   // the entries of the exponent-maxima table that cover tiles [first, last]: lane i takes entries first / 4 + i, + 64, ...; folded byte-wise
   // (a u16 maximum orders by the HIGH byte, so pk_max tracks bytes 1 and 3 of a dword exactly in the high bytes of its halves; the same
@@ -145,7 +148,32 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
       const bool bad = b < prm.n_blocks && prm.blocks[kWgTableInts * b + kWgSlices] != q + (b < r ? 1 : 0);
       if (__ballot(bad)) equal_split = false;
     }
-    if (!equal_split) {  // some other plan: block-major numbering, found by search
+    if (!equal_split && prm.n_blocks <= 64) {
+      // a cost-weighted plan (r06: thin blocks take fewer workgroups): still SLICE-MAJOR -- workgroups are handed out level by level,
+      // level s to every block that has more than s slices, in table order -- so that for the levels all blocks share the numbering is
+      // the equal split's (blocks 8 table positions apart on one XCD at the same time), and a block that runs out of slices only
+      // closes the ranks behind it.  One lane per block holds its slice count; a ballot per level finds this workgroup's.
+      const int mine = lane < prm.n_blocks ? prm.blocks[kWgTableInts * lane + kWgSlices] : 0;
+      int rem = idx;
+      blk = prm.n_blocks - 1, slice = 0;
+      for (int lvl = 0; lvl < 4096; ++lvl) {
+        const unsigned long long has = __ballot(mine > lvl);
+        const int cnt = __builtin_popcountll(has);
+        if (cnt == 0) break;  // (more workgroups than slices: the launch never does that)
+        if (rem < cnt) {
+          unsigned long long m = has;
+          for (int k = 0; k < rem; ++k) m &= m - 1;  // drop the `rem` lowest set bits
+          blk = __builtin_ctzll(m), slice = lvl;
+          break;
+        }
+        rem -= cnt;
+      }
+      blk = __builtin_amdgcn_readfirstlane(blk), slice = __builtin_amdgcn_readfirstlane(slice);
+      fetch_tables(blk);
+      long first, last;
+      if (slice_of(d[kWgSlices], slice, first, last)) fetch_emax(first, last);
+      else fetch_emax(1, 0);
+    } else if (!equal_split) {  // some other plan: block-major numbering, found by search
       blk = 0;
       for (int b0 = 0; b0 < prm.n_blocks; b0 += 64) {
         const int b = b0 + lane;
@@ -212,7 +240,9 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   // quadrant (wr, wc): row pairs 4 wr + ((a + 2 wc) & 3) for operand slot a = 0..3 (slots 0, 1 also take the aux columns), column pairs
   // 8 + 4 wc + c
   const int wr = wave >> 1, wc = wave & 1;
-  const uint32_t aofl = (uint32_t)(4 * wr + 2 * wc) * kPair9, aofh = (uint32_t)(4 * wr + ((2 * wc + 2) & 3)) * kPair9;
+  variant = __builtin_amdgcn_readfirstlane(variant);
+  const bool thin = variant > 0;  // thin streams contract row pair 0 (the block's only one) in operand slot 0, whatever the wave
+  const uint32_t aofl = thin ? 0u : (uint32_t)(4 * wr + 2 * wc) * kPair9, aofh = (uint32_t)(4 * wr + ((2 * wc + 2) & 3)) * kPair9;
   const uint32_t bof = (uint32_t)(8 + 4 * wc) * kPair9;
 
   // ---- fp16 range per row pair (and of MX8 columns) over this workgroup's slice: the byte-wise maxima over the lanes' entries ----------
@@ -264,7 +294,7 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   const float un_col = 1.0f / g_col;  // (powers of two: exact)
   float un_row[4];                    // accumulator row tile a of this wave = pair 4 wr + ((a + 2 wc) & 3)
 #pragma unroll
-  for (int a = 0; a < 4; ++a) un_row[a] = __builtin_bit_cast(float, uni((pair_emax(4 * wr + ((a + 2 * wc) & 3)) - 11u) << 23));  // 2^(Emax - 138)
+  for (int a = 0; a < 4; ++a) un_row[a] = __builtin_bit_cast(float, uni((pair_emax(thin ? 0 : 4 * wr + ((a + 2 * wc) & 3)) - 11u) << 23));  // 2^(Emax - 138)
 
   const uint32_t flags = ring + (uint32_t)(kSlots9 * kSlot9);
   f32x32w c0, c1, c2, c3, c4, c5, c6, c7, cx;
@@ -290,7 +320,55 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   // a wave whose 128 x 128 quadrant nobody reads (narrow blocks: packing.wgrad9_duties' quadrant mask) runs the stream without the 32
   // main MFMAs and their operand reads: same loads, decode, rendezvous, aux tiles -- the time of a tile is unchanged, its energy is not
   const bool quad_on = (__builtin_amdgcn_readfirstlane(pairs[kPairs]) >> wave) & 1;
-  if (col_mx && quad_on) {
+  if (variant == 1) {
+    asm volatile(
+#include "wgrad9_loop_t1.inc"
+        : SR_W9_OUTS
+        : SR_W9_INS
+        :
+#include "wgrad9_loop_clobbers.inc"
+    );
+  } else if (variant == 2) {
+    asm volatile(
+#include "wgrad9_loop_d3.inc"
+        : SR_W9_OUTS
+        : SR_W9_INS
+        :
+#include "wgrad9_loop_clobbers.inc"
+    );
+  } else if (variant == 3) {
+    asm volatile(
+#include "wgrad9_loop_t0.inc"
+        : SR_W9_OUTS
+        : SR_W9_INS
+        :
+#include "wgrad9_loop_clobbers.inc"
+    );
+  } else if (variant == 4) {
+    asm volatile(
+#include "wgrad9_loop_r2.inc"
+        : SR_W9_OUTS
+        : SR_W9_INS
+        :
+#include "wgrad9_loop_clobbers.inc"
+    );
+  } else if (variant == 5) {
+    asm volatile(
+#include "wgrad9_loop_d2.inc"
+        : SR_W9_OUTS
+        : SR_W9_INS
+        :
+#include "wgrad9_loop_clobbers.inc"
+    );
+  } else if (variant == 6) {
+    asm volatile(
+#include "wgrad9_loop_d0.inc"
+        : SR_W9_OUTS
+        : SR_W9_INS
+        :
+#include "wgrad9_loop_clobbers.inc"
+    );
+  } else if (col_mx && quad_on) {
     asm volatile(
 #include SR_W9_M_INC
         : SR_W9_OUTS
@@ -341,9 +419,12 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   float* out = prm.partial + (long)(d[kWgFirstSlice] + slice) * kWgBlockFloats;
   const int n_rows = 16 * nr, n_cols = 16 * nc;
   const f32x32w* cc[8] = {&c0, &c1, &c2, &c3, &c4, &c5, &c6, &c7};
+  // thin streams: variants 1 and 3 (t1, t0) contract row pair 0 into accumulator row tile 0; the others hold no results
+  const bool thin_mfma = variant == 1 || variant == 3;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    const int row0 = 32 * (4 * wr + ((a + 2 * wc) & 3));
+    const int row0 = thin ? 0 : 32 * (4 * wr + ((a + 2 * wc) & 3));
+    if (thin && (a != 0 || !thin_mfma)) continue;
     if (row0 >= n_rows || !quad_on) continue;  // (wave-uniform) tiles the block does not have / nobody reads: never written, never summed
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -359,7 +440,8 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   float* oa = out + 256 * 256;
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
-    const int row0 = 32 * (4 * wr + ((a + 2 * wc) & 3));
+    const int row0 = thin ? 0 : 32 * (4 * wr + ((a + 2 * wc) & 3));
+    if (thin && (a != 0 || !thin_mfma || wc != 0)) continue;  // (both thin MFMA waves hold pair 0's aux tile: the first one writes it)
     if (row0 >= n_rows) continue;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {

@@ -12,6 +12,7 @@ Parameter names/shapes are those of the reference ``SatNeRF`` ``state_dict`` (mo
 from __future__ import annotations
 
 import functools
+import os
 import math
 from collections import OrderedDict
 
@@ -447,7 +448,10 @@ WG9_DUTY_INTS = 4 * 5 * 4  # duty table of the 4-wave kernel (wgrad9.hip): 4 wav
 WG9_SCAN_INTS = 8          # ... + the exponent group (byte of an entry of the dX kernel's table of exponent maxima) of each of the block's 8 row pairs; -1 = none
 EMAX_FEATS, EMAX_RAW = 14, 15   # ... bytes 0..13 = the dpre scale groups (mlp_layout.h), 14 = the saved feats (columns of the MX8 blocks), 15 = the bf16 rows d_sigma_pre / d_head
 WG9_MASK_INTS = 1          # ... + the mask of the 128 x 128 quadrants (bit = wave = 2 row half + column half) somebody reads
-WG8_LOAD_INTS = WG8_OLD_INTS + WG9_DUTY_INTS + WG9_SCAN_INTS + WG9_MASK_INTS
+WG9_VARIANT_INTS = 4       # ... + the instruction stream of each wave: 0 = the full stream (its aux-only form where the quadrant mask says so), k > 0 = thin stream WG9_THIN[k - 1]
+WG8_LOAD_INTS = WG8_OLD_INTS + WG9_DUTY_INTS + WG9_SCAN_INTS + WG9_MASK_INTS + WG9_VARIANT_INTS
+# thin streams of csrc/gen/wgrad9_loop.py (THIN), in the order csrc/wgrad9.hip numbers them: (column double fragments, raw fragment, MFMAs)
+WG9_THIN = ((1, True, "thin"), (3, False, "none"), (0, True, "thin"), (2, True, "none"), (2, False, "none"), (0, False, "none"))
 WG9_DUMP_FRAG = 34         # LDS fragment an unused duty decodes into (csrc/gen/wgrad9_loop.py: 16 rows + 16 columns + 2 aux + 2 dump)
 def fmt8_geometry(feat=256):
     """Unit (1 KiB) offsets of the 8-bit workspaces (csrc/mlp_layout.h kD8* / kA8*) and the 16-bit fragment numbers they map."""
@@ -541,6 +545,7 @@ def wgrad8_loads(feat=256, tau=4):
     duties = wgrad9_duties(feat, tau)
     out[:, WG8_OLD_INTS:WG8_OLD_INTS + WG9_DUTY_INTS] = duties
     out[:, WG8_OLD_INTS + WG9_DUTY_INTS:WG8_OLD_INTS + WG9_DUTY_INTS + WG9_SCAN_INTS] = wgrad9_pair_groups(feat, tau)
+    out[:, WG8_OLD_INTS + WG9_DUTY_INTS + WG9_SCAN_INTS + WG9_MASK_INTS:] = wgrad9_variants(feat, tau)
     # quadrant mask: which (row half, column half) of each 256 x 256 block holds a gradient the scatter map reads
     g = bm["gidx"][bm["gidx"] >= 0].astype(np.int64)
     blk, w = g // WG_BLOCK_FLOATS, g % WG_BLOCK_FLOATS
@@ -575,6 +580,35 @@ def wgrad9_pair_groups(feat=256, tau=4):
     return out
 
 
+def wgrad9_thin_blocks(feat=256, tau=4):
+    """{block: number of column double fragments} of the job blocks that run THIN streams (csrc/gen/wgrad9_loop.py, r06): the row operand is
+    ONE raw bf16 fragment (d_head / d_sigma_pre: a single live 32-row pair), the columns are 4 or 8 PHASE8 double fragments, and there is one
+    aux fragment (tau <= 8).  The full stream spends a full block's time per tile on them (two dump row duties decoded at full price)."""
+    bm = backward_maps(feat, tau)
+    out = {}
+    if os.environ.get("SATNERF_WGRAD_THIN", "1") == "0" or bm["auxs"] != 1:
+        return out
+    for b, (rows, cols) in enumerate(zip(bm["block_rows"], bm["block_cols"])):
+        if len(rows) == 1 and dpre8_source(rows[0], feat)["codec"] == RAW16 and bm["blocks"][b, 8] == KIND_PHASE and len(cols) in (8, 16):
+            if all(act8_source(c, bm["auxs"], feat)["codec"] == PHASE8 for c in cols):
+                out[b] = len(cols) // 2
+    return out
+
+
+@functools.lru_cache(maxsize=8)
+def wgrad9_variants(feat=256, tau=4):
+    """int32 [n_blocks, 4]: the instruction stream wave w of a block's workgroup runs -- 0 = the full stream, k > 0 = WG9_THIN[k - 1].
+    8 column double fragments: waves 0, 1 own the two live quadrants (raw fragment + 1 double fragment + the MFMAs of row pair 0), waves 2, 3
+    decode three double fragments each.  4 of them: wave 0 (raw row fragment, MFMAs), wave 1 (aux fragment + 2), wave 2 (2), wave 3 idle."""
+    thin = wgrad9_thin_blocks(feat, tau)
+    out = np.zeros((len(backward_maps(feat, tau)["block_rows"]), WG9_VARIANT_INTS), np.int32)
+    vid = lambda v: 1 + WG9_THIN.index(v)  # noqa: E731
+    for b, n in thin.items():
+        out[b] = ([vid((1, True, "thin")), vid((1, True, "thin")), vid((3, False, "none")), vid((3, False, "none"))] if n == 8 else
+                  [vid((0, True, "thin")), vid((2, True, "none")), vid((2, False, "none")), vid((0, False, "none"))])
+    return out
+
+
 @functools.lru_cache(maxsize=8)
 def wgrad9_duties(feat=256, tau=4):
     """Duty table of csrc/wgrad9.hip: int32 [n_blocks, 80] = 4 waves x 5 duties x (source, unit, LDS fragment, scale).
@@ -589,6 +623,7 @@ def wgrad9_duties(feat=256, tau=4):
     bm = backward_maps(feat, tau)
     auxs = bm["auxs"]
     out = np.zeros((len(bm["block_rows"]), 4, 5, 4), np.int32)
+    thin = wgrad9_thin_blocks(feat, tau)
     for b, (rows, cols) in enumerate(zip(bm["block_rows"], bm["block_cols"])):
         out[b, :, 0:2] = [SRC_DPRE, 0, WG9_DUMP_FRAG, 0]
         out[b, :, 2:4] = [SRC_ACTS, auxs, WG9_DUMP_FRAG, 16 * auxs]
@@ -596,6 +631,19 @@ def wgrad9_duties(feat=256, tau=4):
         raw_wave = 0
         for a in range(auxs):                                    # aux fragments: waves 1, 2
             out[b, 1 + a, 4] = [SRC_ACTS, a, 32 + a, 0]
+        if b in thin:   # thin streams: duty slots 0.. hold COLUMN double fragments (wgrad9_variants says which wave takes how many)
+            d = dpre8_source(rows[0], feat)
+            out[b, 0, 4] = [SRC_DPRE, d["unit"], 0, 0]
+            share = ([1, 1, 3, 3] if thin[b] == 8 else [0, 2, 2, 0])
+            j = 0
+            for w, k in enumerate(share):
+                for slot in range(k):
+                    c = act8_source(cols[2 * j], auxs, feat)
+                    assert c["codec"] == PHASE8 and c["half"] == 0 and cols[2 * j + 1] == cols[2 * j] + 1
+                    out[b, w, slot] = [SRC_ACTS, c["unit"], 16 + 2 * j, 16 * auxs]
+                    j += 1
+            assert j == thin[b]
+            continue
         for base, frags, src, lookup, d0 in ((0, rows, SRC_DPRE, lambda f: dpre8_source(f, feat), 0),
                                              (16, cols, SRC_ACTS, lambda f: act8_source(f, auxs, feat), 2)):
             pos, n_df = 0, 0

@@ -96,9 +96,15 @@ def test_wgrad_plan_host_only(handle):
         if fmt == 16:
             assert (ns == ns[0]).all()  # equal slices
         elif n_points == 65536 and n_wg == 256:
-            # every workgroup used; the default 4-wave kernel (wgrad9.hip) runs one stream for every block: slices differ by at most one
+            # every workgroup used; the default 4-wave kernel (wgrad9.hip) runs one stream for every FULL block: their slices differ by at
+            # most one; r06: the two one-row blocks (12, 13) run thin streams and are handed workgroups in proportion to their cost per tile
             # (the cost-weighted split of the r02 kernel is selected together with it, SATNERF_WGRAD_V1=1)
-            assert n.value == 256 and ns.max() - ns.min() <= 1
+            thin = sorted(packing.wgrad9_thin_blocks(256, 4))
+            full = np.setdiff1d(np.arange(blocks.shape[0]), thin)
+            assert n.value == 256 and ns[full].max() - ns[full].min() <= 1
+            assert thin == [12, 13] and (ns[thin] < ns[full].min()).all() and (ns[thin] >= 4).all()
+            worst_full = -(-tiles // ns[full].min())
+            assert all(0.25 * worst_full <= -(-tiles // ns[b]) * c <= 1.05 * worst_full for b, c in zip(thin, (0.5, 0.4)))
     bad = np.ascontiguousarray(blocks0.copy())
     bad[0, 1] = 17
     assert handle.sr_wgrad_plan(bad.ctypes.data_as(ctypes.c_void_p), bad.shape[0], 65536, 256, 16, ctypes.byref(n)) != 0

@@ -32,6 +32,43 @@ def test_generated_files_are_current(codec, main, tag):
         assert f.read() == g.clobber_file()
 
 
+def _thin_variants():
+    return list(_gen().THIN.items())
+
+
+def test_thin_stream_files_are_current_and_numbered_as_the_kernel_numbers_them():
+    """r06: the thin streams of one-row blocks.  packing.WG9_THIN (the ids of the per-wave variant table) lists them in the order
+    csrc/wgrad9.hip dispatches on."""
+    g = _gen()
+    from satnerf_amd import packing
+
+    assert list(packing.WG9_THIN) == list(g.THIN)
+    with open(os.path.join(ROOT, "satnerf_amd", "csrc", "wgrad9.hip")) as f:
+        src = f.read()
+    for k, (thin, tag) in enumerate(g.THIN.items()):
+        with open(os.path.join(ROOT, "satnerf_amd", "csrc", f"wgrad9_loop_{tag}.inc")) as f:
+            assert f.read() == g.Stream("phase", thin=thin).inc_file(), "re-run satnerf_amd/csrc/gen/wgrad9_loop.py"
+        assert re.search(rf'variant == {k + 1}\) {{\s+asm volatile\(\s+#include "wgrad9_loop_{tag}.inc"', src), (k + 1, tag)
+
+
+@pytest.mark.parametrize("thin,tag", [(t, tag) for t, tag in [((1, True, "thin"), "t1"), ((3, False, "none"), "d3"), ((0, True, "thin"), "t0"),
+                                                                ((2, True, "none"), "r2"), ((2, False, "none"), "d2"), ((0, False, "none"), "d0")]])
+def test_thin_iteration_shape(thin, tag):
+    g = _gen()
+    assert g.THIN[thin] == tag
+    n_df, raw, mfma = thin
+    s = g.Stream("phase", thin=thin)
+    prologue, bodies = _split(s.ins)
+    assert not any(t == "s_barrier" for b in bodies for t in b) and sum(t == "s_barrier" for t in prologue) == 1
+    for b in bodies:
+        n = lambda pat: sum(bool(re.match(pat, t)) for t in b)  # noqa: E731
+        assert n(r"v_mfma_f32_32x32x16_f16") == (10 if mfma == "thin" else 0)      # 2 k-steps x (row pair 0 x 4 column pairs + its aux tile)
+        assert n(r"ds_read_b64_tr_b16") == (24 if mfma == "thin" else 0)           # A0, B0..B3, X: two reads each, two k-steps
+        assert n(r"ds_write_b128") == 2 * n_df + (1 if raw else 0) and n(r"ds_add_u32") == 1
+        assert n(r"global_load_dwordx4") == n_df + (1 if raw else 0) and n(r"global_load_ubyte") == 0
+        assert n(r"v_sin_f16_sdwa") == 16 * n_df and n(r"v_pk_fma_f16") == 0
+
+
 def _regs(tok):
     """registers of an operand like v[32:35], a[0:15], v246"""
     m = re.fullmatch(r"([va])\[(\d+):(\d+)\]", tok)
@@ -70,10 +107,12 @@ def test_iteration_shape(codec, main, tag):
         assert n(r"v_pk_fma_f16") == (16 if codec == "phase" else 32)
 
 
-@pytest.mark.parametrize("codec,main,tag", VARIANTS)
+@pytest.mark.parametrize("codec,main,tag", VARIANTS + [("phase", t, tag) for t, tag in (((1, True, "thin"), "t1"), ((3, False, "none"), "d3"),
+                                                                                          ((0, True, "thin"), "t0"), ((2, True, "none"), "r2"),
+                                                                                          ((2, False, "none"), "d2"), ((0, False, "none"), "d0"))])
 def test_lds_counter_discipline_across_the_back_edge(codec, main, tag):
     g = _gen()
-    s = g.Stream(codec, main=main)
+    s = g.Stream(codec, main=main) if isinstance(main, bool) else g.Stream(codec, thin=main)
     prologue, bodies = _split(s.ins)
     inflight = []  # LDS operations in issue order: (kind, destination registers)
     exec_one = False
@@ -353,7 +392,7 @@ def _decoded(mem, base, unit_off, codec, scale_addr, g_bits):
     return out
 
 
-@pytest.mark.parametrize("blk,nt,spread", [(2, 6, 0), (1, 5, 0), (8, 3, 0), (1, 4, 44), (9, 3, 30)])
+@pytest.mark.parametrize("blk,nt,spread", [(2, 6, 0), (1, 5, 0), (8, 3, 0), (1, 4, 44), (9, 3, 30), (12, 5, 0), (13, 6, 0), (12, 2, 0)])
 def test_stream_computes_the_block_contraction(blk, nt, spread):
     """``spread`` > 0: the exponent bytes of the block's SECOND row group lie that many binades below the first one's (two layers of very
     different gradient scale sharing a block): with one Emax per block those rows would flush to zero; the range is fitted
@@ -365,6 +404,12 @@ def test_stream_computes_the_block_contraction(blk, nt, spread):
     col_mx = bm["blocks"][blk, 8] == packing.KIND_BF16
     duties = loads[blk, 20:100].reshape(4, 5, 4)
     quad = int(loads[blk, 108])
+    variants = [int(x) for x in loads[blk, 109:113]]   # r06: 0 = the full stream, k > 0 = thin stream packing.WG9_THIN[k - 1]
+    assert (blk in packing.wgrad9_thin_blocks(256, 4)) == any(variants)
+    def n_df_of(w):   # double-fragment duty slots wave w's stream executes
+        return 4 if variants[w] == 0 else packing.WG9_THIN[variants[w] - 1][0]
+    def raw_of(w):
+        return True if variants[w] == 0 else packing.WG9_THIN[variants[w] - 1][1]
     ak, dk = packing.act8_units(1, 256), packing.dpre8_units(256)
     n_tiles = nt + 2                                   # two tiles beyond the slice: what the clamp logic may touch
     D0, A0 = 4096, 4096 + n_tiles * dk * 1024 + 4096   # byte addresses of the two workspaces in `mem`
@@ -398,9 +443,9 @@ def test_stream_computes_the_block_contraction(blk, nt, spread):
     # delivers per scale group; here taken from the bytes themselves), columns likewise when they are MX8
     pair_e, ec = {}, 0
     for w in range(4):
-        for k in range(4):
+        for k in range(n_df_of(w)):
             src, unit, dst, sc = (int(x) for x in duties[w, k])
-            if dst == packing.WG9_DUMP_FRAG or (k >= 2 and not col_mx):
+            if dst == packing.WG9_DUMP_FRAG or ((k >= 2 or variants[w]) and not col_mx):
                 continue
             base = D0 if src == 1 else A0
             stride = (dk if src == 1 else ak) * 1024
@@ -432,8 +477,8 @@ def test_stream_computes_the_block_contraction(blk, nt, spread):
         wr, wc = w >> 1, w & 1
         ops = {"nt": nt, "tleft": n_tiles - 1, "erow0": er_of(int(duties[w, 0, 2])) - 20, "erow1": er_of(int(duties[w, 1, 2])) - 20,
                "ecol": ec - 20, "flags": ring + 4 * slot_b,
-               "strd": dk * 1024, "stra": ak * 1024, "aofl": (4 * wr + 2 * wc) * g.PAIR, "aofh": (4 * wr + ((2 * wc + 2) & 3)) * g.PAIR,
-               "bof": (8 + 4 * wc) * g.PAIR}
+               "strd": dk * 1024, "stra": ak * 1024, "aofl": 0 if variants[w] else (4 * wr + 2 * wc) * g.PAIR,
+               "aofh": (4 * wr + ((2 * wc + 2) & 3)) * g.PAIR, "bof": (8 + 4 * wc) * g.PAIR}
         raw_src = int(duties[w, 4, 0])
         ops["strx"] = ops["strd"] if raw_src == 1 else ops["stra"]
         ops["sraw"] = int(np.float32(g_row_of(int(duties[w, 4, 2])) if raw_src == 1 else 1.0).view(np.uint32))
@@ -444,7 +489,8 @@ def test_stream_computes_the_block_contraction(blk, nt, spread):
             if k < 4:
                 ops[f"sb{k}"] = base + (sc >> 4) * 1024 + (sc & 15)
             ops["wx" if k == 4 else f"w{k}"] = ring + dst * g.FRAG
-        wave = _Wave((s if (quad >> w) & 1 else sx).ins, ops, lds, mem, shared)
+        stream = g.Stream("phase", thin=packing.WG9_THIN[variants[w] - 1]) if variants[w] else (s if (quad >> w) & 1 else sx)
+        wave = _Wave(stream.ins, ops, lds, mem, shared)
         lane = np.arange(64)
         src_unit = np.where(lane < 32, lane, 32 + ((lane - 8) & 31))
         hh, rh, m, q = lane >> 5, (lane >> 4) & 1, (lane >> 2) & 3, lane & 3
@@ -471,7 +517,7 @@ def test_stream_computes_the_block_contraction(blk, nt, spread):
     for t in range(nt):
         sl = slice(32 * t, 32 * t + 32)
         for w in range(4):
-            for k in range(5):
+            for k in list(range(n_df_of(w))) + ([4] if raw_of(w) else []):
                 src, unit, dst, sc = (int(x) for x in duties[w, k])
                 if dst == packing.WG9_DUMP_FRAG:
                     continue
@@ -488,8 +534,9 @@ def test_stream_computes_the_block_contraction(blk, nt, spread):
                     else:
                         rows[16 * dst: 16 * dst + 16, sl] = frag
                     continue
-                codec = "mx" if k < 2 or col_mx else "phase"
-                dec = _decoded(mem, base, unit * 1024, codec, base + (sc >> 4) * 1024 + (sc & 15), (er_of(dst) if k < 2 else ec) - 20)
+                is_row = k < 2 and not variants[w]   # (thin streams: every double-fragment duty is a column duty)
+                codec = "mx" if is_row or col_mx else "phase"
+                dec = _decoded(mem, base, unit * 1024, codec, base + (sc >> 4) * 1024 + (sc & 15), (er_of(dst) if is_row else ec) - 20)
                 dec = _f16(_to_f16_bits(dec))
                 tgt, f0 = (rows, dst) if dst < 16 else (cols, dst - 16)
                 tgt[16 * f0: 16 * f0 + 16, sl], tgt[16 * f0 + 16: 16 * f0 + 32, sl] = dec[0], dec[1]
@@ -498,8 +545,13 @@ def test_stream_computes_the_block_contraction(blk, nt, spread):
     n_rows, n_cols = 16 * len(bm["block_rows"][blk]), 16 * len(bm["block_cols"][blk])   # beyond them: stale LDS, results nobody reads
     for w, wave in enumerate(waves):
         wr, wc = w >> 1, w & 1
+        thin_mfma = variants[w] and packing.WG9_THIN[variants[w] - 1][2] == "thin"
         for a in range(4):
             row0 = 32 * (4 * wr + ((a + 2 * wc) & 3))
+            if variants[w]:   # thin streams contract row pair 0 in operand slot 0 (wgrad9.hip's epilogue reads accumulator row tile 0 only)
+                if a != 0 or not thin_mfma:
+                    continue
+                row0 = 0
             got_rows = np.zeros((32, 128))
             for c in range(4):
                 for gg in range(16):
