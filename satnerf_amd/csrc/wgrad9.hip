@@ -222,7 +222,11 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
     on[k] = dst != kDumpFrag;
     if (k == 4) raw_src = src;
   }
+#ifdef SR_W9_L2WINDOW  // A/B build (wrong results): every tile of a slice re-reads the slice's FIRST tile -- the same loop, decode and MFMAs with its
+  const uint32_t strd = 0u, stra = 0u;  // 410 MB of operand traffic served by the L2 instead of HBM (is the kernel's 4.25 TB/s free?  DESIGN section 4)
+#else
   const uint32_t strd = (uint32_t)__builtin_amdgcn_readfirstlane(prm.dk * 1024), stra = (uint32_t)__builtin_amdgcn_readfirstlane(prm.ak * 1024);
+#endif
   const uint32_t strx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(raw_src == 1 ? strd : stra));
   // rotated image (as wgrad8): LDS position `lane` of a fragment holds source lane src_unit's 16 bytes, so that the transposed reads
   // spread over the banks; every global load fetches that lane's bytes, every LDS write goes to lane * 16
