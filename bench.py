@@ -153,7 +153,9 @@ def cpu_baseline(phase, n_rays, n_samples, budget_s=10.0):
     (a) ONE process, torch's intra-op pool swept over 16 / 32 / 64 threads -- the pool does not scale on these 5120 x 256 operators (r04:
     2.6 rays/s at 256 threads), so the best setting uses 16 of the host's threads;  (b) r06: the batch SHARDED over host_cpus / 16
     processes of 16 threads each (every process renders and back-propagates its slice of the rays, started together) -- all of the host's
-    hardware threads at work on one batch.  `value` is the better of the two; both are reported."""
+    hardware threads at work on one batch (measured: SLOWER than (a), 882 against 2,028 rays/s on a 256-thread host: 64-ray shards are
+    too small for 16 threads);  (c) the same fleet with one whole batch per process -- data-parallel replicas, the CPU counterpart of
+    N GPUs.  `value` is the best of the three; all are reported."""
     import subprocess
 
     cores = os.cpu_count() or 1
@@ -176,31 +178,36 @@ def cpu_baseline(phase, n_rays, n_samples, budget_s=10.0):
     out = {"value": single, "unit": "rays/s", "cores": best_thr, "host_cpus": cores, "kind": "port",
            "sample": f"{it} x {n} rays x {n_samples} samples, {phase}, torch {torch.__version__} CPU fp32",
            "single_process": {"value": single, "threads": best_thr, "sweep_rays_per_s": {str(k): round(v, 1) for k, v in sweep.items()}}}
-    # (b) the batch sharded over processes
+    # (b) the batch sharded over processes, (c) one whole batch per process (what N GPUs do: data-parallel replicas)
     per = 16 if cores >= 32 else max(cores // 2, 1)
     procs = max(min(cores // per, n // 8), 1)
-    if procs > 1:
-        shard = n // procs
-        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", phase, str(shard), str(n_samples), str(per), str(budget_s)]
+
+    def fleet(rays_each, seconds):
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", phase, str(rays_each), str(n_samples), str(per), str(seconds)]
         env = dict(os.environ, OMP_NUM_THREADS=str(per), MKL_NUM_THREADS=str(per), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
         t0 = time.time()
         kids = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(procs)]
         rates = []
         for k in kids:
             try:
-                txt, _ = k.communicate(timeout=budget_s * 6 + 120)
+                txt, _ = k.communicate(timeout=seconds * 6 + 120)
                 r = json.loads(txt.strip().splitlines()[-1])
                 rates.append(r["rays"] * r["passes"] / r["seconds"])
             except Exception:  # noqa: BLE001  (a baseline leg must not take the bench line down)
                 k.kill()
-        if len(rates) == procs:
-            sharded = sum(rates)
-            out["sharded"] = {"value": sharded, "processes": procs, "threads_per_process": per, "rays_per_process": shard,
-                              "wall_s": round(time.time() - t0, 1)}
-            if sharded > single:
-                out.update(value=sharded, cores=procs * per,
-                           sample=f"{procs} processes x {per} threads, each {shard} of the batch's {n} rays x {n_samples} samples, {phase}, "
-                                  f"~{budget_s:.0f} s, torch {torch.__version__} CPU fp32")
+        return (sum(rates), round(time.time() - t0, 1)) if len(rates) == procs else (None, None)
+
+    if procs > 1:
+        for key, rays_each, what in (("sharded", n // procs, f"each {n // procs} of the batch's {n} rays"),
+                                     ("replicas", n, f"each its own {n}-ray batch (data-parallel replicas)")):
+            rate, wall = fleet(rays_each, budget_s * 0.6)
+            if rate is None:
+                continue
+            out[key] = {"value": rate, "processes": procs, "threads_per_process": per, "rays_per_process": rays_each, "wall_s": wall}
+            if rate > out["value"]:
+                out.update(value=rate, cores=procs * per,
+                           sample=f"{procs} processes x {per} threads, {what} x {n_samples} samples, {phase}, ~{budget_s * 0.6:.0f} s, "
+                                  f"torch {torch.__version__} CPU fp32")
     return out
 
 
