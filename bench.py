@@ -332,7 +332,10 @@ def measure(phase, mode, n_rays, n_samples, steps, warmup, world, rank, dev, wan
     if phase == "train":
         measure.schedule.update(lr=float(stepper.lr), epoch=int(stepper.current_epoch()))
         measure.collective = {"in_graph": bool(getattr(stepper, "_adam_in_graph", False) and stepper._collective),
-                              "capture_failed": bool(getattr(stepper, "_collective_capture_failed", False))}
+                              "capture_failed": bool(getattr(stepper, "_collective_capture_failed", False)),
+                              # r06: the N > 1 step = the N = 1 step split at the collective (forward | dX | wgrad | sr_grad_tail, all-reduce,
+                              # sr_adam_step_pack: no sr_pack_all, no separate Adam launch)
+                              "update_repacks": bool(getattr(stepper, "_pack_in_tail", False))}
     return dt, kernels, fmt
 
 

@@ -58,6 +58,7 @@ def test_bench_contract_with_two_ranks_sharing_the_gpu():
     c = d["comm"]
     assert c["rccl_ranks"] == 2 and c["backend"] == "gloo" and c["allreduce_us"] > 0 and c["allreduce_bytes"] == (662537 + 120) * 4
     assert c["in_graph"] is False and c["capture_failed"] is False
+    assert c["update_repacks"] is True  # r06: the N > 1 step is the N = 1 step split at the collective (no sr_pack_all, one update launch)
     assert d["schedule"]["steps_per_epoch"] >= 1 and d["schedule"]["warming_up"] is False and d["schedule"]["epoch"] >= 2
     assert d["provenance"]["lib"].endswith("libsatrender.so") and d["config"]["global_batch"] == 2048
     # strong scaling: the same global batch split over the ranks
