@@ -89,9 +89,16 @@ __device__ __forceinline__ void ws_store(uint4* p, const uint4& v) {
   asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(p));
   return;
 #endif
+#ifdef SR_WS_TEMPORAL  // A/B (tools/ab_nt.sh): default cache policy on the workspace traffic of this translation unit
+  *reinterpret_cast<u32x4_native*>(p) = __builtin_bit_cast(u32x4_native, v);
+  return;
+#endif
   __builtin_nontemporal_store(__builtin_bit_cast(u32x4_native, v), reinterpret_cast<u32x4_native*>(p));
 }
 __device__ __forceinline__ uint4 ws_load(const uint4* p) {
+#ifdef SR_WS_TEMPORAL
+  return *p;
+#endif
   return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_native*>(p)));
 }
 __device__ __forceinline__ uint4 ws_load_cached(const uint4* p) { return *p; }

@@ -159,7 +159,15 @@ def train_one(arm, run, steps, batch, bank_steps, n_eval, every, dev, verbose=Tr
                                 val.zero_()
                 torch.cuda.synchronize()
             except Exception as e:  # noqa: BLE001
-                print(f"ref run {run}: graph capture failed ({type(e).__name__}: {e}); eager steps", file=sys.stderr)
+                import traceback
+
+                tb = traceback.extract_tb(e.__traceback__)
+                where = "; ".join(f"{os.path.basename(f.filename)}:{f.lineno} {f.name}" for f in tb[-6:])
+                print(f"ref run {run}: graph capture failed ({type(e).__name__}: {str(e).splitlines()[0]}) at {where}; eager steps", file=sys.stderr)
+                try:
+                    torch.cuda.synchronize()
+                except Exception:  # noqa: BLE001
+                    pass
                 graph = None
                 po = {k: v.clone().to(dev).requires_grad_(True) for k, v in init.items()}
                 eo = emb_init.clone().to(dev).requires_grad_(True)
