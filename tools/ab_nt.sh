@@ -9,7 +9,7 @@
 set -e
 root=$(cd "$(dirname "$0")/.." && pwd); c=$root/satnerf_amd/csrc; v=$root/build_variants/nt; mkdir -p $v
 CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment"
-link() { name=$1; shift; /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $c/build/*.o | grep -v -e "/$2.o") $v/$name.o -o $root/build_variants/lib_$name.so; echo built lib_$name.so; }
+link() { name=$1; excl=$2; /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $c/build/*.o | grep -v -e "/$excl.o") $v/$name.o -o $root/build_variants/lib_$name.so; echo built lib_$name.so; }
 # dX
 sed -e '/global_store_dwordx4/s/ nt\\n/\\n/' $c/mlp_bwd_trunk_a1.inc > $v/trunk_st_a1.inc
 sed -e 's/ nt\\n/\\n/' $c/mlp_bwd_trunk_a1.inc > $v/trunk_all_a1.inc

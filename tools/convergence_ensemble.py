@@ -130,6 +130,41 @@ def train_one(arm, run, steps, batch, bank_steps, n_eval, every, dev, verbose=Tr
         # capturable -- the same arithmetic) a 20,000-step run takes about a fifth of the time.  CONV_REF_GRAPH=0 or a failed capture: eager.
         graph, static = None, None
         if os.environ.get("CONV_REF_GRAPH", "1") == "1":
+            # Two of autograd's backward formulas synchronise with the host and cannot be captured; both are replaced by the SAME arithmetic
+            # without the synchronisation (the oracle's code is untouched, forward values are bit-identical):
+            #  * cumprod (the transmittance, models/satnerf.py:62): torch's backward first asks the host whether the input holds a zero
+            #    (`.any().item()`) and then, without zeros, returns reversed_cumsum(grad * out) / input -- the input here is 1 - alpha + 1e-10
+            #    >= 1e-10, never zero, so that branch is the one eager mode takes; _Cumprod below is that branch;
+            #  * emb[ts] (rendering.py:100): index_put_(accumulate=True) sorts through thrust; F.embedding's backward (same gather forward,
+            #    same sums into the 30 rows) does not.
+            class _Cumprod(torch.autograd.Function):
+                @staticmethod
+                def forward(ctx, x, dim):
+                    out = _torch_cumprod(x, dim)
+                    ctx.save_for_backward(x, out)
+                    ctx.dim = dim
+                    return out
+
+                @staticmethod
+                def backward(ctx, g):
+                    x, out = ctx.saved_tensors
+                    d = ctx.dim
+                    return (g * out).flip(d).cumsum(d).flip(d) / x, None
+
+            class _Rows:
+                def __init__(self, w):
+                    self.w = w
+
+                def __getitem__(self, idx):
+                    return torch.nn.functional.embedding(idx, self.w)
+
+            class _Emb:
+                def __init__(self, w):
+                    self.weight = _Rows(w)
+
+            _torch_cumprod = torch.cumprod
+            torch.cumprod = lambda x, dim=-1, **kw: _Cumprod.apply(x, dim)
+            mo = {"coarse": po, "t": _Emb(eo)}
             try:
                 opt = torch.optim.Adam(list(po.values()) + [eo], lr=5e-4, capturable=True)
                 static = [rays[:batch].clone(), ts[:batch].clone(), rgbs[:batch].clone(), d_rays[:batch].clone(), d_ts[:batch].clone(),
@@ -169,6 +204,7 @@ def train_one(arm, run, steps, batch, bank_steps, n_eval, every, dev, verbose=Tr
                 except Exception:  # noqa: BLE001
                     pass
                 graph = None
+                torch.cumprod = _torch_cumprod
                 po = {k: v.clone().to(dev).requires_grad_(True) for k, v in init.items()}
                 eo = emb_init.clone().to(dev).requires_grad_(True)
                 mo = {"coarse": po, "t": eo}
@@ -194,6 +230,8 @@ def train_one(arm, run, steps, batch, bank_steps, n_eval, every, dev, verbose=Tr
                 out[k + 1] = mae(d)
                 if verbose:
                     print(f"ref run {run} step {k + 1}: MAE vs truth {out[k + 1]:.3f} m  ({time.time() - t0:.0f} s, {'graph' if graph is not None else 'eager'})", file=sys.stderr)
+        if graph is not None:
+            torch.cumprod = _torch_cumprod
     else:
         args_hip = O.default_args(mlp_mode="bf16", ds_lambda=ds_lambda)
         model = load_model(args_hip)

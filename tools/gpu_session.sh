@@ -18,5 +18,8 @@ for r in 1 2; do
 done
 } > gpurun_out/ab_r06c.txt 2>&1
 cat gpurun_out/ab_r06c.txt
-python tools/convergence_ensemble.py run --arm ref --run 0 --steps 200 --every 50 2>&1 | grep -v amdgpu.ids | cut -c1-900 > gpurun_out/ens_graph_check.txt
+{
+python tools/convergence_ensemble.py run --arm ref --run 0 --steps 300 --every 100 2>&1 | grep -v amdgpu.ids | cut -c1-900
+CONV_REF_GRAPH=0 python tools/convergence_ensemble.py run --arm ref --run 0 --steps 300 --every 100 2>&1 | grep -v amdgpu.ids | cut -c1-400
+} > gpurun_out/ens_graph_check.txt
 cat gpurun_out/ens_graph_check.txt
