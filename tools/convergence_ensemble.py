@@ -181,9 +181,20 @@ def train_one(arm, run, steps, batch, bank_steps, n_eval, every, dev, verbose=Tr
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 opt.zero_grad(set_to_none=True)
-                with torch.cuda.graph(graph):
-                    step_math(*static).backward()
-                    opt.step()
+                if os.environ.get("CONV_REF_GRAPH_EAGER", "0") == "1":
+                    # check mode: the SAME patched formulas, static buffers and capturable Adam, every step launched eagerly -- a faithful
+                    # capture reproduces this run (same kernels in the same order)
+                    class _EagerGraph:
+                        def replay(self_inner):
+                            opt.zero_grad(set_to_none=True)
+                            step_math(*static).backward()
+                            opt.step()
+
+                    graph = _EagerGraph()
+                else:
+                    with torch.cuda.graph(graph):
+                        step_math(*static).backward()
+                        opt.step()
                 # the warm-up stepped the optimizer: start the run from the initial weights and fresh moments
                 with torch.no_grad():
                     for v, v0 in zip(list(po.values()) + [eo], snap):
