@@ -439,6 +439,8 @@ class Core:
             drop |= {"nop"}
         if "nostore" in ab:   # (saving cores) the workspace stores and their address steps
             drop |= {"store", "store2", "soff"}
+        if "storesame" in ab:  # (saving cores) every store of a wave lands on the wave's FIRST unit: the store instructions and their vmcnt
+            drop |= {"soff"}   # bookkeeping stay, the 196 MB of HBM traffic become 2 MB of L2 traffic
         if "noenc" in ab:     # (saving cores) the PHASE8 / MX8 encodes of the saved state
             drop |= {"phase", "mx_max", "mx_e1", "mx_e2", "mx_e3a", "mx_e3", "mx_e4", "mx_e5", "mx_e6", "mx_q1", "mx_q2"}
         if "empty" in ab:
@@ -739,7 +741,7 @@ def main():
 
     ap = argparse.ArgumentParser(description=__doc__)
     ap.add_argument("--out", default=None, help="output directory (default: csrc/)")
-    ap.add_argument("--ablate", default="", help="comma list of timing ablations: nodma,nobarrier,nosync,noepi,noread,nowaitl,nonop,nostore,noenc")
+    ap.add_argument("--ablate", default="", help="comma list of timing ablations: nodma,nobarrier,nosync,noepi,noread,nowaitl,nonop,nostore,storesame,noenc")
     ap.add_argument("--R", type=int, default=128)
     ap.add_argument("--PF", type=int, default=5)
     ap.add_argument("--GROUP", type=int, default=2)

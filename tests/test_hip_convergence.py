@@ -30,3 +30,26 @@ def test_bf16_training_reaches_the_reference_depth_mae():
     # them by ~3 cm (SURVEY.md section 6 predicted 1.7-2.2 cm at init): DSM extraction should run in bf16x3 or f16
     r0 = res["rows"][0]
     assert r0["mae_infer_bf16x3_m"] < 0.002 and r0["mae_infer_f16_m"] < 0.02 and r0["mae_infer_bf16_m"] < 0.10, r0
+
+
+def test_ensemble_statistic_short_version():
+    """g1 as a statistical statement (the full study: tools/convergence_ensemble.py, profiles/r06_convergence_ensemble.json --
+    8 + 8 independent trainings of 20,000 steps).  The short version of the SAME statistic: 3 trainings per arm (HIP bf16 / 8-bit state vs the
+    fp32 oracle), each on its own initialisation and jitter, 600 steps, final metric = mean MAE of the last three checkpoints.  Gate: the
+    difference of the two ensembles' means is not distinguishable from zero (its 95 % Welch interval contains 0), both arms learn the surface,
+    and the helper statistics behave (the interval is centred on the difference and widens with the spread)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import convergence_ensemble as ce
+
+    s = ce.short_study(k=3, steps=600)
+    print(json.dumps({k: v for k, v in s.items() if k != "runs"}), s["runs"])
+    assert all(m < 5.0 for arm in s["runs"].values() for m in arm), s["runs"]   # untrained: ~40 m
+    lo, hi = s["ci95_m"]
+    assert lo <= s["delta_mean_m"] <= hi and abs((lo + hi) / 2 - s["delta_mean_m"]) < 1e-9
+    assert not s["ci_excludes_zero"], s
+    # the statistics themselves (no GPU involved): known answers
+    w = ce.welch([1.0, 2.0, 3.0], [2.0, 3.0, 4.0])
+    assert abs(w["delta"] + 1.0) < 1e-12 and abs(w["df"] - 4.0) < 1e-9 and abs(w["se"] - (2.0 / 3.0) ** 0.5) < 1e-12
+    assert abs(ce.t975(4) - 2.776) < 1e-9 and 1.96 < ce.t975(1e6) < 1.961
+    tight = ce.summarise([0.500, 0.501, 0.499, 0.500], [0.505, 0.506, 0.504, 0.505])
+    assert tight["ci_inside_bar"] and tight["ci_excludes_zero"] and not tight["bar_inside_ci"]
