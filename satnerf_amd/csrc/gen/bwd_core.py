@@ -256,6 +256,7 @@ class Trunk:
             if delta:
                 self.e("soff", (delta,), f"v_add_u32 v{SOFF}, 0x{delta & 0xffffffff:x}, v{SOFF}")
             self.e("store", (sv, unit), f"global_store_dwordx4 v{SOFF}, v[{sv}:{sv + 3}], %[db] nt")
+        store.is_store = True
         it.append(store)
         if t == MT - 1:
             grp = l - 1   # the layer's MT scale bytes: group l - 1 -> unit kD8Scale + (l - 1) / groups per unit, its slot of the lane's 16 bytes
@@ -292,6 +293,12 @@ class Trunk:
         return it
 
     def emit_item(self, f):
+        if "storelate" in self.ablate and getattr(f, "is_store", False) and not self.last_sync_done:
+            # experiment (correct results): a tile's dpre store, due now, is held back until the gap behind the NEXT counted vmcnt wait (which
+            # cannot tell stores from loads): it is then most of a tile old, not two MFMAs, when the following wait comes.  Its quad (SV, one of
+            # two) is not written again before the epilogue after next.
+            self.late.append([self.syncs_done + 1, f, self.cur_tile])
+            return 0
         n0 = len(self.ins)
         f()
         return len(self.ins) - n0
@@ -362,12 +369,16 @@ class Trunk:
             read_for(i)
             dsread(i)
         epi = []          # [earliest gap, closure, tile]
+        self.late, self.syncs_done, self.cur_tile, self.last_sync_done = [], 0, 0, False   # (storelate) deferred stores: [rendezvous count after which they go out, closure]
         for i in range(N):
             ti, k = mf[i]
             l = g.L0 - ti // MT
             inp = g.X if (g.L0 - l) % 2 == 0 else g.Y
             acc = g.ACC[ti & 1]
+            self.cur_tile = ti
             if k == 0:
+                while self.late and self.late[0][2] <= ti - 2:   # (storelate) no rendezvous came (the stream's end): out before its quad is rewritten
+                    self.late.pop(0)[1]()
                 # the tile before last's epilogue still reads this accumulator: it must be out (and every B fragment of a new layer
                 # is produced by the previous layer's epilogues: the last tile's runs during this tile, its two k-steps come last)
                 while epi and epi[0][2] <= ti - 2:
@@ -388,8 +399,12 @@ class Trunk:
             # ---- gap(i)
             if i + PF < N:
                 if read_for(i + PF):
+                    self.syncs_done += 1
+                    self.last_sync_done = sync_done_for >= NT - 1   # (storelate) no further rendezvous: stores go out when due again
                     allow_rows(first_piece[ti])   # the barrier proves every wave has issued MFMA i: all tiles before the current one are consumed
                 dsread(i + PF)
+            while self.late and self.late[0][0] <= self.syncs_done:
+                self.late.pop(0)[1]()
             if k == 0 and ti + 2 < NT:
                 self.phase_load(ti + 2)
             if pending:
@@ -402,6 +417,8 @@ class Trunk:
             self.e("nop", (3,), "s_nop 3")
         while epi:
             self.emit_item(epi.pop(0)[1])
+        while self.late:   # (storelate) the last tiles' stores
+            self.late.pop(0)[1]()
         assert not pending and rows_issued == n_rows
         self.e("waitall", (), "s_waitcnt vmcnt(0) lgkmcnt(0)")
         self.e("restm0", (), "s_mov_b32 m0, %[m0save]")

@@ -228,14 +228,27 @@ class Core:
                 # quad by an SDWA add BEFORE the value's sin overwrites the accumulator; cvt_pk one pair behind (trans -> VALU use)
                 sv = SV[self.n_saves & 1]
                 self.n_saves += 1
-                for q in range(8):
-                    for g in (2 * q, 2 * q + 1):
+                if "phasefirst" in self.ablate and ti % self.GROUP == self.GROUP - 1:   # (its epilogue runs in a tile that holds no counted wait)
+                    # experiment (correct results): all 16 PHASE8 bytes first, the store right behind them -- it is then ~8 MFMAs older when
+                    # the next counted vmcnt wait (which cannot tell stores from LDS-DMA loads) comes -- then the sines and packs
+                    for g in range(16):
                         epi_q.append([g0, "phase", (sv + (g >> 2), g & 3, a + g)])
-                        epi_q.append([g0, "sin", (a, g, t.out)])
-                    if q > 0:
-                        epi_q.append([g0, "pk", (a, q - 1, t.out)])
-                epi_q.append([g0, "store", (sv, t.save_unit)])
-                epi_q.append([g0, "pk", (a, 7, t.out)])
+                    epi_q.append([g0, "store", (sv, t.save_unit)])
+                    for q in range(8):
+                        for g in (2 * q, 2 * q + 1):
+                            epi_q.append([g0, "sin", (a, g, t.out)])
+                        if q > 0:
+                            epi_q.append([g0, "pk", (a, q - 1, t.out)])
+                    epi_q.append([g0, "pk", (a, 7, t.out)])
+                else:
+                    for q in range(8):
+                        for g in (2 * q, 2 * q + 1):
+                            epi_q.append([g0, "phase", (sv + (g >> 2), g & 3, a + g)])
+                            epi_q.append([g0, "sin", (a, g, t.out)])
+                        if q > 0:
+                            epi_q.append([g0, "pk", (a, q - 1, t.out)])
+                    epi_q.append([g0, "store", (sv, t.save_unit)])
+                    epi_q.append([g0, "pk", (a, 7, t.out)])
             elif self.save and t.save_unit is not None and t.epi == "id":
                 # MX8: E = exponent of 1.0079 max|v| clamped to [6, 254]; u = cvt_pk_u8(v * 2^(133 - E) + 128); byte t of EB = E
                 sv = SV[self.n_saves & 1]

@@ -293,7 +293,8 @@ class Machine:
 def test_instruction_stream_computes_the_trunk(feat, tau):
     gen = _gen()
     auxs = packing.aux_steps(tau)
-    trunk = gen.Trunk(auxs, feat=feat)
+    # (SR_BWD_ABLATE: run the lane model on an experimental ordering of the same stream, e.g. storelate, before it goes to the GPU)
+    trunk = gen.Trunk(auxs, feat=feat, ablate=tuple(x for x in os.environ.get("SR_BWD_ABLATE", "").split(",") if x))
     G = trunk.g
     KS, MT = G.KS, G.MT
     bm = packing.backward_maps(feat, tau)

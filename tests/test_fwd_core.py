@@ -39,7 +39,8 @@ def test_generated_files_are_current(auxs, save):
 def test_instruction_stream_computes_the_forward_pass(tau, save):
     g = _gen()
     auxs = g.aux_steps(tau)
-    core = g.Core(auxs, save=save)
+    # (SR_FWD_ABLATE: run the lane model on an experimental ordering of the same stream, e.g. phasefirst, before it goes to the GPU)
+    core = g.Core(auxs, save=save, ablate=tuple(x for x in os.environ.get("SR_FWD_ABLATE", "").split(",") if x))
     params = O.procedural_satnerf_params(256, tau, seed=3)
     flat = np.concatenate([v.numpy().reshape(-1) for v in params.values()]).astype(np.float32)
     em = E.Emulator(flat, 256, tau, bf16=True, l0_split=True)
