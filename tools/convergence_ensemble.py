@@ -224,7 +224,9 @@ def train_one(arm, run, steps, batch, bank_steps, n_eval, every, dev, verbose=Tr
         for k in range(steps):
             b = k % bank_steps
             sl = slice(b * batch, (b + 1) * batch)
-            u_c, u_d = (u.to(dev, non_blocking=True) for u in _jitter(seed, k, batch))
+            # (blocking copies: with a captured step the host runs many steps ahead of the device, and an asynchronous copy out of pageable
+            # memory that the next draw re-uses would deliver the NEXT step's numbers -- the first r06 attempt did exactly that)
+            u_c, u_d = (u.to(dev) for u in _jitter(seed, k, batch))
             batch_now = (rays[sl], ts[sl], rgbs[sl], d_rays[sl], d_ts[sl], depths[sl], u_c, u_d)
             if graph is not None:
                 for dst, src in zip(static, batch_now):

@@ -22,3 +22,10 @@ for v in fwd_phasefirst bwd_storelate; do
 done
 } > gpurun_out/ab_r06d.txt 2>&1
 cat gpurun_out/ab_r06d.txt
+./build_variants/probe_war > gpurun_out/probe_war.txt 2>&1; cat gpurun_out/probe_war.txt
+{
+echo "== is the captured oracle step faithful?  graph replay vs the same patched step launched eagerly (same seed, 300 steps)"
+python tools/convergence_ensemble.py run --arm ref --run 0 --steps 300 --every 100 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-400
+CONV_REF_GRAPH_EAGER=1 python tools/convergence_ensemble.py run --arm ref --run 0 --steps 300 --every 100 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-400
+} > gpurun_out/ens_graph_check.txt
+cat gpurun_out/ens_graph_check.txt
