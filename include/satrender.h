@@ -242,8 +242,9 @@ int sr_satnerf_wgrad(int feat, int tau, int64_t n_points, const uint16_t* dpre, 
  * r02 kernel cost-weighted ones.
  * plan_span = int 11 of the planned table's first row (sr_wgrad_plan): 0 = one slice per workgroup; > 0 = a stream-K plan (the 4-wave kernel
  * walks `plan_span` tile units of the block-major job list per workgroup, writing one partial block per block it touches). */
-int sr_satnerf_wgrad8(int feat, int tau, int64_t n_points, const uint16_t* dpre, const uint16_t* acts, const int32_t* blocks,
-                      const int32_t* loads, int n_blocks, int n_slices, int plan_span, float* partial, void* stream);
+/* dpre_elems = 16-bit elements the caller's dpre buffer holds: rejected below sr_dpre_workspace_elems(n_points, feat, SR_FMT8) */
+int sr_satnerf_wgrad8(int feat, int tau, int64_t n_points, const uint16_t* dpre, int64_t dpre_elems, const uint16_t* acts,
+                      const int32_t* blocks, const int32_t* loads, int n_blocks, int n_slices, int plan_span, float* partial, void* stream);
 int sr_wgrad8_load_ints(void);
 
 /* parameter gradients of the sky head (atomicAdd into g_*; zero them first) and of the embedding table

@@ -76,7 +76,7 @@ SIGNATURES = {
     "sr_wgrad_plan": (_i, [_vp, _i, _i64, _i, _i, _vp]),
     "sr_satnerf_mlp_bwd": (_i, [_i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sr_satnerf_wgrad": (_i, [_i, _i, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp]),
-    "sr_satnerf_wgrad8": (_i, [_i, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "sr_satnerf_wgrad8": (_i, [_i, _i, _i64, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "sr_wgrad8_load_ints": (_i, []),
     "sr_sky_bwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sr_embedding_bwd": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),

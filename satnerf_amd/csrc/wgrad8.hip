@@ -273,10 +273,13 @@ bool wgrad9_fits(long n_tiles, int ak, int dk);
 }
 using namespace sr;
 
-extern "C" int sr_satnerf_wgrad8(int feat, int tau, int64_t n_points, const uint16_t* dpre, const uint16_t* acts, const int32_t* blocks,
-                                 const int32_t* loads, int n_blocks, int n_slices, int plan_span, float* partial, void* stream) {
+extern "C" int sr_satnerf_wgrad8(int feat, int tau, int64_t n_points, const uint16_t* dpre, int64_t dpre_elems, const uint16_t* acts,
+                                 const int32_t* blocks, const int32_t* loads, int n_blocks, int n_slices, int plan_span, float* partial, void* stream) {
   SR_REQUIRE(feat == 256 || feat == 512, "sr_satnerf_wgrad8: feat=%d unsupported (256, 512)", feat);
   SR_REQUIRE(dpre && acts && blocks && loads && partial, "sr_satnerf_wgrad8: null pointer argument");
+  // the default kernel reads the table of exponent maxima BEHIND the last tile (a buffer of tiles x sr_dpre_elems_per_tile is too short)
+  SR_REQUIRE(dpre_elems >= sr_dpre_workspace_elems(n_points, feat, SR_FMT8), "sr_satnerf_wgrad8: dpre holds %lld elements, sr_dpre_workspace_elems asks for %lld",
+             (long long)dpre_elems, (long long)sr_dpre_workspace_elems(n_points, feat, SR_FMT8));
   SR_REQUIRE(n_blocks >= 1 && n_slices >= n_blocks && plan_span >= 0, "sr_satnerf_wgrad8: bad plan (%d blocks, %d slices, span %d): run sr_wgrad_plan first",
              n_blocks, n_slices, plan_span);
   Wgrad8Params p;

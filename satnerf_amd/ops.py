@@ -499,7 +499,7 @@ def wgrad_partials(feat, tau, n_points, dpre, acts, blocks, fmt=16, loads=None):
     if ev:
         ev[0].record()
     if int(fmt) == 8:
-        _lib.call("sr_satnerf_wgrad8", feat, tau, n_points, _p(dpre), _p(acts), _p(plan), _p(_chk(loads, "loads", torch.int32)), plan.shape[0], n_slices,
+        _lib.call("sr_satnerf_wgrad8", feat, tau, n_points, _p(dpre), dpre.numel(), _p(acts), _p(plan), _p(_chk(loads, "loads", torch.int32)), plan.shape[0], n_slices,
                   span, _p(partial), _stream())
     else:
         _lib.call("sr_satnerf_wgrad", feat, tau, n_points, _p(dpre), _p(acts), _p(plan), plan.shape[0], n_slices, _p(partial), _stream())

@@ -33,7 +33,7 @@ def make(n_wg):
         k = int(os.environ["AB_SPLITS"]); plan = plan.clone(); plan[:, 9] = k; plan[:, 10] = torch.arange(plan.shape[0], device=plan.device, dtype=plan.dtype) * k; n_slices = k * plan.shape[0]
     partial = torch.empty(n_slices * (256 * 256 + 256 * 32), dtype=torch.float32, device=dev)
     ld = loads[sel].contiguous() if os.environ.get("AB_BLOCKS") else loads
-    return n_slices, lambda: _lib.call("sr_satnerf_wgrad8", 256, 4, n_points, dpre.data_ptr(), acts.data_ptr(), plan.data_ptr(), ld.data_ptr(), plan.shape[0],
+    return n_slices, lambda: _lib.call("sr_satnerf_wgrad8", 256, 4, n_points, dpre.data_ptr(), dpre.numel(), acts.data_ptr(), plan.data_ptr(), ld.data_ptr(), plan.shape[0],
                                        n_slices, span, partial.data_ptr(), torch.cuda.current_stream().cuda_stream)
 for n_wg in n_wgs:
     n_slices, run = make(n_wg)
