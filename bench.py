@@ -43,7 +43,7 @@ KERNEL_NAMES = {"mlp_fwd": "satnerf_fwd2_kernel (one-launch training forward: st
                            "compositing + loss + compositing backward)",
                 "mlp_bwd": "satnerf_bwd_kernel (fused dX chain, generated trunk)", "wgrad": "wgrad9_kernel (weight-gradient GEMMs)"}
 PMC_ROWS = {"mlp_fwd": "satnerf_fwd", "mlp_bwd": "satnerf_bwd_kernel", "wgrad": "wgrad"}
-PMC_FILE = os.path.join("profiles", "r05_train_pmc.csv")
+PMC_FILE = os.path.join("profiles", "r06_train_pmc.csv")
 MIN_WARM_S = 0.05                 # wall time every leg keeps the device busy before its clock starts (clocks, caches)
 
 

@@ -1,5 +1,13 @@
 #!/bin/bash
-# one GPU-box session of round 6: the g1 ensemble study, sequential.
-mkdir -p gpurun_out
+# final GPU-box session of round 6: 24 more HIP trainings of the ensemble study, full test suite, profiles, the default bench line, interleaved r05-vs-r06 A/B.
+mkdir -p gpurun_out/ens32
 export PYTHONDONTWRITEBYTECODE=1
-timeout 3300 bash tools/run_ensemble.sh 8 20000 2>&1 | tail -12
+for r in $(seq 8 31); do python tools/convergence_ensemble.py run --arm hip --run $r --steps 20000 > gpurun_out/ens32/hip_$r.json 2> gpurun_out/ens32/hip_$r.err; done
+ls gpurun_out/ens32 | wc -l
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/gputest_final.log 2>&1; echo "pytest rc $?" >> gpurun_out/gputest_final.log
+tail -3 gpurun_out/gputest_final.log
+bash tools/collect_profiles3.sh r06 > gpurun_out/collect_r06.log 2>&1; tail -14 gpurun_out/collect_r06.log
+cp gpurun_out/profiles_r06/train_pmc.csv profiles/r06_train_pmc.csv
+python bench.py > gpurun_out/r06_bench_train.json 2> gpurun_out/bench_final.err; tail -c 400 gpurun_out/r06_bench_train.json
+bash tools/ab_trees.sh 3 > gpurun_out/r06_ab_round.txt 2>&1; cat gpurun_out/r06_ab_round.txt
+echo "width 512, eager kernel timings:" $(AB_WIDTH=512 python tools/ab_step.py 2>/dev/null | head -1) > gpurun_out/w512_step.txt; cat gpurun_out/w512_step.txt
