@@ -154,8 +154,7 @@ def cpu_baseline(phase, n_rays, n_samples, budget_s=10.0):
     2.6 rays/s at 256 threads), so the best setting uses 16 of the host's threads;  (b) r06: the batch SHARDED over host_cpus / 16
     processes of 16 threads each (every process renders and back-propagates its slice of the rays, started together) -- all of the host's
     hardware threads at work on one batch (measured: SLOWER than (a), 882 against 2,028 rays/s on a 256-thread host: 64-ray shards are
-    too small for 16 threads);  (c) the same fleet with one whole batch per process -- data-parallel replicas, the CPU counterpart of
-    N GPUs.  `value` is the best of the three; all are reported."""
+    too small for 16 threads).  `value` is the better of the two; both are reported."""
     import subprocess
 
     cores = os.cpu_count() or 1
@@ -178,7 +177,7 @@ def cpu_baseline(phase, n_rays, n_samples, budget_s=10.0):
     out = {"value": single, "unit": "rays/s", "cores": best_thr, "host_cpus": cores, "kind": "port",
            "sample": f"{it} x {n} rays x {n_samples} samples, {phase}, torch {torch.__version__} CPU fp32",
            "single_process": {"value": single, "threads": best_thr, "sweep_rays_per_s": {str(k): round(v, 1) for k, v in sweep.items()}}}
-    # (b) the batch sharded over processes, (c) one whole batch per process (what N GPUs do: data-parallel replicas)
+    # (b) the batch sharded over processes
     per = 16 if cores >= 32 else max(cores // 2, 1)
     procs = max(min(cores // per, n // 8), 1)
 
@@ -198,8 +197,9 @@ def cpu_baseline(phase, n_rays, n_samples, budget_s=10.0):
         return (sum(rates), round(time.time() - t0, 1)) if len(rates) == procs else (None, None)
 
     if procs > 1:
-        for key, rays_each, what in (("sharded", n // procs, f"each {n // procs} of the batch's {n} rays"),
-                                     ("replicas", n, f"each its own {n}-ray batch (data-parallel replicas)")):
+        # (a third leg -- the same fleet with one WHOLE batch per process, data-parallel replicas -- was measured once on the 256-thread host
+        #  and dropped: 575 rays/s in all, 73 s of wall time for one timed pass per process; profiles/r06_bench_train.json keeps that record)
+        for key, rays_each, what in (("sharded", n // procs, f"each {n // procs} of the batch's {n} rays"),):
             rate, wall = fleet(rays_each, budget_s * 0.6)
             if rate is None:
                 continue

@@ -16,9 +16,8 @@ def test_cpu_baseline_reports_the_sweep_and_the_sharded_leg(monkeypatch):
     # r06: the batch sharded over processes (here 2 x 1 thread, 8 rays each), started together; `value` = the better of the two legs
     sh = r["sharded"]
     assert sh["processes"] == 2 and sh["threads_per_process"] == 1 and sh["rays_per_process"] == 8 and sh["value"] > 0
-    rp = r["replicas"]   # ... and as data-parallel replicas (a whole 16-ray batch per process)
-    assert rp["processes"] == 2 and rp["rays_per_process"] == 16 and rp["value"] > 0
-    assert r["value"] == max(sp["value"], sh["value"], rp["value"]) and r["cores"] in (3, 2)
+    assert "replicas" not in r   # (one whole batch per process: measured once, 575 rays/s on 256 threads, dropped)
+    assert r["value"] == max(sp["value"], sh["value"]) and r["cores"] in (3, 2)
     assert "x 8 samples" in r["sample"] and "forward" in r["sample"]
 
 
