@@ -89,7 +89,7 @@ def summarise(finals_hip, finals_ref, bar_m=0.02):
             "bar_inside_ci": bool(lo <= -bar_m or hi >= bar_m)}
 
 
-def train_one(arm, run, steps, batch, bank_steps, n_eval, every, dev, verbose=True):
+def train_one(arm, run, steps, batch, bank_steps, n_eval, every, dev, verbose=True, ncp=3):
     """one training of the scene; returns {checkpoint: MAE vs the true surface in metres}"""
     from oracle import satnerf_oracle as O
     from satnerf_amd import rendering
@@ -98,7 +98,7 @@ def train_one(arm, run, steps, batch, bank_steps, n_eval, every, dev, verbose=Tr
 
     ds_lambda = 1000.0
     seed = ARM_OFFSET[arm] + run
-    cps = [c for c in (steps - 2 * every, steps - every, steps) if c > 0]
+    cps = [c for c in (steps - k * every for k in range(ncp - 1, -1, -1)) if c > 0]   # (final metric: the last three; ncp > 3: a finer trace of the run's end)
     n_bank = bank_steps * batch
     rays, ts, rgbs, _ = make_scene(n_bank, seed=SCENE_SEED + 1)
     d_rays, d_ts, _, d_depth = make_scene(n_bank, seed=SCENE_SEED + 2)
@@ -275,8 +275,9 @@ def train_one(arm, run, steps, batch, bank_steps, n_eval, every, dev, verbose=Tr
                 out[k + 1], out_bf16[k + 1] = mae(d), mae(d16)  # (secondary: the same weights rendered in single-pass bf16)
                 if verbose:
                     print(f"hip run {run} step {k + 1}: MAE vs truth {out[k + 1]:.3f} m  ({time.time() - t0:.0f} s)", file=sys.stderr)
+    last3 = [out[c] for c in sorted(out)[-3:]]
     res = {"arm": arm, "run": run, "seed": seed, "steps": steps, "batch": batch, "bank_steps": bank_steps, "checkpoints": {str(k): v for k, v in out.items()},
-           "final_m": sum(out.values()) / len(out), "seconds": time.time() - t0}
+           "final_m": sum(last3) / len(last3), "seconds": time.time() - t0}
     if arm == "hip":
         res["final_bf16_inference_m"] = sum(out_bf16.values()) / len(out_bf16)
     return res
@@ -302,7 +303,8 @@ def main():
     r.add_argument("--batch", type=int, default=256)
     r.add_argument("--bank-steps", type=int, default=2000)
     r.add_argument("--eval", type=int, default=2048)
-    r.add_argument("--every", type=int, default=1000, help="spacing of the last three checkpoints")
+    r.add_argument("--every", type=int, default=1000, help="spacing of the checkpoints")
+    r.add_argument("--ncp", type=int, default=3, help="number of checkpoints at the run's end (the final metric averages the last three)")
     c = sub.add_parser("combine")
     c.add_argument("files", nargs="+")
     s = sub.add_parser("short")
@@ -310,7 +312,7 @@ def main():
     s.add_argument("--steps", type=int, default=600)
     a = ap.parse_args()
     if a.cmd == "run":
-        print(json.dumps(train_one(a.arm, a.run, a.steps, a.batch, a.bank_steps, a.eval, a.every, torch.device("cuda:0"))))
+        print(json.dumps(train_one(a.arm, a.run, a.steps, a.batch, a.bank_steps, a.eval, a.every, torch.device("cuda:0"), ncp=a.ncp)))
     elif a.cmd == "short":
         print(json.dumps(short_study(a.k, a.steps)))
     else:
