@@ -93,7 +93,7 @@ THIN = {(1, True, "thin"): "t1", (3, False, "none"): "d3", (0, True, "thin"): "t
 
 
 class Stream:
-    def __init__(self, col_codec, ablate=(), main=True, thin=None):
+    def __init__(self, col_codec, ablate=(), main=True, thin=None, raw=True):
         assert col_codec in ("phase", "mx")
         self.col_codec = col_codec
         self.main = main               # False: a wave whose quadrant nobody reads (narrow blocks): aux tiles only, same loads / decode / rendezvous
@@ -105,7 +105,9 @@ class Stream:
             self.duties = list(range(self.n_df))
             self.ns = 0
         else:
-            self.n_df, self.raw, self.mfma_set = 4, True, ("full" if main else "aux")
+            # raw = False (r06): a wave of a full block whose raw duty is a dump (three of the four waves of most blocks) runs the stream without
+            # the raw fragment's load, conversion (21 VALU) and LDS write -- work nobody reads
+            self.n_df, self.raw, self.mfma_set = 4, bool(raw), ("full" if main else "aux")
             self.duties = [0, 2, 1, 3]                 # decode order: row, column, row, column
             self.ns = 2 if col_codec == "phase" else 4     # scale-byte loads per tile
         self.nld = self.n_df + self.ns + (1 if self.raw else 0)   # global loads per tile and wave
@@ -435,7 +437,7 @@ class Stream:
             e("s_nop 15", "salu")    # the last MFMAs' results -> the epilogue's v_accvgpr_read (inline asm is not hazard-padded)
 
     def inc_file(self):
-        kind = "" if self.thin is None else f"thin stream {self.thin}; "
+        kind = ("" if self.raw else "no raw duty; ") if self.thin is None else f"thin stream {self.thin}; "
         head = [f"// GENERATED by csrc/gen/wgrad9_loop.py -- do not edit.  {kind}Column codec: {self.col_codec}; {len(self.ins)} lines: "
                 + ", ".join(f"{v} {k}" for k, v in sorted(self.n.items()))]
         return "\n".join(head + ['"' + t + '\\n"' for t in self.ins]) + "\n"
@@ -456,6 +458,11 @@ def main():
     ablate = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ()
     for codec, tag in (("phase", "p"), ("mx", "m"), ("phase", "px"), ("mx", "mx")):
         s = Stream(codec, ablate=ablate, main=len(tag) == 1)
+        with open(os.path.join(out_dir, f"wgrad9_loop_{tag}{suffix}.inc"), "w") as f:
+            f.write(s.inc_file())
+        print(tag, s.n, len(s.ins), "LDS operations in flight at body ends:", [len(x) for x in s.states])
+    for codec, tag in (("phase", "pn"), ("mx", "mn"), ("phase", "pxn"), ("mx", "mxn")):   # the same four without the raw duty
+        s = Stream(codec, ablate=ablate, main=len(tag) == 2, raw=False)
         with open(os.path.join(out_dir, f"wgrad9_loop_{tag}{suffix}.inc"), "w") as f:
             f.write(s.inc_file())
         print(tag, s.n, len(s.ins), "LDS operations in flight at body ends:", [len(x) for x in s.states])

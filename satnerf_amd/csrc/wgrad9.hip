@@ -47,6 +47,7 @@ struct Wgrad9Params {
   int n_blocks;
   int ak, dk;  // 1-KiB units per tile of the activation / dpre workspace
   int load_ints;
+  int keep_dump_raw;   // A/B (SATNERF_WGRAD_NORAW=0): every full-stream wave runs its raw duty, dump or not (the r05 behaviour)
   int span;            // stream-K plans: tile units per workgroup (= int kWgSpan of the table's first row); 0 = one slice per workgroup
   long long* dbg;  // SR_W9_TIMING builds: per workgroup (shader cycles, 100-MHz ticks, tiles) of wave 0's slice loop
 };
@@ -324,6 +325,8 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   // a wave whose 128 x 128 quadrant nobody reads (narrow blocks: packing.wgrad9_duties' quadrant mask) runs the stream without the 32
   // main MFMAs and their operand reads: same loads, decode, rendezvous, aux tiles -- the time of a tile is unchanged, its energy is not
   const bool quad_on = (__builtin_amdgcn_readfirstlane(pairs[kPairs]) >> wave) & 1;
+  // a full-stream wave whose raw duty is a dump (no aux fragment, no bf16 row fragment for it) runs the variant without that duty
+  const bool has_raw = prm.keep_dump_raw || __builtin_amdgcn_readfirstlane(du[4 * kDutyInts + 2]) != kDumpFrag;
   if (variant == 1) {
     asm volatile(
 #include "wgrad9_loop_t1.inc"
@@ -367,6 +370,38 @@ __global__ void __launch_bounds__(256) wgrad9_kernel(const Wgrad9Params prm) {
   } else if (variant == 6) {
     asm volatile(
 #include "wgrad9_loop_d0.inc"
+        : SR_W9_OUTS
+        : SR_W9_INS
+        :
+#include "wgrad9_loop_clobbers.inc"
+    );
+  } else if (!has_raw && col_mx && quad_on) {   // (r06) full streams without the raw duty: this wave's raw duty is a dump
+    asm volatile(
+#include "wgrad9_loop_mn.inc"
+        : SR_W9_OUTS
+        : SR_W9_INS
+        :
+#include "wgrad9_loop_clobbers.inc"
+    );
+  } else if (!has_raw && col_mx) {
+    asm volatile(
+#include "wgrad9_loop_mxn.inc"
+        : SR_W9_OUTS
+        : SR_W9_INS
+        :
+#include "wgrad9_loop_clobbers.inc"
+    );
+  } else if (!has_raw && quad_on) {
+    asm volatile(
+#include "wgrad9_loop_pn.inc"
+        : SR_W9_OUTS
+        : SR_W9_INS
+        :
+#include "wgrad9_loop_clobbers.inc"
+    );
+  } else if (!has_raw) {
+    asm volatile(
+#include "wgrad9_loop_pxn.inc"
         : SR_W9_OUTS
         : SR_W9_INS
         :
@@ -475,6 +510,8 @@ int launch_wgrad9(const uint4* dpre, const uint4* acts, const uint4* emax, const
   p.dpre = (const char*)dpre, p.acts = (const char*)acts, p.emax = emax, p.blocks = blocks, p.loads = loads, p.partial = partial;
   p.n_tiles = n_tiles, p.n_blocks = n_blocks, p.ak = ak, p.dk = dk, p.load_ints = load_ints, p.span = span;
   p.dbg = nullptr;
+  static const bool noraw_off = [] { const char* e = getenv("SATNERF_WGRAD_NORAW"); return e && e[0] == '0'; }();
+  p.keep_dump_raw = noraw_off ? 1 : 0;
 #ifdef SR_W9_TIMING  // timing builds only (tools/ab_wgrad8.py passes the address of its stamp buffer): a product build never takes a pointer from the environment
   if (const char* dbg = getenv("SR_W9_DBG")) p.dbg = (long long*)strtoull(dbg, nullptr, 10);
 #endif

@@ -14,6 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GEN = os.path.join(ROOT, "satnerf_amd", "csrc", "gen", "wgrad9_loop.py")
 VARIANTS = [("phase", True, "p"), ("mx", True, "m"), ("phase", False, "px"), ("mx", False, "mx")]
+NORAW = [("phase", True, "pn"), ("mx", True, "mn"), ("phase", False, "pxn"), ("mx", False, "mxn")]   # r06: the same four without the raw duty
 
 
 def _gen():
@@ -30,6 +31,19 @@ def test_generated_files_are_current(codec, main, tag):
         assert f.read() == g.Stream(codec, main=main).inc_file(), "re-run satnerf_amd/csrc/gen/wgrad9_loop.py"
     with open(os.path.join(ROOT, "satnerf_amd", "csrc", "wgrad9_loop_clobbers.inc")) as f:
         assert f.read() == g.clobber_file()
+
+
+@pytest.mark.parametrize("codec,main,tag", NORAW)
+def test_noraw_files_are_current_and_one_duty_lighter(codec, main, tag):
+    g = _gen()
+    s = g.Stream(codec, main=main, raw=False)
+    with open(os.path.join(ROOT, "satnerf_amd", "csrc", f"wgrad9_loop_{tag}.inc")) as f:
+        assert f.read() == s.inc_file(), "re-run satnerf_amd/csrc/gen/wgrad9_loop.py"
+    _, bodies = _split(s.ins)
+    for b in bodies:
+        n = lambda pat: sum(bool(re.match(pat, t)) for t in b)  # noqa: E731
+        assert n(r"v_mfma_f32_32x32x16_f16") == (36 if main else 4) and n(r"ds_write_b128") == 8 and n(r"global_load_dwordx4") == 4
+        assert n(r"v_cvt_pk_f16_f32") == 0   # (the raw fragment's conversion is gone)
 
 
 def _thin_variants():
@@ -107,12 +121,17 @@ def test_iteration_shape(codec, main, tag):
         assert n(r"v_pk_fma_f16") == (16 if codec == "phase" else 32)
 
 
-@pytest.mark.parametrize("codec,main,tag", VARIANTS + [("phase", t, tag) for t, tag in (((1, True, "thin"), "t1"), ((3, False, "none"), "d3"),
+@pytest.mark.parametrize("codec,main,tag", VARIANTS + [(c, ("noraw", m), t) for c, m, t in NORAW] + [("phase", t, tag) for t, tag in (((1, True, "thin"), "t1"), ((3, False, "none"), "d3"),
                                                                                           ((0, True, "thin"), "t0"), ((2, True, "none"), "r2"),
                                                                                           ((2, False, "none"), "d2"), ((0, False, "none"), "d0"))])
 def test_lds_counter_discipline_across_the_back_edge(codec, main, tag):
     g = _gen()
-    s = g.Stream(codec, main=main) if isinstance(main, bool) else g.Stream(codec, thin=main)
+    if isinstance(main, bool):
+        s = g.Stream(codec, main=main)
+    elif main[0] == "noraw":
+        s = g.Stream(codec, main=main[1], raw=False)
+    else:
+        s = g.Stream(codec, thin=main)
     prologue, bodies = _split(s.ins)
     inflight = []  # LDS operations in issue order: (kind, destination registers)
     exec_one = False
@@ -408,8 +427,8 @@ def test_stream_computes_the_block_contraction(blk, nt, spread):
     assert (blk in packing.wgrad9_thin_blocks(256, 4)) == any(variants)
     def n_df_of(w):   # double-fragment duty slots wave w's stream executes
         return 4 if variants[w] == 0 else packing.WG9_THIN[variants[w] - 1][0]
-    def raw_of(w):
-        return True if variants[w] == 0 else packing.WG9_THIN[variants[w] - 1][1]
+    def raw_of(w):   # full streams: the wave runs the raw duty unless it is a dump (r06: the no-raw variants); thin streams: per variant
+        return int(duties[w, 4, 2]) != packing.WG9_DUMP_FRAG if variants[w] == 0 else packing.WG9_THIN[variants[w] - 1][1]
     ak, dk = packing.act8_units(1, 256), packing.dpre8_units(256)
     n_tiles = nt + 2                                   # two tiles beyond the slice: what the clamp logic may touch
     D0, A0 = 4096, 4096 + n_tiles * dk * 1024 + 4096   # byte addresses of the two workspaces in `mem`
@@ -489,7 +508,10 @@ def test_stream_computes_the_block_contraction(blk, nt, spread):
             if k < 4:
                 ops[f"sb{k}"] = base + (sc >> 4) * 1024 + (sc & 15)
             ops["wx" if k == 4 else f"w{k}"] = ring + dst * g.FRAG
-        stream = g.Stream("phase", thin=packing.WG9_THIN[variants[w] - 1]) if variants[w] else (s if (quad >> w) & 1 else sx)
+        if variants[w]:
+            stream = g.Stream("phase", thin=packing.WG9_THIN[variants[w] - 1])
+        else:   # wgrad9.hip's dispatch: column codec, quadrant on / off, raw duty or not
+            stream = g.Stream("mx" if col_mx else "phase", main=bool((quad >> w) & 1), raw=raw_of(w))
         wave = _Wave(stream.ins, ops, lds, mem, shared)
         lane = np.arange(64)
         src_unit = np.where(lane < 32, lane, 32 + ((lane - 8) & 31))
