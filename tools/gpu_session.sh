@@ -1,8 +1,12 @@
 #!/bin/bash
-# GPU-box session: (i) the layout probe, (ii) a finer trace of the runs' ends -- MAE every 250 steps over the last 5,000 -- for 8 HIP and 3 fp32 trainings of the ensemble
-# study (same seeds as runs 0.. of the study: the same trajectories), to see whether the end-of-run excursions two of the 32 HIP runs show belong to the arithmetic.
-mkdir -p gpurun_out/trace
+# final GPU-box session of round 6 (after the last kernel change): full test suite, profiles, the default bench line, interleaved r05-vs-r06 A/B.
+mkdir -p gpurun_out
 export PYTHONDONTWRITEBYTECODE=1
-./build_variants/probe_layout > gpurun_out/probe_layout.txt 2>&1; cat gpurun_out/probe_layout.txt
-for r in 8 23 0 1 2 3 4 5; do python tools/convergence_ensemble.py run --arm hip --run $r --steps 20000 --every 250 --ncp 21 > gpurun_out/trace/hip_$r.json 2> gpurun_out/trace/hip_$r.err; done
-for r in 0 1 2; do python tools/convergence_ensemble.py run --arm ref --run $r --steps 20000 --every 250 --ncp 21 > gpurun_out/trace/ref_$r.json 2> gpurun_out/trace/ref_$r.err; tail -1 gpurun_out/trace/ref_$r.err; done
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/gputest_final.log 2>&1; echo "pytest rc $?" >> gpurun_out/gputest_final.log
+tail -3 gpurun_out/gputest_final.log
+bash tools/collect_profiles3.sh r06 > gpurun_out/collect_r06.log 2>&1; tail -6 gpurun_out/collect_r06.log
+cp gpurun_out/profiles_r06/train_pmc.csv profiles/r06_train_pmc.csv
+python bench.py > gpurun_out/r06_bench_train.json 2> gpurun_out/bench_final.err; tail -c 300 gpurun_out/r06_bench_train.json
+bash tools/ab_trees.sh 4 > gpurun_out/r06_ab_round.txt 2>&1; cat gpurun_out/r06_ab_round.txt
+echo "width 512, eager kernel timings:" $(AB_WIDTH=512 python tools/ab_step.py 2>/dev/null | head -1) > gpurun_out/w512_step.txt; cat gpurun_out/w512_step.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
