@@ -1,6 +1,6 @@
 """The kernels behind the A/B switches stay correct: SATNERF_FWD_V1=1 (the hipcc-scheduled forward kernels of mlp_fwd.inc instead of the
 generated cores -- also the fallback when a workspace exceeds the generated streams' 32-bit offsets) and SATNERF_WGRAD_V2=1 (the
-fat-wave weight-gradient kernel wgrad8f.hip).  The switches are read once per process, so each case runs the relevant reference-golden
+fat-wave weight-gradient kernel wgrad8f.hip), r06: SATNERF_WGRAD_THIN=0 / SATNERF_WGRAD_NORAW=0.  The switches are read once per process, so each case runs the relevant reference-golden
 tests in a child interpreter with the variable set."""
 import os
 import subprocess
@@ -34,6 +34,16 @@ def test_hipcc_scheduled_training_forward_matches_the_gradient_goldens():
 @pytest.mark.gpu
 def test_fat_wave_weight_gradient_kernel_matches_the_gradient_goldens():
     _run({"SATNERF_WGRAD_V2": "1"}, "test_hip_backward.py", "gradients_match_reference_golden or direct_step_matches_autograd")
+
+
+@pytest.mark.gpu
+def test_full_streams_for_the_one_row_blocks_match_the_gradient_goldens():
+    """r06 A/B switches of the 4-wave weight-gradient kernel: SATNERF_WGRAD_THIN=0 (the head blocks on the full stream with equal slices, as
+    r05 ran them) and SATNERF_WGRAD_NORAW=0 (every full-stream wave runs its raw duty, dump or not): the paths the defaults replaced stay
+    correct -- the reference's gradient goldens and the benched-shape gates through each."""
+    _run({"SATNERF_WGRAD_THIN": "0"}, "test_hip_backward.py", "gradients_match_reference_golden or direct_step_matches_autograd")
+    _run({"SATNERF_WGRAD_NORAW": "0"}, "test_hip_backward.py", "gradients_match_reference_golden")
+    _run({"SATNERF_WGRAD_THIN": "0", "SATNERF_WGRAD_NORAW": "0"}, "test_hip_benched_shape.py", "bf16-256 or bf16-512")
 
 
 @pytest.mark.gpu
