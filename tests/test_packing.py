@@ -114,3 +114,63 @@ def test_pack_scatter_map_is_the_inverse_of_the_gather_maps(feat, tau):
     assert np.array_equal(got, want) and np.array_equal(got_l0, want_l0)
     live = (idx >= 0) & (scale != 0)
     assert np.array_equal(hits, live.astype(np.int32)) and np.array_equal(hits_l0, ((fm["l0_idx"] >= 0) & (fm["l0_scale"] != 0)).astype(np.int32))
+
+
+@pytest.mark.parametrize("feat", [256, 512])
+def test_duty_tables_of_the_weight_gradient_kernel_cover_every_operand_once(feat):
+    """packing.wgrad9_duties / wgrad9_variants (r06: thin streams for the one-row head blocks): in EVERY block each row and column fragment is
+    decoded by exactly one duty that its wave's stream executes, into the LDS fragment the MFMAs read it from; the raw fragment of a block with
+    a bf16 row sits on wave 0, the aux fragment on wave 1; a thin block is exactly a block whose row operand is one raw fragment over PHASE8
+    columns, and its variants hold the stream shapes gen/wgrad9_loop.py generates."""
+    import numpy as np
+
+    bm = packing.backward_maps(feat, 4)
+    auxs = bm["auxs"]
+    duties = packing.wgrad9_duties(feat, 4).reshape(-1, 4, 5, 4)
+    variants = packing.wgrad9_variants(feat, 4)
+    thin = packing.wgrad9_thin_blocks(feat, 4)
+    assert len(thin) == (2 if feat == 256 else 5)
+    for b, (rows, cols) in enumerate(zip(bm["block_rows"], bm["block_cols"])):
+        is_thin = b in thin
+        assert is_thin == bool(variants[b].any())
+        assert is_thin == (len(rows) == 1 and packing.dpre8_source(rows[0], feat)["codec"] == packing.RAW16 and bm["blocks"][b, 8] == packing.KIND_PHASE)
+        got = {}   # LDS fragment -> (source, unit) of the duty that fills it
+        for w in range(4):
+            v = int(variants[b, w])
+            n_df, raw = (4, True) if v == 0 else packing.WG9_THIN[v - 1][:2]
+            for k in list(range(n_df)) + ([4] if raw else []):
+                src, unit, dst, _ = (int(x) for x in duties[b, w, k])
+                if dst == packing.WG9_DUMP_FRAG:
+                    continue
+                assert dst not in got, (b, w, k, "two duties fill one fragment")
+                got[dst] = (src, unit)
+                if k < 4:
+                    assert dst % 2 == 0 and dst + 1 not in got   # a double fragment fills an even / odd pair
+                    if v:   # thin streams read every double fragment from the activation workspace
+                        assert src == packing.SRC_ACTS and dst >= 16
+        want = {}
+        pos = 0
+        while pos < len(rows):
+            d = packing.dpre8_source(rows[pos], feat)
+            want[pos] = (packing.SRC_DPRE, d["unit"])
+            pos += 1 if d["codec"] == packing.RAW16 else 2
+        pos = 0
+        while pos < len(cols):
+            want[16 + pos] = (packing.SRC_ACTS, packing.act8_source(cols[pos], auxs, feat)["unit"])
+            pos += 2
+        for a in range(auxs):
+            want[32 + a] = (packing.SRC_ACTS, a)
+        assert got == want, (b, sorted(set(got) ^ set(want)))
+        if any(packing.dpre8_source(r, feat)["codec"] == packing.RAW16 for r in rows):
+            assert int(duties[b, 0, 4, 0]) == packing.SRC_DPRE   # the bf16 row fragment: wave 0's raw duty
+        assert tuple(int(x) for x in duties[b, 1, 4][:3]) == (packing.SRC_ACTS, 0, 32)   # the aux fragment: wave 1's
+    # the thin variants are the shapes the generator emits, in the kernel's order
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("w9gen", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "satnerf_amd", "csrc", "gen", "wgrad9_loop.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert list(gen.THIN) == list(packing.WG9_THIN)
+    loads = packing.wgrad8_loads(feat, 4)
+    assert loads.shape[1] == packing.WG8_LOAD_INTS == 113 and np.array_equal(loads[:, 109:113], variants)
