@@ -105,6 +105,21 @@ def test_wgrad_plan_host_only(handle):
             assert thin == [12, 13] and (ns[thin] < ns[full].min()).all() and (ns[thin] >= 4).all()
             worst_full = -(-tiles // ns[full].min())
             assert all(0.25 * worst_full <= -(-tiles // ns[b]) * c <= 1.05 * worst_full for b, c in zip(thin, (0.5, 0.4)))
+    # width 512 (47 blocks, five of them thin): the cost-weighted split would leave 410-tile slices beside 342-tile ones, a stream-K plan gives
+    # every workgroup 376 tile units -- the plan takes whichever makespan is shorter (r06), here stream-K; SATNERF_WGRAD_STREAMK=0 forces weights
+    b512 = np.ascontiguousarray(packing.backward_maps(512, 4)["blocks"].copy())
+    n = ctypes.c_int(0)
+    assert handle.sr_wgrad_plan(b512.ctypes.data_as(ctypes.c_void_p), b512.shape[0], 65536, 256, 8, ctypes.byref(n)) == 0
+    assert int(b512[0, 11]) == -(-47 * 2048 // 256) and n.value <= 256 + 46
+    os.environ["SATNERF_WGRAD_STREAMK"] = "0"
+    try:
+        b512w = np.ascontiguousarray(packing.backward_maps(512, 4)["blocks"].copy())
+        assert handle.sr_wgrad_plan(b512w.ctypes.data_as(ctypes.c_void_p), b512w.shape[0], 65536, 256, 8, ctypes.byref(n)) == 0
+        thin512 = sorted(packing.wgrad9_thin_blocks(512, 4))
+        full512 = np.setdiff1d(np.arange(47), thin512)
+        assert int(b512w[0, 11]) == 0 and n.value == 256 and (b512w[thin512, 9] <= b512w[full512, 9].min()).all()
+    finally:
+        del os.environ["SATNERF_WGRAD_STREAMK"]
     bad = np.ascontiguousarray(blocks0.copy())
     bad[0, 1] = 17
     assert handle.sr_wgrad_plan(bad.ctypes.data_as(ctypes.c_void_p), bad.shape[0], 65536, 256, 16, ctypes.byref(n)) != 0
