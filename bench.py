@@ -81,7 +81,7 @@ def pmc_mfma_busy(kernel_key):
 
 def provenance():
     """What a stale `traffic` figure would be detected by: the git blob id of the committed PMC summary and the build time of the library
-    the kernels of this run came from (the PMC file is regenerated with every kernel change; tools/collect_profiles2.sh)."""
+    the kernels of this run came from (the PMC file is regenerated with every kernel change; tools/collect_profiles3.sh)."""
     import hashlib
 
     from satnerf_amd import _lib
